@@ -1,0 +1,284 @@
+/*
+ * raptor_quad.h — C ABI of the MI355X-native vectorised quadrotor rollout engine.
+ *
+ * This is the drop-in boundary for the rollout hot path of rl-tools/raptor.  Every entry
+ * point replaces one call site of the reference's Python/C++ surface (citations are
+ * /root/reference/README.md:<line>; "checkpoint.h:<line>" is the generated policy export
+ * inside data/raptor-policy-checkpoint.tar.gz):
+ *
+ *   reference call (README.md)                                   this ABI
+ *   -----------------------------------------------------------  ---------------------------------
+ *   l2f.Device()                                        :49      rq_device_create
+ *   vector.VectorRng()                                  :50      rq_rng_create
+ *   vector.VectorEnvironment()  (.N_ENVIRONMENTS,
+ *                                .OBSERVATION_DIM)      :51,55   rq_env_create / rq_env_num_envs / RQ_OBSERVATION_DIM
+ *   vector.VectorParameters()                           :53      rq_params_create
+ *   vector.VectorState()   (.states[i].position,
+ *                           .assign(), copy)            :54,56,73-75,99   rq_state_create / rq_state_assign / rq_state_{get,set}
+ *   vector.initialize_rng(device, rng, seed)            :58      rq_initialize_rng
+ *   vector.initialize_environment(device, env)          :59      rq_initialize_environment
+ *   vector.sample_initial_parameters(device, env,
+ *                                    params, rng)       :60      rq_sample_initial_parameters
+ *   vector.sample_initial_state(device, env, params,
+ *                               state, rng)             :61      rq_sample_initial_state
+ *   vector.observe(device, env, params, state,
+ *                  observation, rng)                    :96      rq_observe
+ *   vector.step(device, env, params, state, action,
+ *               next_state, rng) -> dts                 :98      rq_step
+ *   foundation_policy.Raptor()                          :20,48   rq_policy_create (+ rq_policy_load_weights)
+ *   Raptor.reset()                                      :21,94   rq_policy_reset
+ *   Raptor.evaluate_step(obs[B,22]) -> act[B,4]         :24,97   rq_policy_evaluate_step
+ *   the loop body README.md:95-99 x K                            rq_rollout  (fused or hipGraph-chained)
+ *   boot self-test of the embedded backend              :136-139,155   rq_policy_selftest
+ *   rl_tools_inference_applications_l2f_control(...)->status :163      convention: POD in/out, int status
+ *
+ * Conventions
+ *   - Every function returns an int status: RQ_OK (0) or a negative rq_status; the message of
+ *     the last failure on the calling thread is available from rq_last_error().  Nothing
+ *     throws across the boundary.
+ *   - Host buffers are caller-owned, C-contiguous float32, row-major [n_envs, dim] exactly as
+ *     the reference's NumPy arrays (README.md:55,92).  Passing NULL for an observation /
+ *     action pointer means "use the device-resident buffer of the env / policy" (no PCIe
+ *     traffic): the chain observe(NULL) -> evaluate_step(NULL,NULL) -> step(NULL) never
+ *     leaves HBM.
+ *   - One rq_device = one HIP device + one HIP stream.  Calls on objects of one rq_device are
+ *     not re-entrant; objects of different rq_devices are independent.  Calls that return
+ *     host data are synchronous w.r.t. that data; everything else is asynchronous on the
+ *     device stream (rq_device_synchronize waits).
+ *   - Batch size is a runtime value (the reference bakes it into the module name "vector8").
+ *   - Device data is struct-of-arrays, field-major: field f of env i lives at base[f*ld + i]
+ *     (ld = n_envs rounded up to 64), so a wavefront's 64 lanes read 256 contiguous bytes.
+ */
+#ifndef RAPTOR_QUAD_H
+#define RAPTOR_QUAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RQ_ABI_VERSION 1
+
+/* ---- sizes fixed by the checkpoint / observation spec ---------------------------------- */
+#define RQ_POLICY_INPUT_DIM 22   /* checkpoint.h:62  Shape<500,2,22>; README.md:23            */
+#define RQ_POLICY_HIDDEN_DIM 16  /* checkpoint.h:134 gru::Configuration<float,...,16,...>      */
+#define RQ_POLICY_OUTPUT_DIM 4   /* checkpoint.h:170,211                                        */
+#define RQ_POLICY_NUM_WEIGHTS 2084 /* W0[16,22] b0[16] Wi[48,16] Wh[48,16] bi[48] bh[48] h0[16] W2[4,16] b2[4] */
+#define RQ_ACTION_DIM 4          /* motor commands FR,BR,BL,FL in [-1,1]  (README.md:27)        */
+/* observation = policy-visible head (22) + privileged tail (4 normalised rotor speeds);
+ * the caller slices [:, :22] exactly as README.md:97 does. */
+#define RQ_OBSERVATION_DIM 26
+
+/* ---- per-env parameter fields (float32 each), SoA field index -------------------------- */
+enum rq_param_field {
+    RQ_P_MASS = 0,
+    RQ_P_JXX = 1, RQ_P_JYY = 2, RQ_P_JZZ = 3,   /* diagonal inertia, body frame [kg m^2]        */
+    RQ_P_ROTOR_POS = 4,                          /* 4 rotors x (x,y,z) body frame [m], 12 fields */
+    RQ_P_THRUST_C0 = 16, RQ_P_THRUST_C1 = 17, RQ_P_THRUST_C2 = 18, /* T = c0 + c1 r + c2 r^2 [N] */
+    RQ_P_TORQUE_CONST = 19,                      /* yaw reaction torque per unit thrust [m]      */
+    RQ_P_TAU_RISE = 20, RQ_P_TAU_FALL = 21,      /* first-order rotor time constants [s]         */
+    RQ_P_RPM_MIN = 22, RQ_P_RPM_MAX = 23,        /* action -1 / +1 map to these rotor speeds     */
+    RQ_P_HOVER_RPM = 24,                         /* rotor speed at which 4 T = m g               */
+    RQ_P_HOVER_ACTION = 25,                      /* the same, in normalised action units         */
+    RQ_PARAM_DIM = 26
+};
+
+/* ---- per-env state fields (float32 each), SoA field index ------------------------------ */
+enum rq_state_field {
+    RQ_S_POS = 0,        /* 3: position, world frame FLU [m]                                     */
+    RQ_S_QUAT = 3,       /* 4: orientation quaternion (w,x,y,z), body -> world                  */
+    RQ_S_VEL = 7,        /* 3: linear velocity, world frame [m/s]                                */
+    RQ_S_OMEGA = 10,     /* 3: angular velocity, body frame [rad/s]                              */
+    RQ_S_RPM = 13,       /* 4: rotor speeds                                                      */
+    RQ_S_LAST_ACTION = 17, /* 4: previous (clipped) action = ActionHistory(1)                    */
+    RQ_S_FORCE = 21,     /* 3: per-episode disturbance force, world frame [N]                    */
+    RQ_S_TORQUE = 24,    /* 3: per-episode disturbance torque, body frame [N m]                  */
+    RQ_STATE_DIM = 27
+};
+
+typedef enum rq_status {
+    RQ_OK = 0,
+    RQ_ERR_INVALID_ARGUMENT = -1,
+    RQ_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime failure at creation            */
+    RQ_ERR_HIP = -3,              /* a HIP call failed (message in rq_last_error)               */
+    RQ_ERR_OUT_OF_MEMORY = -4,
+    RQ_ERR_SHAPE_MISMATCH = -5,   /* objects belong to different envs / devices / batch sizes   */
+    RQ_ERR_NOT_INITIALIZED = -6,  /* e.g. observe before initialize_environment                 */
+    RQ_ERR_SELFTEST_FAILED = -7
+} rq_status;
+
+/* Static MDP configuration shared by all envs of a VectorEnvironment
+ * (what vector.initialize_environment fills, README.md:59).  Plain data; copied on set. */
+typedef struct rq_env_config {
+    uint32_t struct_size;               /* = sizeof(rq_env_config), checked on set              */
+    /* integration */
+    float dt;                           /* 0.01 s: "simulation dt=10 ms" README.md:25           */
+    float gravity;                      /* 9.81, acts along world -z                            */
+    uint32_t episode_step_limit;        /* 500: README.md:95, checkpoint.h:62                   */
+    /* per-env parameter sampling */
+    uint32_t domain_randomization;      /* 0: nominal Crazyflie for every env; 1: scaling law   */
+    float dr_scale_min, dr_scale_max;               /* length scale s ~ U[.,.] (0.5, 8)          */
+    float dr_thrust_to_weight_min, dr_thrust_to_weight_max; /* (1.5, 5)                          */
+    float dr_torque_const_min, dr_torque_const_max;         /* x s  (0.005, 0.03)                */
+    float dr_motor_tau_min, dr_motor_tau_max;               /* (0.03, 0.2) s                     */
+    /* initial-state sampling */
+    float init_guidance;                /* probability of the hover-at-origin state (0.1)       */
+    float init_max_position;            /* 0.5 m, per axis                                      */
+    float init_max_angle;               /* pi/2 rad about a uniform random axis                 */
+    float init_max_linear_velocity;     /* 1 m/s per axis                                       */
+    float init_max_angular_velocity;    /* 1 rad/s per axis                                     */
+    /* per-episode constant disturbances, std relative to m g (force) and m g * arm (torque)  */
+    float disturbance_force_std;        /* 0 = off                                              */
+    float disturbance_torque_std;       /* 0 = off                                              */
+    /* observation noise (std); all zero = no RNG draw */
+    float noise_position, noise_orientation, noise_linear_velocity, noise_angular_velocity;
+    /* reward = terminated ? termination_penalty : constant - scale * weighted cost */
+    float reward_scale, reward_constant, reward_termination_penalty;
+    float reward_position, reward_orientation, reward_linear_velocity,
+          reward_angular_velocity, reward_action;
+    /* termination: |p_i| > .., |v_i| > .., |w_i| > .. (any axis) or any non-finite state     */
+    uint32_t termination_enabled;
+    float termination_position, termination_linear_velocity, termination_angular_velocity;
+} rq_env_config;
+
+typedef struct rq_device rq_device;   /* l2f.Device                                             */
+typedef struct rq_rng rq_rng;         /* vector.VectorRng                                       */
+typedef struct rq_env rq_env;         /* vector.VectorEnvironment                               */
+typedef struct rq_params rq_params;   /* vector.VectorParameters                                */
+typedef struct rq_state rq_state;     /* vector.VectorState                                     */
+typedef struct rq_policy rq_policy;   /* foundation_policy.Raptor                               */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int rq_abi_version(void);
+const char* rq_last_error(void);
+const char* rq_status_string(int status);
+int rq_device_count(int* count);
+
+/* ---- Device (README.md:49) ------------------------------------------------------------- */
+int rq_device_create(int hip_device_ordinal, rq_device** out);
+int rq_device_destroy(rq_device* dev);
+int rq_device_synchronize(rq_device* dev);
+/* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
+int rq_device_timer_start(rq_device* dev);
+int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
+/* raw hipStream_t of the device, for callers that enqueue their own work behind ours */
+int rq_device_stream(rq_device* dev, void** hip_stream);
+
+/* ---- Rng (README.md:50,58) -------------------------------------------------------------
+ * Counter-based Philox4x32-10: key = seed, counter = (block, epoch|episode, GLOBAL env id,
+ * purpose).  Results depend only on (seed, global env id, call history), never on how envs
+ * are sharded over devices. */
+int rq_rng_create(rq_device* dev, rq_rng** out);
+int rq_rng_destroy(rq_rng* rng);
+int rq_initialize_rng(rq_device* dev, rq_rng* rng, uint64_t seed);
+int rq_rng_get(const rq_rng* rng, uint64_t* seed, uint32_t* epoch);
+int rq_rng_set_epoch(rq_rng* rng, uint32_t epoch);
+
+/* ---- Environment (README.md:51,59) ----------------------------------------------------- */
+/* n_envs envs whose global ids are [global_env_offset, global_env_offset + n_envs). */
+int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_offset, rq_env** out);
+int rq_env_destroy(rq_env* env);
+int rq_env_num_envs(const rq_env* env, uint32_t* n_envs);
+int rq_env_leading_dim(const rq_env* env, uint32_t* ld);
+int rq_env_default_config(rq_env_config* cfg);                 /* fills the documented defaults */
+int rq_initialize_environment(rq_device* dev, rq_env* env);    /* = set default config          */
+int rq_env_set_config(rq_env* env, const rq_env_config* cfg);
+int rq_env_get_config(const rq_env* env, rq_env_config* cfg);
+
+/* ---- Parameters / State containers (README.md:53,54,56,99) ---------------------------- */
+int rq_params_create(rq_env* env, rq_params** out);
+int rq_params_destroy(rq_params* p);
+/* host copies are row-major [n_envs, RQ_PARAM_DIM] */
+int rq_params_get(const rq_params* p, float* host_out);
+int rq_params_set(rq_params* p, const float* host_in);
+int rq_params_device_ptr(const rq_params* p, float** dev_ptr); /* SoA base, ld = env ld        */
+
+int rq_state_create(rq_env* env, rq_state** out);
+int rq_state_destroy(rq_state* s);
+int rq_state_assign(rq_state* dst, const rq_state* src);       /* state.assign(next_state)      */
+int rq_state_get(const rq_state* s, float* host_out);          /* [n_envs, RQ_STATE_DIM]        */
+int rq_state_set(rq_state* s, const float* host_in);
+int rq_state_device_ptr(const rq_state* s, float** dev_ptr);
+
+/* ---- the five l2f vector:: functions (README.md:60,61,96,98) --------------------------- */
+int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* params, rq_rng* rng);
+int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params* params,
+                            rq_state* state, rq_rng* rng);
+/* observation: host [n_envs, RQ_OBSERVATION_DIM] or NULL (stay in the env's device buffer) */
+int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state,
+               float* observation, rq_rng* rng);
+/* action: host [n_envs, RQ_ACTION_DIM] or NULL (= the env's device action buffer, which
+ * rq_policy_evaluate_step(obs=NULL, act=NULL) fills).  dts: host [n_envs] or NULL.
+ * Also evaluates reward and termination of the transition into the env's episode
+ * statistics (see rq_env_get_*). state and next_state may be the same object. */
+int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state,
+            const float* action, rq_state* next_state, rq_rng* rng, float* dts);
+
+/* device-resident observation [RQ_OBSERVATION_DIM][ld] and action [RQ_ACTION_DIM][ld] */
+int rq_env_observation_device_ptr(const rq_env* env, float** dev_ptr);
+int rq_env_action_device_ptr(const rq_env* env, float** dev_ptr);
+int rq_env_get_observation(const rq_env* env, float* host_out); /* [n_envs, RQ_OBSERVATION_DIM] */
+int rq_env_get_action(const rq_env* env, float* host_out);      /* [n_envs, RQ_ACTION_DIM]      */
+int rq_env_set_action(rq_env* env, const float* host_in);
+
+/* ---- episode statistics (reward / termination of transitions taken by rq_step/rq_rollout) */
+/* dst_is_device != 0: dst is a device pointer on the same HIP device (e.g. a torch tensor's
+ * data_ptr()), copied on the env's stream and synchronised before return. */
+int rq_env_get_rewards(const rq_env* env, float* dst, int dst_is_device);          /* last transition */
+int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dst_is_device);     /* last transition */
+int rq_env_get_returns(const rq_env* env, float* dst, int dst_is_device);          /* running episode */
+int rq_env_get_episode_steps(const rq_env* env, uint32_t* dst, int dst_is_device);
+int rq_env_get_finished_returns(const rq_env* env, float* dst, int dst_is_device); /* last finished episode */
+int rq_env_get_finished_lengths(const rq_env* env, uint32_t* dst, int dst_is_device);
+int rq_env_get_finished_counts(const rq_env* env, uint32_t* dst, int dst_is_device); /* #episodes finished */
+int rq_env_get_finished_terminated(const rq_env* env, uint32_t* dst, int dst_is_device); /* #of those that terminated */
+int rq_env_reset_statistics(rq_env* env);
+
+/* ---- Policy (README.md:19-24,48,94,97; checkpoint.h:34-194) ---------------------------- */
+typedef enum rq_policy_precision {
+    RQ_POLICY_FP32 = 0,       /* fp32 VALU, weights broadcast from LDS                         */
+    RQ_POLICY_BF16_MFMA = 1   /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates */
+} rq_policy_precision;
+
+/* weights: RQ_POLICY_NUM_WEIGHTS float32 in the order documented at RQ_POLICY_NUM_WEIGHTS
+ * (the order of checkpoint.h:39,50,75,87,99,111,123,149,160). */
+int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out);
+int rq_policy_destroy(rq_policy* pol);
+int rq_policy_set_precision(rq_policy* pol, int precision);
+/* hidden state h[B,16] <- initial_hidden_state (checkpoint.h:123); sized on first use */
+int rq_policy_reset(rq_policy* pol);
+/* One recurrent step for a batch.  observation: host [batch, obs_stride] (first 22 columns
+ * used, obs_stride >= 22) -> action host [batch, 4]; output is the raw Dense output (not
+ * squashed/clipped, checkpoint.h:170 IDENTITY).  With env != NULL and observation == NULL the
+ * env's device observation buffer is read; with action == NULL the env's device action
+ * buffer is written. batch must stay constant between resets. */
+int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* observation,
+                            uint32_t batch, uint32_t obs_stride, float* action);
+int rq_policy_get_hidden(const rq_policy* pol, float* host_out, uint32_t batch); /* [batch,16] */
+int rq_policy_set_hidden(rq_policy* pol, const float* host_in, uint32_t batch);
+/* Known-answer self-test (README.md:136-139): runs `steps` x `batch` of a [steps,batch,22]
+ * input through reset()+evaluate_step and reports max |out - expected|. */
+int rq_policy_selftest(rq_policy* pol, const float* input, const float* expected,
+                       uint32_t steps, uint32_t batch, float tolerance, float* max_abs_err);
+
+/* ---- Rollout: the loop body README.md:95-99, K times, on device ------------------------ */
+typedef enum rq_rollout_mode {
+    RQ_ROLLOUT_FUSED = 0,   /* one persistent kernel: state + hidden stay in registers for K steps */
+    RQ_ROLLOUT_CHAINED = 1  /* observe -> evaluate_step -> step kernels, K x 3 launches (hipGraph)   */
+} rq_rollout_mode;
+
+enum rq_rollout_flags {
+    RQ_ROLLOUT_AUTORESET = 1u  /* an env whose episode ends (terminated or step limit) is
+                                  re-sampled in place (sample_initial_state + policy reset for
+                                  that env) and keeps stepping; otherwise it freezes. */
+};
+
+int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,
+               rq_policy* policy, rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAPTOR_QUAD_H */
