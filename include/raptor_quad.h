@@ -61,6 +61,12 @@ extern "C" {
 
 #define RQ_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define RQ_API __attribute__((visibility("default")))
+#else
+#define RQ_API
+#endif
+
 /* ---- sizes fixed by the checkpoint / observation spec ---------------------------------- */
 #define RQ_POLICY_INPUT_DIM 22   /* checkpoint.h:62  Shape<500,2,22>; README.md:23            */
 #define RQ_POLICY_HIDDEN_DIM 16  /* checkpoint.h:134 gru::Configuration<float,...,16,...>      */
@@ -151,90 +157,90 @@ typedef struct rq_state rq_state;     /* vector.VectorState                     
 typedef struct rq_policy rq_policy;   /* foundation_policy.Raptor                               */
 
 /* ---- library ---------------------------------------------------------------------------- */
-int rq_abi_version(void);
-const char* rq_last_error(void);
-const char* rq_status_string(int status);
-int rq_device_count(int* count);
+RQ_API int rq_abi_version(void);
+RQ_API const char* rq_last_error(void);
+RQ_API const char* rq_status_string(int status);
+RQ_API int rq_device_count(int* count);
 
 /* ---- Device (README.md:49) ------------------------------------------------------------- */
-int rq_device_create(int hip_device_ordinal, rq_device** out);
-int rq_device_destroy(rq_device* dev);
-int rq_device_synchronize(rq_device* dev);
+RQ_API int rq_device_create(int hip_device_ordinal, rq_device** out);
+RQ_API int rq_device_destroy(rq_device* dev);
+RQ_API int rq_device_synchronize(rq_device* dev);
 /* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
-int rq_device_timer_start(rq_device* dev);
-int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
+RQ_API int rq_device_timer_start(rq_device* dev);
+RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
 /* raw hipStream_t of the device, for callers that enqueue their own work behind ours */
-int rq_device_stream(rq_device* dev, void** hip_stream);
+RQ_API int rq_device_stream(rq_device* dev, void** hip_stream);
 
 /* ---- Rng (README.md:50,58) -------------------------------------------------------------
  * Counter-based Philox4x32-10: key = seed, counter = (block, epoch|episode, GLOBAL env id,
  * purpose).  Results depend only on (seed, global env id, call history), never on how envs
  * are sharded over devices. */
-int rq_rng_create(rq_device* dev, rq_rng** out);
-int rq_rng_destroy(rq_rng* rng);
-int rq_initialize_rng(rq_device* dev, rq_rng* rng, uint64_t seed);
-int rq_rng_get(const rq_rng* rng, uint64_t* seed, uint32_t* epoch);
-int rq_rng_set_epoch(rq_rng* rng, uint32_t epoch);
+RQ_API int rq_rng_create(rq_device* dev, rq_rng** out);
+RQ_API int rq_rng_destroy(rq_rng* rng);
+RQ_API int rq_initialize_rng(rq_device* dev, rq_rng* rng, uint64_t seed);
+RQ_API int rq_rng_get(const rq_rng* rng, uint64_t* seed, uint32_t* epoch);
+RQ_API int rq_rng_set_epoch(rq_rng* rng, uint32_t epoch);
 
 /* ---- Environment (README.md:51,59) ----------------------------------------------------- */
 /* n_envs envs whose global ids are [global_env_offset, global_env_offset + n_envs). */
-int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_offset, rq_env** out);
-int rq_env_destroy(rq_env* env);
-int rq_env_num_envs(const rq_env* env, uint32_t* n_envs);
-int rq_env_leading_dim(const rq_env* env, uint32_t* ld);
-int rq_env_default_config(rq_env_config* cfg);                 /* fills the documented defaults */
-int rq_initialize_environment(rq_device* dev, rq_env* env);    /* = set default config          */
-int rq_env_set_config(rq_env* env, const rq_env_config* cfg);
-int rq_env_get_config(const rq_env* env, rq_env_config* cfg);
+RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_offset, rq_env** out);
+RQ_API int rq_env_destroy(rq_env* env);
+RQ_API int rq_env_num_envs(const rq_env* env, uint32_t* n_envs);
+RQ_API int rq_env_leading_dim(const rq_env* env, uint32_t* ld);
+RQ_API int rq_env_default_config(rq_env_config* cfg);                 /* fills the documented defaults */
+RQ_API int rq_initialize_environment(rq_device* dev, rq_env* env);    /* = set default config          */
+RQ_API int rq_env_set_config(rq_env* env, const rq_env_config* cfg);
+RQ_API int rq_env_get_config(const rq_env* env, rq_env_config* cfg);
 
 /* ---- Parameters / State containers (README.md:53,54,56,99) ---------------------------- */
-int rq_params_create(rq_env* env, rq_params** out);
-int rq_params_destroy(rq_params* p);
+RQ_API int rq_params_create(rq_env* env, rq_params** out);
+RQ_API int rq_params_destroy(rq_params* p);
 /* host copies are row-major [n_envs, RQ_PARAM_DIM] */
-int rq_params_get(const rq_params* p, float* host_out);
-int rq_params_set(rq_params* p, const float* host_in);
-int rq_params_device_ptr(const rq_params* p, float** dev_ptr); /* SoA base, ld = env ld        */
+RQ_API int rq_params_get(const rq_params* p, float* host_out);
+RQ_API int rq_params_set(rq_params* p, const float* host_in);
+RQ_API int rq_params_device_ptr(const rq_params* p, float** dev_ptr); /* SoA base, ld = env ld        */
 
-int rq_state_create(rq_env* env, rq_state** out);
-int rq_state_destroy(rq_state* s);
-int rq_state_assign(rq_state* dst, const rq_state* src);       /* state.assign(next_state)      */
-int rq_state_get(const rq_state* s, float* host_out);          /* [n_envs, RQ_STATE_DIM]        */
-int rq_state_set(rq_state* s, const float* host_in);
-int rq_state_device_ptr(const rq_state* s, float** dev_ptr);
+RQ_API int rq_state_create(rq_env* env, rq_state** out);
+RQ_API int rq_state_destroy(rq_state* s);
+RQ_API int rq_state_assign(rq_state* dst, const rq_state* src);       /* state.assign(next_state)      */
+RQ_API int rq_state_get(const rq_state* s, float* host_out);          /* [n_envs, RQ_STATE_DIM]        */
+RQ_API int rq_state_set(rq_state* s, const float* host_in);
+RQ_API int rq_state_device_ptr(const rq_state* s, float** dev_ptr);
 
 /* ---- the five l2f vector:: functions (README.md:60,61,96,98) --------------------------- */
-int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* params, rq_rng* rng);
-int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params* params,
+RQ_API int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* params, rq_rng* rng);
+RQ_API int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params* params,
                             rq_state* state, rq_rng* rng);
 /* observation: host [n_envs, RQ_OBSERVATION_DIM] or NULL (stay in the env's device buffer) */
-int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state,
+RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state,
                float* observation, rq_rng* rng);
 /* action: host [n_envs, RQ_ACTION_DIM] or NULL (= the env's device action buffer, which
  * rq_policy_evaluate_step(obs=NULL, act=NULL) fills).  dts: host [n_envs] or NULL.
  * Also evaluates reward and termination of the transition into the env's episode
  * statistics (see rq_env_get_*). state and next_state may be the same object. */
-int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state,
+RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state,
             const float* action, rq_state* next_state, rq_rng* rng, float* dts);
 
 /* device-resident observation [RQ_OBSERVATION_DIM][ld] and action [RQ_ACTION_DIM][ld] */
-int rq_env_observation_device_ptr(const rq_env* env, float** dev_ptr);
-int rq_env_action_device_ptr(const rq_env* env, float** dev_ptr);
-int rq_env_get_observation(const rq_env* env, float* host_out); /* [n_envs, RQ_OBSERVATION_DIM] */
-int rq_env_get_action(const rq_env* env, float* host_out);      /* [n_envs, RQ_ACTION_DIM]      */
-int rq_env_set_action(rq_env* env, const float* host_in);
+RQ_API int rq_env_observation_device_ptr(const rq_env* env, float** dev_ptr);
+RQ_API int rq_env_action_device_ptr(const rq_env* env, float** dev_ptr);
+RQ_API int rq_env_get_observation(const rq_env* env, float* host_out); /* [n_envs, RQ_OBSERVATION_DIM] */
+RQ_API int rq_env_get_action(const rq_env* env, float* host_out);      /* [n_envs, RQ_ACTION_DIM]      */
+RQ_API int rq_env_set_action(rq_env* env, const float* host_in);
 
 /* ---- episode statistics (reward / termination of transitions taken by rq_step/rq_rollout) */
 /* dst_is_device != 0: dst is a device pointer on the same HIP device (e.g. a torch tensor's
  * data_ptr()), copied on the env's stream and synchronised before return. */
-int rq_env_get_rewards(const rq_env* env, float* dst, int dst_is_device);          /* last transition */
-int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dst_is_device);     /* last transition */
-int rq_env_get_returns(const rq_env* env, float* dst, int dst_is_device);          /* running episode */
-int rq_env_get_episode_steps(const rq_env* env, uint32_t* dst, int dst_is_device);
-int rq_env_get_finished_returns(const rq_env* env, float* dst, int dst_is_device); /* last finished episode */
-int rq_env_get_finished_lengths(const rq_env* env, uint32_t* dst, int dst_is_device);
-int rq_env_get_finished_counts(const rq_env* env, uint32_t* dst, int dst_is_device); /* #episodes finished */
-int rq_env_get_finished_terminated(const rq_env* env, uint32_t* dst, int dst_is_device); /* #of those that terminated */
-int rq_env_reset_statistics(rq_env* env);
+RQ_API int rq_env_get_rewards(const rq_env* env, float* dst, int dst_is_device);          /* last transition */
+RQ_API int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dst_is_device);     /* last transition */
+RQ_API int rq_env_get_returns(const rq_env* env, float* dst, int dst_is_device);          /* running episode */
+RQ_API int rq_env_get_episode_steps(const rq_env* env, uint32_t* dst, int dst_is_device);
+RQ_API int rq_env_get_finished_returns(const rq_env* env, float* dst, int dst_is_device); /* last finished episode */
+RQ_API int rq_env_get_finished_lengths(const rq_env* env, uint32_t* dst, int dst_is_device);
+RQ_API int rq_env_get_finished_counts(const rq_env* env, uint32_t* dst, int dst_is_device); /* #episodes finished */
+RQ_API int rq_env_get_finished_terminated(const rq_env* env, uint32_t* dst, int dst_is_device); /* #of those that terminated */
+RQ_API int rq_env_reset_statistics(rq_env* env);
 
 /* ---- Policy (README.md:19-24,48,94,97; checkpoint.h:34-194) ---------------------------- */
 typedef enum rq_policy_precision {
@@ -244,23 +250,23 @@ typedef enum rq_policy_precision {
 
 /* weights: RQ_POLICY_NUM_WEIGHTS float32 in the order documented at RQ_POLICY_NUM_WEIGHTS
  * (the order of checkpoint.h:39,50,75,87,99,111,123,149,160). */
-int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out);
-int rq_policy_destroy(rq_policy* pol);
-int rq_policy_set_precision(rq_policy* pol, int precision);
+RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out);
+RQ_API int rq_policy_destroy(rq_policy* pol);
+RQ_API int rq_policy_set_precision(rq_policy* pol, int precision);
 /* hidden state h[B,16] <- initial_hidden_state (checkpoint.h:123); sized on first use */
-int rq_policy_reset(rq_policy* pol);
+RQ_API int rq_policy_reset(rq_policy* pol);
 /* One recurrent step for a batch.  observation: host [batch, obs_stride] (first 22 columns
  * used, obs_stride >= 22) -> action host [batch, 4]; output is the raw Dense output (not
  * squashed/clipped, checkpoint.h:170 IDENTITY).  With env != NULL and observation == NULL the
  * env's device observation buffer is read; with action == NULL the env's device action
  * buffer is written. batch must stay constant between resets. */
-int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* observation,
+RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* observation,
                             uint32_t batch, uint32_t obs_stride, float* action);
-int rq_policy_get_hidden(const rq_policy* pol, float* host_out, uint32_t batch); /* [batch,16] */
-int rq_policy_set_hidden(rq_policy* pol, const float* host_in, uint32_t batch);
+RQ_API int rq_policy_get_hidden(const rq_policy* pol, float* host_out, uint32_t batch); /* [batch,16] */
+RQ_API int rq_policy_set_hidden(rq_policy* pol, const float* host_in, uint32_t batch);
 /* Known-answer self-test (README.md:136-139): runs `steps` x `batch` of a [steps,batch,22]
  * input through reset()+evaluate_step and reports max |out - expected|. */
-int rq_policy_selftest(rq_policy* pol, const float* input, const float* expected,
+RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* expected,
                        uint32_t steps, uint32_t batch, float tolerance, float* max_abs_err);
 
 /* ---- Rollout: the loop body README.md:95-99, K times, on device ------------------------ */
@@ -275,7 +281,7 @@ enum rq_rollout_flags {
                                   that env) and keeps stepping; otherwise it freezes. */
 };
 
-int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,
+RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,
                rq_policy* policy, rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags);
 
 #ifdef __cplusplus

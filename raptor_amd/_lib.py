@@ -1,0 +1,168 @@
+"""ctypes binding of libraptor_quad.so (the C ABI declared in include/raptor_quad.h).
+
+The library is the product: there is no Python/NumPy/torch fallback.  If the shared object
+is missing or no HIP device is present the calls fail loudly (``RaptorQuadError``).
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libraptor_quad.so")
+
+POLICY_INPUT_DIM = 22
+POLICY_HIDDEN_DIM = 16
+POLICY_OUTPUT_DIM = 4
+POLICY_NUM_WEIGHTS = 2084
+ACTION_DIM = 4
+OBSERVATION_DIM = 26
+PARAM_DIM = 26
+STATE_DIM = 27
+
+ROLLOUT_FUSED, ROLLOUT_CHAINED = 0, 1
+ROLLOUT_AUTORESET = 1
+POLICY_FP32, POLICY_BF16_MFMA = 0, 1
+
+
+class RaptorQuadError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libraptor_quad status {status}: {message}")
+        self.status = status
+
+
+class EnvConfig(C.Structure):
+    """``rq_env_config`` (include/raptor_quad.h) — what vector.initialize_environment fills."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("dt", C.c_float), ("gravity", C.c_float), ("episode_step_limit", C.c_uint32),
+        ("domain_randomization", C.c_uint32),
+        ("dr_scale_min", C.c_float), ("dr_scale_max", C.c_float),
+        ("dr_thrust_to_weight_min", C.c_float), ("dr_thrust_to_weight_max", C.c_float),
+        ("dr_torque_const_min", C.c_float), ("dr_torque_const_max", C.c_float),
+        ("dr_motor_tau_min", C.c_float), ("dr_motor_tau_max", C.c_float),
+        ("init_guidance", C.c_float), ("init_max_position", C.c_float), ("init_max_angle", C.c_float),
+        ("init_max_linear_velocity", C.c_float), ("init_max_angular_velocity", C.c_float),
+        ("disturbance_force_std", C.c_float), ("disturbance_torque_std", C.c_float),
+        ("noise_position", C.c_float), ("noise_orientation", C.c_float),
+        ("noise_linear_velocity", C.c_float), ("noise_angular_velocity", C.c_float),
+        ("reward_scale", C.c_float), ("reward_constant", C.c_float),
+        ("reward_termination_penalty", C.c_float),
+        ("reward_position", C.c_float), ("reward_orientation", C.c_float),
+        ("reward_linear_velocity", C.c_float), ("reward_angular_velocity", C.c_float),
+        ("reward_action", C.c_float),
+        ("termination_enabled", C.c_uint32),
+        ("termination_position", C.c_float), ("termination_linear_velocity", C.c_float),
+        ("termination_angular_velocity", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_vp = C.c_void_p
+_fp = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+
+# name -> argtypes (every function returns int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "rq_abi_version": [],
+    "rq_last_error": [],
+    "rq_status_string": [C.c_int],
+    "rq_device_count": [C.POINTER(C.c_int)],
+    "rq_device_create": [C.c_int, C.POINTER(_vp)],
+    "rq_device_destroy": [_vp],
+    "rq_device_synchronize": [_vp],
+    "rq_device_timer_start": [_vp],
+    "rq_device_timer_stop": [_vp, _fp],
+    "rq_device_stream": [_vp, C.POINTER(_vp)],
+    "rq_rng_create": [_vp, C.POINTER(_vp)],
+    "rq_rng_destroy": [_vp],
+    "rq_initialize_rng": [_vp, _vp, C.c_uint64],
+    "rq_rng_get": [_vp, C.POINTER(C.c_uint64), _u32p],
+    "rq_rng_set_epoch": [_vp, C.c_uint32],
+    "rq_env_create": [_vp, C.c_uint32, C.c_uint64, C.POINTER(_vp)],
+    "rq_env_destroy": [_vp],
+    "rq_env_num_envs": [_vp, _u32p],
+    "rq_env_leading_dim": [_vp, _u32p],
+    "rq_env_default_config": [C.POINTER(EnvConfig)],
+    "rq_initialize_environment": [_vp, _vp],
+    "rq_env_set_config": [_vp, C.POINTER(EnvConfig)],
+    "rq_env_get_config": [_vp, C.POINTER(EnvConfig)],
+    "rq_params_create": [_vp, C.POINTER(_vp)],
+    "rq_params_destroy": [_vp],
+    "rq_params_get": [_vp, _fp],
+    "rq_params_set": [_vp, _fp],
+    "rq_params_device_ptr": [_vp, C.POINTER(_vp)],
+    "rq_state_create": [_vp, C.POINTER(_vp)],
+    "rq_state_destroy": [_vp],
+    "rq_state_assign": [_vp, _vp],
+    "rq_state_get": [_vp, _fp],
+    "rq_state_set": [_vp, _fp],
+    "rq_state_device_ptr": [_vp, C.POINTER(_vp)],
+    "rq_sample_initial_parameters": [_vp, _vp, _vp, _vp],
+    "rq_sample_initial_state": [_vp, _vp, _vp, _vp, _vp],
+    "rq_observe": [_vp, _vp, _vp, _vp, _fp, _vp],
+    "rq_step": [_vp, _vp, _vp, _vp, _fp, _vp, _vp, _fp],
+    "rq_env_observation_device_ptr": [_vp, C.POINTER(_vp)],
+    "rq_env_action_device_ptr": [_vp, C.POINTER(_vp)],
+    "rq_env_get_observation": [_vp, _fp],
+    "rq_env_get_action": [_vp, _fp],
+    "rq_env_set_action": [_vp, _fp],
+    "rq_env_get_rewards": [_vp, _vp, C.c_int],
+    "rq_env_get_terminated": [_vp, _vp, C.c_int],
+    "rq_env_get_returns": [_vp, _vp, C.c_int],
+    "rq_env_get_episode_steps": [_vp, _vp, C.c_int],
+    "rq_env_get_finished_returns": [_vp, _vp, C.c_int],
+    "rq_env_get_finished_lengths": [_vp, _vp, C.c_int],
+    "rq_env_get_finished_counts": [_vp, _vp, C.c_int],
+    "rq_env_get_finished_terminated": [_vp, _vp, C.c_int],
+    "rq_env_reset_statistics": [_vp],
+    "rq_policy_create": [_vp, _fp, C.c_size_t, C.POINTER(_vp)],
+    "rq_policy_destroy": [_vp],
+    "rq_policy_set_precision": [_vp, C.c_int],
+    "rq_policy_reset": [_vp],
+    "rq_policy_evaluate_step": [_vp, _vp, _fp, C.c_uint32, C.c_uint32, _fp],
+    "rq_policy_get_hidden": [_vp, _fp, C.c_uint32],
+    "rq_policy_set_hidden": [_vp, _fp, C.c_uint32],
+    "rq_policy_selftest": [_vp, _fp, _fp, C.c_uint32, C.c_uint32, C.c_float, _fp],
+    "rq_rollout": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32],
+}
+_RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libraptor_quad.so (built in-tree by ``python -m raptor_amd.build``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RaptorQuadError(-2, f"{LIB_PATH} is missing: run `python -m raptor_amd.build` "
+                                      "(there is no fallback implementation)")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        if lib.rq_abi_version() != 1:
+            raise RaptorQuadError(-1, "ABI version mismatch between raptor_amd and libraptor_quad.so")
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().rq_last_error()
+        raise RaptorQuadError(status, msg.decode() if msg else "")
+    return status
+
+
+def call(name, *args):
+    return check(getattr(load(), name)(*args))
+
+
+def fptr(a):
+    """float32 C-contiguous numpy array -> float*"""
+    return a.ctypes.data_as(_fp)

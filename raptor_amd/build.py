@@ -1,0 +1,73 @@
+"""In-tree build of libraptor_quad.so (hipcc, gfx950 only).
+
+    python -m raptor_amd.build            # incremental
+    python -m raptor_amd.build --force
+
+hipcc cross-compiles without a GPU; the resulting .so sits next to this file so it travels
+with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(PKG, "libraptor_quad.so")
+
+ARCH = "gfx950"
+# -ffp-contract=off: only explicit fmaf() calls fuse (DESIGN.md "Arithmetic contract")
+DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
+                "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+SOURCES = ["rq_kernels.hip", "rq_capi.cpp"]
+HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libraptor_quad.so cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    deps = [os.path.join(CSRC, src)] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(obj, deps):
+        return obj, False
+    cmd = [_hipcc()] + DEVICE_FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in results]
+    if force or any(c for _, c in results) or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,763 @@
+// rq_capi.cpp — C-ABI host layer of libraptor_quad.so (see include/raptor_quad.h).
+//
+// Host side of the rollout path in C++ (the reference's host side is C++: rl-tools / l2f,
+// with pybind11 bindings; README.md:33,110-165).  Owns device memory (struct-of-arrays,
+// field-major), one HIP stream per rq_device, and launches the kernels of rq_kernels.hip.
+// There is NO CPU fallback: without a HIP device rq_device_create fails with RQ_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/raptor_quad.h"
+#include "rq_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string& msg) {
+    g_last_error = msg;
+    return status;
+}
+
+#define RQ_REQUIRE(cond, status, msg)                                             \
+    do {                                                                          \
+        if (!(cond)) return fail((status), std::string(__func__) + ": " + (msg)); \
+    } while (0)
+
+#define RQ_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? RQ_ERR_OUT_OF_MEMORY : RQ_ERR_HIP,            \
+                        std::string(__func__) + ": " #expr " -> " + hipGetErrorString(e_));      \
+    } while (0)
+
+inline uint32_t round_up64(uint32_t n) { return (n + 63u) & ~63u; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- objects ---
+struct rq_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    void* staging = nullptr;       // pinned host buffer for transposing copies
+    size_t staging_bytes = 0;
+};
+
+struct rq_rng {
+    rq_device* dev = nullptr;
+    uint64_t seed = 0;
+    uint32_t epoch = 0;        // observation-noise counter: +1 per observe / per rollout step
+    uint32_t param_epoch = 0;  // +1 per sample_initial_parameters
+    bool initialized = false;
+};
+
+struct rq_env {
+    rq_device* dev = nullptr;
+    uint32_t n = 0, ld = 0;
+    uint64_t offset = 0;
+    rq_env_config cfg{};
+    bool initialized = false;
+    float* obs = nullptr;       // [RQ_OBSERVATION_DIM][ld]
+    float* act = nullptr;       // [RQ_ACTION_DIM][ld]
+    void* stats_block = nullptr;
+    rq::StatsPtrs st{};
+};
+
+struct rq_params { rq_env* env = nullptr; float* d = nullptr; };
+struct rq_state { rq_env* env = nullptr; float* d = nullptr; };
+
+struct rq_policy {
+    rq_device* dev = nullptr;
+    float* w_dev = nullptr;
+    float w_host[RQ_POLICY_NUM_WEIGHTS];
+    int precision = RQ_POLICY_FP32;
+    uint32_t batch = 0, ld = 0;   // 0 = not sized yet
+    bool needs_reset = true;      // hidden must be (re)filled with initial_hidden_state before use
+    float* hidden = nullptr;      // [16][ld]
+    float* obs = nullptr;         // [22][ld] staging for host observations
+    float* act = nullptr;         // [4][ld]
+};
+
+namespace {
+
+int set_device(const rq_device* dev) {
+    RQ_HIP(hipSetDevice(dev->ordinal));
+    return RQ_OK;
+}
+
+int ensure_staging(rq_device* dev, size_t bytes) {
+    if (dev->staging_bytes >= bytes) return RQ_OK;
+    if (dev->staging) { RQ_HIP(hipHostFree(dev->staging)); dev->staging = nullptr; dev->staging_bytes = 0; }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    RQ_HIP(hipHostMalloc(&dev->staging, want, hipHostMallocDefault));
+    dev->staging_bytes = want;
+    return RQ_OK;
+}
+
+// device SoA [dim][ld] -> host row-major [n][dim]
+int soa_to_host(rq_device* dev, const float* d_soa, uint32_t n, uint32_t ld, uint32_t dim, float* host) {
+    int rc = set_device(dev); if (rc) return rc;
+    const size_t bytes = (size_t)dim * ld * sizeof(float);
+    rc = ensure_staging(dev, bytes); if (rc) return rc;
+    RQ_HIP(hipMemcpyAsync(dev->staging, d_soa, bytes, hipMemcpyDeviceToHost, dev->stream));
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    const float* s = static_cast<const float*>(dev->staging);
+    for (uint32_t f = 0; f < dim; ++f) {
+        const float* col = s + (size_t)f * ld;
+        for (uint32_t i = 0; i < n; ++i) host[(size_t)i * dim + f] = col[i];
+    }
+    return RQ_OK;
+}
+
+// host row-major [n][stride] (first dim columns) -> device SoA [dim][ld]; padding lanes zeroed
+int host_to_soa(rq_device* dev, const float* host, uint32_t n, uint32_t stride, uint32_t ld, uint32_t dim,
+                float* d_soa) {
+    int rc = set_device(dev); if (rc) return rc;
+    const size_t bytes = (size_t)dim * ld * sizeof(float);
+    rc = ensure_staging(dev, bytes); if (rc) return rc;
+    // the previous async copy out of the staging buffer must have completed
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    float* s = static_cast<float*>(dev->staging);
+    for (uint32_t f = 0; f < dim; ++f) {
+        float* col = s + (size_t)f * ld;
+        for (uint32_t i = 0; i < n; ++i) col[i] = host[(size_t)i * stride + f];
+        for (uint32_t i = n; i < ld; ++i) col[i] = 0.0f;
+    }
+    RQ_HIP(hipMemcpyAsync(d_soa, dev->staging, bytes, hipMemcpyHostToDevice, dev->stream));
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    return RQ_OK;
+}
+
+template <typename T>
+int copy_out(const rq_env* env, const T* src, T* dst, int dst_is_device) {
+    RQ_REQUIRE(env && dst, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(env->dev); if (rc) return rc;
+    RQ_HIP(hipMemcpyAsync(dst, src, (size_t)env->n * sizeof(T),
+                          dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, env->dev->stream));
+    RQ_HIP(hipStreamSynchronize(env->dev->stream));
+    return RQ_OK;
+}
+
+rq::Batch batch_of(const rq_env* env) { return {env->n, env->ld, env->offset}; }
+
+int check_env_objects(const rq_device* dev, const rq_env* env, const rq_params* params, const rq_state* state) {
+    RQ_REQUIRE(dev && env, RQ_ERR_INVALID_ARGUMENT, "null device/env");
+    RQ_REQUIRE(env->dev == dev, RQ_ERR_SHAPE_MISMATCH, "env belongs to another device");
+    RQ_REQUIRE(env->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_environment was not called");
+    if (params) RQ_REQUIRE(params->env == env, RQ_ERR_SHAPE_MISMATCH, "params belong to another env");
+    if (state) RQ_REQUIRE(state->env == env, RQ_ERR_SHAPE_MISMATCH, "state belongs to another env");
+    return RQ_OK;
+}
+
+void policy_free_buffers(rq_policy* pol);
+
+// Size the per-batch buffers on first use (Raptor sizes its hidden state on the first
+// batch, README.md:24) and apply a pending reset(): h <- initial_hidden_state.
+int policy_size(rq_policy* pol, uint32_t batch) {
+    int rc = set_device(pol->dev); if (rc) return rc;
+    if (pol->batch != batch || !pol->hidden) {
+        RQ_REQUIRE(pol->batch == 0 || pol->needs_reset, RQ_ERR_SHAPE_MISMATCH,
+                   "batch size changed without reset (hidden state is per batch element)");
+        RQ_HIP(hipStreamSynchronize(pol->dev->stream));
+        policy_free_buffers(pol);
+        const uint32_t ld = round_up64(batch);
+        RQ_HIP(hipMalloc(&pol->hidden, (size_t)RQ_POLICY_HIDDEN_DIM * ld * sizeof(float)));
+        RQ_HIP(hipMalloc(&pol->obs, (size_t)RQ_POLICY_INPUT_DIM * ld * sizeof(float)));
+        RQ_HIP(hipMalloc(&pol->act, (size_t)RQ_ACTION_DIM * ld * sizeof(float)));
+        pol->batch = batch; pol->ld = ld;
+        pol->needs_reset = true;
+    }
+    if (pol->needs_reset) {
+        for (int j = 0; j < RQ_POLICY_HIDDEN_DIM; ++j)
+            RQ_HIP(rq::launch_fill_f32(pol->dev->stream, pol->hidden + (size_t)j * pol->ld,
+                                       pol->w_host[2000 + j], pol->ld));
+        pol->needs_reset = false;
+    }
+    return RQ_OK;
+}
+
+void policy_free_buffers(rq_policy* pol) {
+    if (pol->hidden) (void)hipFree(pol->hidden);
+    if (pol->obs) (void)hipFree(pol->obs);
+    if (pol->act) (void)hipFree(pol->act);
+    pol->hidden = pol->obs = pol->act = nullptr;
+    pol->batch = pol->ld = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------- library ---
+RQ_API int rq_abi_version(void) { return RQ_ABI_VERSION; }
+RQ_API const char* rq_last_error(void) { return g_last_error.c_str(); }
+
+RQ_API const char* rq_status_string(int status) {
+    switch (status) {
+        case RQ_OK: return "ok";
+        case RQ_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case RQ_ERR_NO_DEVICE: return "no HIP device";
+        case RQ_ERR_HIP: return "HIP runtime error";
+        case RQ_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case RQ_ERR_SHAPE_MISMATCH: return "objects do not belong together";
+        case RQ_ERR_NOT_INITIALIZED: return "object not initialized";
+        case RQ_ERR_SELFTEST_FAILED: return "self-test failed";
+        default: return "unknown status";
+    }
+}
+
+RQ_API int rq_device_count(int* count) {
+    RQ_REQUIRE(count, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RQ_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- Device ----
+RQ_API int rq_device_create(int ordinal, rq_device** out) {
+    RQ_REQUIRE(out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RQ_ERR_NO_DEVICE, "rq_device_create: no HIP device available (this library has no CPU path)");
+    RQ_REQUIRE(ordinal >= 0 && ordinal < n, RQ_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    RQ_HIP(hipSetDevice(ordinal));
+    rq_device* d = new (std::nothrow) rq_device();
+    RQ_REQUIRE(d, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    d->ordinal = ordinal;
+    hipError_t e1 = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    hipError_t e2 = hipEventCreate(&d->ev_start);
+    hipError_t e3 = hipEventCreate(&d->ev_stop);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        delete d;
+        return fail(RQ_ERR_HIP, "rq_device_create: stream/event creation failed");
+    }
+    *out = d;
+    return RQ_OK;
+}
+
+RQ_API int rq_device_destroy(rq_device* dev) {
+    if (!dev) return RQ_OK;
+    (void)hipSetDevice(dev->ordinal);
+    if (dev->stream) { (void)hipStreamSynchronize(dev->stream); (void)hipStreamDestroy(dev->stream); }
+    if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
+    if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
+    if (dev->staging) (void)hipHostFree(dev->staging);
+    delete dev;
+    return RQ_OK;
+}
+
+RQ_API int rq_device_synchronize(rq_device* dev) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(dev); if (rc) return rc;
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    return RQ_OK;
+}
+
+RQ_API int rq_device_timer_start(rq_device* dev) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(dev); if (rc) return rc;
+    RQ_HIP(hipEventRecord(dev->ev_start, dev->stream));
+    return RQ_OK;
+}
+
+RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms) {
+    RQ_REQUIRE(dev && elapsed_ms, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(dev); if (rc) return rc;
+    RQ_HIP(hipEventRecord(dev->ev_stop, dev->stream));
+    RQ_HIP(hipEventSynchronize(dev->ev_stop));
+    RQ_HIP(hipEventElapsedTime(elapsed_ms, dev->ev_start, dev->ev_stop));
+    return RQ_OK;
+}
+
+RQ_API int rq_device_stream(rq_device* dev, void** hip_stream) {
+    RQ_REQUIRE(dev && hip_stream, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *hip_stream = (void*)dev->stream;
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- Rng -------
+RQ_API int rq_rng_create(rq_device* dev, rq_rng** out) {
+    RQ_REQUIRE(dev && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    rq_rng* r = new (std::nothrow) rq_rng();
+    RQ_REQUIRE(r, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    r->dev = dev;
+    *out = r;
+    return RQ_OK;
+}
+
+RQ_API int rq_rng_destroy(rq_rng* rng) { delete rng; return RQ_OK; }
+
+RQ_API int rq_initialize_rng(rq_device* dev, rq_rng* rng, uint64_t seed) {
+    RQ_REQUIRE(dev && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(rng->dev == dev, RQ_ERR_SHAPE_MISMATCH, "rng belongs to another device");
+    rng->seed = seed; rng->epoch = 0; rng->param_epoch = 0; rng->initialized = true;
+    return RQ_OK;
+}
+
+RQ_API int rq_rng_get(const rq_rng* rng, uint64_t* seed, uint32_t* epoch) {
+    RQ_REQUIRE(rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (seed) *seed = rng->seed;
+    if (epoch) *epoch = rng->epoch;
+    return RQ_OK;
+}
+
+RQ_API int rq_rng_set_epoch(rq_rng* rng, uint32_t epoch) {
+    RQ_REQUIRE(rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    rng->epoch = epoch;
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- Env -------
+RQ_API int rq_env_default_config(rq_env_config* c) {
+    RQ_REQUIRE(c, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (uint32_t)sizeof(*c);
+    c->dt = 0.01f;                         // README.md:25
+    c->gravity = 9.81f;
+    c->episode_step_limit = 500;           // README.md:95, checkpoint.h:62
+    c->domain_randomization = 1;
+    c->dr_scale_min = 0.5f; c->dr_scale_max = 8.0f;
+    c->dr_thrust_to_weight_min = 1.5f; c->dr_thrust_to_weight_max = 5.0f;
+    c->dr_torque_const_min = 0.005f; c->dr_torque_const_max = 0.03f;
+    c->dr_motor_tau_min = 0.03f; c->dr_motor_tau_max = 0.2f;
+    c->init_guidance = 0.1f;
+    c->init_max_position = 0.5f;
+    c->init_max_angle = 1.5707963267948966f;
+    c->init_max_linear_velocity = 1.0f;
+    c->init_max_angular_velocity = 1.0f;
+    c->reward_scale = 1.0f; c->reward_constant = 1.5f; c->reward_termination_penalty = 0.0f;
+    c->reward_position = 1.0f; c->reward_orientation = 0.1f; c->reward_linear_velocity = 0.01f;
+    c->reward_angular_velocity = 0.001f; c->reward_action = 0.01f;
+    c->termination_enabled = 1;
+    c->termination_position = 3.0f;
+    c->termination_linear_velocity = 1000.0f;
+    c->termination_angular_velocity = 1000.0f;
+    return RQ_OK;
+}
+
+RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_offset, rq_env** out) {
+    RQ_REQUIRE(dev && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(n_envs > 0, RQ_ERR_INVALID_ARGUMENT, "n_envs must be positive");
+    RQ_REQUIRE(n_envs <= 0xFFFFFF00u, RQ_ERR_INVALID_ARGUMENT, "n_envs too large");
+    *out = nullptr;
+    int rc = set_device(dev); if (rc) return rc;
+    rq_env* e = new (std::nothrow) rq_env();
+    RQ_REQUIRE(e, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    e->dev = dev; e->n = n_envs; e->ld = round_up64(n_envs); e->offset = global_env_offset;
+    const size_t ld = e->ld;
+    // one block for all statistics: 8 x 4-byte arrays + 2 x 1-byte arrays
+    const size_t stats_bytes = ld * (8 * 4 + 2 * 1);
+    hipError_t e1 = hipMalloc(&e->obs, (size_t)RQ_OBSERVATION_DIM * ld * sizeof(float));
+    hipError_t e2 = hipMalloc(&e->act, (size_t)RQ_ACTION_DIM * ld * sizeof(float));
+    hipError_t e3 = hipMalloc(&e->stats_block, stats_bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        if (e->obs) (void)hipFree(e->obs);
+        if (e->act) (void)hipFree(e->act);
+        if (e->stats_block) (void)hipFree(e->stats_block);
+        delete e;
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_env_create: device allocation failed");
+    }
+    char* b = static_cast<char*>(e->stats_block);
+    e->st.returns = (float*)(b + 0 * 4 * ld);
+    e->st.steps = (uint32_t*)(b + 1 * 4 * ld);
+    e->st.fin_returns = (float*)(b + 2 * 4 * ld);
+    e->st.fin_lengths = (uint32_t*)(b + 3 * 4 * ld);
+    e->st.fin_counts = (uint32_t*)(b + 4 * 4 * ld);
+    e->st.fin_terminated = (uint32_t*)(b + 5 * 4 * ld);
+    e->st.last_reward = (float*)(b + 6 * 4 * ld);
+    e->st.episode = (uint32_t*)(b + 7 * 4 * ld);
+    e->st.last_terminated = (uint8_t*)(b + 8 * 4 * ld);
+    e->st.frozen = (uint8_t*)(b + 8 * 4 * ld + ld);
+    hipError_t m1 = hipMemsetAsync(e->stats_block, 0, stats_bytes, dev->stream);
+    hipError_t m2 = hipMemsetAsync(e->obs, 0, (size_t)RQ_OBSERVATION_DIM * ld * sizeof(float), dev->stream);
+    hipError_t m3 = hipMemsetAsync(e->act, 0, (size_t)RQ_ACTION_DIM * ld * sizeof(float), dev->stream);
+    if (m1 != hipSuccess || m2 != hipSuccess || m3 != hipSuccess) {
+        rq_env_destroy(e);
+        return fail(RQ_ERR_HIP, "rq_env_create: memset failed");
+    }
+    *out = e;
+    return RQ_OK;
+}
+
+RQ_API int rq_env_destroy(rq_env* env) {
+    if (!env) return RQ_OK;
+    (void)hipSetDevice(env->dev->ordinal);
+    (void)hipStreamSynchronize(env->dev->stream);
+    if (env->obs) (void)hipFree(env->obs);
+    if (env->act) (void)hipFree(env->act);
+    if (env->stats_block) (void)hipFree(env->stats_block);
+    delete env;
+    return RQ_OK;
+}
+
+RQ_API int rq_env_num_envs(const rq_env* env, uint32_t* n) {
+    RQ_REQUIRE(env && n, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *n = env->n; return RQ_OK;
+}
+RQ_API int rq_env_leading_dim(const rq_env* env, uint32_t* ld) {
+    RQ_REQUIRE(env && ld, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *ld = env->ld; return RQ_OK;
+}
+
+RQ_API int rq_initialize_environment(rq_device* dev, rq_env* env) {
+    RQ_REQUIRE(dev && env, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(env->dev == dev, RQ_ERR_SHAPE_MISMATCH, "env belongs to another device");
+    rq_env_default_config(&env->cfg);
+    env->initialized = true;
+    return RQ_OK;
+}
+
+RQ_API int rq_env_set_config(rq_env* env, const rq_env_config* cfg) {
+    RQ_REQUIRE(env && cfg, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(cfg->struct_size == sizeof(rq_env_config), RQ_ERR_INVALID_ARGUMENT,
+               "rq_env_config.struct_size does not match this library (ABI mismatch)");
+    RQ_REQUIRE(cfg->dt > 0.0f, RQ_ERR_INVALID_ARGUMENT, "dt must be positive");
+    RQ_REQUIRE(cfg->episode_step_limit > 0, RQ_ERR_INVALID_ARGUMENT, "episode_step_limit must be positive");
+    env->cfg = *cfg;
+    env->initialized = true;
+    return RQ_OK;
+}
+
+RQ_API int rq_env_get_config(const rq_env* env, rq_env_config* cfg) {
+    RQ_REQUIRE(env && cfg, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(env->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_environment was not called");
+    *cfg = env->cfg;
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- containers
+RQ_API int rq_params_create(rq_env* env, rq_params** out) {
+    RQ_REQUIRE(env && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(env->dev); if (rc) return rc;
+    rq_params* p = new (std::nothrow) rq_params();
+    RQ_REQUIRE(p, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    p->env = env;
+    const size_t bytes = (size_t)RQ_PARAM_DIM * env->ld * sizeof(float);
+    hipError_t e = hipMalloc(&p->d, bytes);
+    if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_params_create: device allocation failed"); }
+    (void)hipMemsetAsync(p->d, 0, bytes, env->dev->stream);
+    *out = p;
+    return RQ_OK;
+}
+RQ_API int rq_params_destroy(rq_params* p) {
+    if (!p) return RQ_OK;
+    (void)hipSetDevice(p->env->dev->ordinal);
+    (void)hipStreamSynchronize(p->env->dev->stream);
+    if (p->d) (void)hipFree(p->d);
+    delete p;
+    return RQ_OK;
+}
+RQ_API int rq_params_get(const rq_params* p, float* host_out) {
+    RQ_REQUIRE(p && host_out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return soa_to_host(p->env->dev, p->d, p->env->n, p->env->ld, RQ_PARAM_DIM, host_out);
+}
+RQ_API int rq_params_set(rq_params* p, const float* host_in) {
+    RQ_REQUIRE(p && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return host_to_soa(p->env->dev, host_in, p->env->n, RQ_PARAM_DIM, p->env->ld, RQ_PARAM_DIM, p->d);
+}
+RQ_API int rq_params_device_ptr(const rq_params* p, float** dev_ptr) {
+    RQ_REQUIRE(p && dev_ptr, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *dev_ptr = p->d; return RQ_OK;
+}
+
+RQ_API int rq_state_create(rq_env* env, rq_state** out) {
+    RQ_REQUIRE(env && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(env->dev); if (rc) return rc;
+    rq_state* s = new (std::nothrow) rq_state();
+    RQ_REQUIRE(s, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->env = env;
+    const size_t bytes = (size_t)RQ_STATE_DIM * env->ld * sizeof(float);
+    hipError_t e = hipMalloc(&s->d, bytes);
+    if (e != hipSuccess) { delete s; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_state_create: device allocation failed"); }
+    (void)hipMemsetAsync(s->d, 0, bytes, env->dev->stream);
+    *out = s;
+    return RQ_OK;
+}
+RQ_API int rq_state_destroy(rq_state* s) {
+    if (!s) return RQ_OK;
+    (void)hipSetDevice(s->env->dev->ordinal);
+    (void)hipStreamSynchronize(s->env->dev->stream);
+    if (s->d) (void)hipFree(s->d);
+    delete s;
+    return RQ_OK;
+}
+RQ_API int rq_state_assign(rq_state* dst, const rq_state* src) {
+    RQ_REQUIRE(dst && src, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(dst->env == src->env, RQ_ERR_SHAPE_MISMATCH, "states belong to different envs");
+    if (dst == src) return RQ_OK;
+    int rc = set_device(dst->env->dev); if (rc) return rc;
+    RQ_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)RQ_STATE_DIM * dst->env->ld * sizeof(float),
+                          hipMemcpyDeviceToDevice, dst->env->dev->stream));
+    return RQ_OK;
+}
+RQ_API int rq_state_get(const rq_state* s, float* host_out) {
+    RQ_REQUIRE(s && host_out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return soa_to_host(s->env->dev, s->d, s->env->n, s->env->ld, RQ_STATE_DIM, host_out);
+}
+RQ_API int rq_state_set(rq_state* s, const float* host_in) {
+    RQ_REQUIRE(s && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return host_to_soa(s->env->dev, host_in, s->env->n, RQ_STATE_DIM, s->env->ld, RQ_STATE_DIM, s->d);
+}
+RQ_API int rq_state_device_ptr(const rq_state* s, float** dev_ptr) {
+    RQ_REQUIRE(s && dev_ptr, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *dev_ptr = s->d; return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- l2f vector::
+RQ_API int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* params, rq_rng* rng) {
+    int rc = check_env_objects(dev, env, params, nullptr); if (rc) return rc;
+    RQ_REQUIRE(params && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
+    rc = set_device(dev); if (rc) return rc;
+    RQ_HIP(rq::launch_sample_params(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed,
+                                    rng->param_epoch, params->d));
+    rng->param_epoch += 1;
+    return RQ_OK;
+}
+
+RQ_API int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_rng* rng) {
+    int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
+    RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
+    rc = set_device(dev); if (rc) return rc;
+    RQ_HIP(rq::launch_sample_state(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed, params->d,
+                                   state->d, env->st.episode, env->st.frozen));
+    return RQ_OK;
+}
+
+RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state, float* observation,
+               rq_rng* rng) {
+    int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
+    RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
+    rc = set_device(dev); if (rc) return rc;
+    RQ_HIP(rq::launch_observe(dev->stream, batch_of(env), rq::noise_cfg(env->cfg), rq::noise_enabled(env->cfg),
+                              rng->seed, rng->epoch, params->d, state->d, env->obs));
+    rng->epoch += 1;
+    if (observation) return soa_to_host(dev, env->obs, env->n, env->ld, RQ_OBSERVATION_DIM, observation);
+    return RQ_OK;
+}
+
+RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const rq_state* state, const float* action,
+            rq_state* next_state, rq_rng* rng, float* dts) {
+    int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
+    RQ_REQUIRE(params && state && next_state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(next_state->env == env, RQ_ERR_SHAPE_MISMATCH, "next_state belongs to another env");
+    rc = set_device(dev); if (rc) return rc;
+    if (action) {
+        rc = host_to_soa(dev, action, env->n, RQ_ACTION_DIM, env->ld, RQ_ACTION_DIM, env->act);
+        if (rc) return rc;
+    }
+    RQ_HIP(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
+                           next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
+                           nullptr, nullptr));
+    if (dts) for (uint32_t i = 0; i < env->n; ++i) dts[i] = env->cfg.dt;
+    return RQ_OK;
+}
+
+RQ_API int rq_env_observation_device_ptr(const rq_env* env, float** p) {
+    RQ_REQUIRE(env && p, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *p = env->obs; return RQ_OK;
+}
+RQ_API int rq_env_action_device_ptr(const rq_env* env, float** p) {
+    RQ_REQUIRE(env && p, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *p = env->act; return RQ_OK;
+}
+RQ_API int rq_env_get_observation(const rq_env* env, float* host_out) {
+    RQ_REQUIRE(env && host_out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return soa_to_host(env->dev, env->obs, env->n, env->ld, RQ_OBSERVATION_DIM, host_out);
+}
+RQ_API int rq_env_get_action(const rq_env* env, float* host_out) {
+    RQ_REQUIRE(env && host_out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return soa_to_host(env->dev, env->act, env->n, env->ld, RQ_ACTION_DIM, host_out);
+}
+RQ_API int rq_env_set_action(rq_env* env, const float* host_in) {
+    RQ_REQUIRE(env && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    return host_to_soa(env->dev, host_in, env->n, RQ_ACTION_DIM, env->ld, RQ_ACTION_DIM, env->act);
+}
+
+// ---------------------------------------------------------------------------- statistics
+RQ_API int rq_env_get_rewards(const rq_env* env, float* dst, int dev_dst) { return copy_out(env, env ? env->st.last_reward : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dev_dst) { return copy_out(env, env ? env->st.last_terminated : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_returns(const rq_env* env, float* dst, int dev_dst) { return copy_out(env, env ? env->st.returns : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_episode_steps(const rq_env* env, uint32_t* dst, int dev_dst) { return copy_out(env, env ? env->st.steps : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_finished_returns(const rq_env* env, float* dst, int dev_dst) { return copy_out(env, env ? env->st.fin_returns : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_finished_lengths(const rq_env* env, uint32_t* dst, int dev_dst) { return copy_out(env, env ? env->st.fin_lengths : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_finished_counts(const rq_env* env, uint32_t* dst, int dev_dst) { return copy_out(env, env ? env->st.fin_counts : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_finished_terminated(const rq_env* env, uint32_t* dst, int dev_dst) { return copy_out(env, env ? env->st.fin_terminated : nullptr, dst, dev_dst); }
+
+RQ_API int rq_env_reset_statistics(rq_env* env) {
+    RQ_REQUIRE(env, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(env->dev); if (rc) return rc;
+    const size_t ld = env->ld;
+    // everything except the per-env episode counters (they key the initial-state RNG)
+    RQ_HIP(hipMemsetAsync(env->stats_block, 0, 7 * 4 * ld, env->dev->stream));
+    RQ_HIP(hipMemsetAsync(env->st.last_terminated, 0, 2 * ld, env->dev->stream));
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- Policy ----
+RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out) {
+    RQ_REQUIRE(dev && weights && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(n_weights == RQ_POLICY_NUM_WEIGHTS, RQ_ERR_INVALID_ARGUMENT,
+               "expected 2084 weights: W0[16,22] b0[16] Wi[48,16] Wh[48,16] bi[48] bh[48] h0[16] W2[4,16] b2[4]");
+    *out = nullptr;
+    int rc = set_device(dev); if (rc) return rc;
+    rq_policy* p = new (std::nothrow) rq_policy();
+    RQ_REQUIRE(p, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    p->dev = dev;
+    std::memcpy(p->w_host, weights, sizeof(p->w_host));
+    hipError_t e = hipMalloc(&p->w_dev, sizeof(p->w_host));
+    if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed"); }
+    e = hipMemcpyAsync(p->w_dev, p->w_host, sizeof(p->w_host), hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e != hipSuccess) { (void)hipFree(p->w_dev); delete p; return fail(RQ_ERR_HIP, "rq_policy_create: weight upload failed"); }
+    *out = p;
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_destroy(rq_policy* pol) {
+    if (!pol) return RQ_OK;
+    (void)hipSetDevice(pol->dev->ordinal);
+    (void)hipStreamSynchronize(pol->dev->stream);
+    policy_free_buffers(pol);
+    if (pol->w_dev) (void)hipFree(pol->w_dev);
+    delete pol;
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_set_precision(rq_policy* pol, int precision) {
+    RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA, RQ_ERR_INVALID_ARGUMENT,
+               "unknown precision");
+    RQ_REQUIRE(precision == RQ_POLICY_FP32, RQ_ERR_INVALID_ARGUMENT,
+               "RQ_POLICY_BF16_MFMA is not implemented in this build");
+    pol->precision = precision;
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_reset(rq_policy* pol) {
+    RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(pol->dev); if (rc) return rc;
+    pol->needs_reset = true;   // applied (h <- initial_hidden_state, checkpoint.h:123) on the next use
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* observation, uint32_t batch,
+                            uint32_t obs_stride, float* action) {
+    RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null policy");
+    RQ_REQUIRE(observation || env, RQ_ERR_INVALID_ARGUMENT, "observation == NULL needs an env to read from");
+    RQ_REQUIRE(action || env, RQ_ERR_INVALID_ARGUMENT, "action == NULL needs an env to write to");
+    if (env) {
+        RQ_REQUIRE(env->dev == pol->dev, RQ_ERR_SHAPE_MISMATCH, "env and policy live on different devices");
+        RQ_REQUIRE(batch == env->n, RQ_ERR_SHAPE_MISMATCH, "batch must equal the env's n_envs");
+    }
+    RQ_REQUIRE(batch > 0, RQ_ERR_INVALID_ARGUMENT, "batch must be positive");
+    if (observation) RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
+    int rc = set_device(pol->dev); if (rc) return rc;
+    rc = policy_size(pol, batch); if (rc) return rc;
+    const float* d_obs; uint32_t ld_obs;
+    if (observation) {
+        rc = host_to_soa(pol->dev, observation, batch, obs_stride, pol->ld, RQ_POLICY_INPUT_DIM, pol->obs);
+        if (rc) return rc;
+        d_obs = pol->obs; ld_obs = pol->ld;
+    } else {
+        d_obs = env->obs; ld_obs = env->ld;
+    }
+    float* d_act = action ? pol->act : env->act;
+    const uint32_t ld_act = action ? pol->ld : env->ld;
+    RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, pol->w_dev, d_obs, ld_obs, pol->hidden, pol->ld, d_act,
+                                 ld_act, nullptr, pol->precision));
+    if (action) return soa_to_host(pol->dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_get_hidden(const rq_policy* pol, float* host_out, uint32_t batch) {
+    RQ_REQUIRE(pol && host_out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = policy_size(const_cast<rq_policy*>(pol), batch); if (rc) return rc;
+    return soa_to_host(pol->dev, pol->hidden, batch, pol->ld, RQ_POLICY_HIDDEN_DIM, host_out);
+}
+
+RQ_API int rq_policy_set_hidden(rq_policy* pol, const float* host_in, uint32_t batch) {
+    RQ_REQUIRE(pol && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(pol->dev); if (rc) return rc;
+    rc = policy_size(pol, batch); if (rc) return rc;
+    return host_to_soa(pol->dev, host_in, batch, RQ_POLICY_HIDDEN_DIM, pol->ld, RQ_POLICY_HIDDEN_DIM, pol->hidden);
+}
+
+RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* expected, uint32_t steps, uint32_t batch,
+                       float tolerance, float* max_abs_err) {
+    RQ_REQUIRE(pol && input && expected, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(steps > 0 && batch > 0, RQ_ERR_INVALID_ARGUMENT, "empty test");
+    // runs on a private policy object so the caller's hidden state is untouched
+    rq_policy* tmp = nullptr;
+    int rc = rq_policy_create(pol->dev, pol->w_host, RQ_POLICY_NUM_WEIGHTS, &tmp); if (rc) return rc;
+    tmp->precision = pol->precision;
+    std::vector<float> act((size_t)batch * RQ_ACTION_DIM);
+    float worst = 0.0f;
+    for (uint32_t t = 0; t < steps && rc == RQ_OK; ++t) {
+        rc = rq_policy_evaluate_step(tmp, nullptr, input + (size_t)t * batch * RQ_POLICY_INPUT_DIM, batch,
+                                     RQ_POLICY_INPUT_DIM, act.data());
+        const float* ex = expected + (size_t)t * batch * RQ_ACTION_DIM;
+        for (size_t k = 0; k < act.size(); ++k) {
+            float d = act[k] - ex[k]; if (d < 0) d = -d;
+            if (!(d <= worst)) worst = d;   // NaN-propagating max
+        }
+    }
+    rq_policy_destroy(tmp);
+    if (rc) return rc;
+    if (max_abs_err) *max_abs_err = worst;
+    if (!(worst <= tolerance))
+        return fail(RQ_ERR_SELFTEST_FAILED, "rq_policy_selftest: max |out - expected| = " + std::to_string(worst) +
+                                                " exceeds tolerance " + std::to_string(tolerance));
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- Rollout ---
+RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
+               rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags) {
+    int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
+    RQ_REQUIRE(params && state && policy && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(policy->dev == dev, RQ_ERR_SHAPE_MISMATCH, "policy lives on another device");
+    RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
+    RQ_REQUIRE(mode == RQ_ROLLOUT_FUSED || mode == RQ_ROLLOUT_CHAINED, RQ_ERR_INVALID_ARGUMENT, "unknown mode");
+    RQ_REQUIRE((flags & ~(uint32_t)RQ_ROLLOUT_AUTORESET) == 0, RQ_ERR_INVALID_ARGUMENT, "unknown flags");
+    rc = set_device(dev); if (rc) return rc;
+    rc = policy_size(policy, env->n); if (rc) return rc;
+    RQ_REQUIRE(policy->ld == env->ld, RQ_ERR_SHAPE_MISMATCH, "policy batch does not match the env");
+    const rq::Batch b = batch_of(env);
+    const rq::StepCfg sc = rq::step_cfg(env->cfg);
+    const rq::NoiseCfg nc = rq::noise_cfg(env->cfg);
+    const rq::SampleCfg smp = rq::sample_cfg(env->cfg);
+    const bool noise = rq::noise_enabled(env->cfg);
+    if (mode == RQ_ROLLOUT_FUSED) {
+        RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
+                                        params->d, state->d, policy->hidden, policy->w_dev, env->st,
+                                        policy->precision));
+    } else {
+        for (uint32_t t = 0; t < n_steps; ++t) {
+            RQ_HIP(rq::launch_observe(dev->stream, b, nc, noise, rng->seed, rng->epoch + t, params->d, state->d,
+                                      env->obs));
+            RQ_HIP(rq::launch_actor_step(dev->stream, env->n, policy->w_dev, env->obs, env->ld, policy->hidden,
+                                         policy->ld, env->act, env->ld, env->st.frozen, policy->precision));
+            RQ_HIP(rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
+                                   /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev));
+        }
+    }
+    rng->epoch += n_steps;
+    return RQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+// rq_device_math.hpp — per-lane (one wavefront lane = one quadrotor) device functions for gfx950.
+//
+// Everything here works on register-resident per-env values; the kernels in rq_kernels.hip
+// move them between HBM (struct-of-arrays, field-major) and registers.  The arithmetic
+// follows DESIGN.md "Environment specification" operation by operation: float32, the only
+// fused operations are the explicit fmaf() calls (the translation unit is built with
+// -ffp-contract=off), so state transitions are bit-reproducible across kernels (fused vs
+// chained) and across GPUs/shardings.
+//
+// Replaces (call sites in /root/reference/README.md): vector.observe :96, vector.step :98,
+// vector.sample_initial_parameters :60, vector.sample_initial_state :61 and
+// Raptor.evaluate_step :97 (layers: checkpoint.h:39-65, 75-139, 149-175).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/raptor_quad.h"
+#include "rq_kernels.hpp"
+
+namespace rq {
+
+// ------------------------------------------------------------------ Philox4x32-10 ------
+enum : uint32_t { PURPOSE_PARAMS = 1, PURPOSE_STATE = 2, PURPOSE_OBS = 3 };
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// counter = (block, epoch-or-episode, low 32 bits of the GLOBAL env id, purpose | high id bits << 8)
+__device__ __forceinline__ u32x4 rng_block(uint64_t seed, uint32_t block, uint32_t epoch, uint64_t genv,
+                                           uint32_t purpose) {
+    return philox4x32_10(block, epoch, (uint32_t)genv, purpose | ((uint32_t)(genv >> 32) << 8),
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// uniform in (0,1): 23 random bits + 0.5 — exact in float32
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 0x1p-23f; }
+__device__ __forceinline__ float lerpf(float lo, float hi, float u) { return fmaf(u, hi - lo, lo); }
+__device__ __forceinline__ void box_muller(float u1, float u2, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u1));
+    const float th = 6.2831853071795865f * u2;
+    n0 = r * cosf(th);
+    n1 = r * sinf(th);
+}
+
+// ------------------------------------------------------------------ per-env constants --
+// What one transition needs from the parameter fields, with the divisions hoisted.
+struct EnvConsts {
+    float inv_m, jx, jy, jz, ijx, ijy, ijz;
+    float px[4], py[4];
+    float c0, c1, c2, kq, itr, itf;
+    float rmin, rmax, half, mid;   // action -> set-point map
+    float ha;                      // hover action (reward baseline)
+};
+
+// p(f) returns parameter field f of this lane's env
+template <typename F>
+__device__ __forceinline__ EnvConsts make_consts(F p) {
+    EnvConsts k;
+    k.inv_m = 1.0f / p(RQ_P_MASS);
+    k.jx = p(RQ_P_JXX); k.jy = p(RQ_P_JYY); k.jz = p(RQ_P_JZZ);
+    k.ijx = 1.0f / k.jx; k.ijy = 1.0f / k.jy; k.ijz = 1.0f / k.jz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k.px[i] = p(RQ_P_ROTOR_POS + 3 * i); k.py[i] = p(RQ_P_ROTOR_POS + 3 * i + 1); }
+    k.c0 = p(RQ_P_THRUST_C0); k.c1 = p(RQ_P_THRUST_C1); k.c2 = p(RQ_P_THRUST_C2);
+    k.kq = p(RQ_P_TORQUE_CONST);
+    k.itr = 1.0f / p(RQ_P_TAU_RISE); k.itf = 1.0f / p(RQ_P_TAU_FALL);
+    k.rmin = p(RQ_P_RPM_MIN); k.rmax = p(RQ_P_RPM_MAX);
+    k.half = (k.rmax - k.rmin) * 0.5f;
+    k.mid = k.rmin + k.half;
+    k.ha = p(RQ_P_HOVER_ACTION);
+    return k;
+}
+
+// per-episode disturbance, folded: acceleration incl. gravity, and body torque
+struct Disturbance { float adx, ady, adz, tdx, tdy, tdz; };
+
+__device__ __forceinline__ Disturbance make_disturbance(const EnvConsts& k, float gravity, const float (&f)[6]) {
+    Disturbance d;
+    d.adx = f[0] * k.inv_m;
+    d.ady = f[1] * k.inv_m;
+    d.adz = fmaf(f[2], k.inv_m, -gravity);
+    d.tdx = f[3]; d.tdy = f[4]; d.tdz = f[5];
+    return d;
+}
+
+// ------------------------------------------------------------------ dynamics + RK4 -----
+// y = (p[0..2], q[3..6] = (w,x,y,z), v[7..9], w_body[10..12], rpm[13..16]); d = dy/dt
+__device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& ds, const float (&y)[17],
+                                         const float (&sp)[4], float (&d)[17]) {
+    const float qw = y[3], qx = y[4], qy = y[5], qz = y[6];
+    const float wx = y[10], wy = y[11], wz = y[12];
+    float T[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[i] = fmaf(fmaf(k.c2, y[13 + i], k.c1), y[13 + i], k.c0);
+    const float Tsum = ((T[0] + T[1]) + T[2]) + T[3];
+    float tx = fmaf(k.py[3], T[3], fmaf(k.py[2], T[2], fmaf(k.py[1], T[1], k.py[0] * T[0])));
+    float ty = -fmaf(k.px[3], T[3], fmaf(k.px[2], T[2], fmaf(k.px[1], T[1], k.px[0] * T[0])));
+    float tz = k.kq * (((T[1] + T[3]) - T[0]) - T[2]);   // spin directions (-1,+1,-1,+1)
+    tx += ds.tdx; ty += ds.tdy; tz += ds.tdz;
+    d[0] = y[7]; d[1] = y[8]; d[2] = y[9];
+    d[3] = -0.5f * fmaf(qz, wz, fmaf(qy, wy, qx * wx));
+    d[4] = 0.5f * fmaf(-qz, wy, fmaf(qy, wz, qw * wx));
+    d[5] = 0.5f * fmaf(-qx, wz, fmaf(qz, wx, qw * wy));
+    d[6] = 0.5f * fmaf(-qy, wx, fmaf(qx, wy, qw * wz));
+    const float r02 = 2.0f * fmaf(qx, qz, qw * qy);
+    const float r12 = 2.0f * fmaf(qy, qz, -(qw * qx));
+    const float r22 = fmaf(-2.0f, fmaf(qx, qx, qy * qy), 1.0f);
+    const float acc = Tsum * k.inv_m;
+    d[7] = fmaf(r02, acc, ds.adx);
+    d[8] = fmaf(r12, acc, ds.ady);
+    d[9] = fmaf(r22, acc, ds.adz);
+    const float jwx = k.jx * wx, jwy = k.jy * wy, jwz = k.jz * wz;
+    const float cx = fmaf(wy, jwz, -(wz * jwy));
+    const float cy = fmaf(wz, jwx, -(wx * jwz));
+    const float cz = fmaf(wx, jwy, -(wy * jwx));
+    d[10] = (tx - cx) * k.ijx;
+    d[11] = (ty - cy) * k.ijy;
+    d[12] = (tz - cz) * k.ijz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float e = sp[i] - y[13 + i];
+        d[13 + i] = e * (sp[i] >= y[13 + i] ? k.itr : k.itf);
+    }
+}
+
+
+__device__ __forceinline__ bool finite_(float x) { return fabsf(x) <= 3.402823466e+38f; }
+
+// One transition, in place: y[17] <- RK4(y, clip(a)); ac = clipped action; returns reward, sets term.
+__device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts& k, const Disturbance& ds,
+                                              float (&y)[17], const float (&a)[4], float (&ac)[4], bool& term) {
+    float sp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ac[i] = fminf(fmaxf(a[i], -1.0f), 1.0f);
+        sp[i] = fmaf(ac[i], k.half, k.mid);
+    }
+    const float dt = c.dt, hdt = 0.5f * c.dt, dt6 = c.dt / 6.0f;
+    float yt[17], kk[17], ks[17];   // ks accumulates k1 + k4 and (k2 + k3) is folded in place
+    dynamics(k, ds, y, sp, kk);                       // k1
+#pragma unroll
+    for (int i = 0; i < 17; ++i) { ks[i] = kk[i]; yt[i] = fmaf(hdt, kk[i], y[i]); }
+    float k2[17];
+    dynamics(k, ds, yt, sp, k2);                      // k2
+#pragma unroll
+    for (int i = 0; i < 17; ++i) yt[i] = fmaf(hdt, k2[i], y[i]);
+    dynamics(k, ds, yt, sp, kk);                      // k3
+#pragma unroll
+    for (int i = 0; i < 17; ++i) { k2[i] = k2[i] + kk[i]; yt[i] = fmaf(dt, kk[i], y[i]); }
+    dynamics(k, ds, yt, sp, kk);                      // k4
+#pragma unroll
+    for (int i = 0; i < 17; ++i) y[i] = fmaf(dt6, fmaf(2.0f, k2[i], ks[i] + kk[i]), y[i]);
+    const float nq = sqrtf(fmaf(y[6], y[6], fmaf(y[5], y[5], fmaf(y[4], y[4], y[3] * y[3]))));
+    const float inq = 1.0f / nq;
+#pragma unroll
+    for (int i = 3; i < 7; ++i) y[i] *= inq;
+#pragma unroll
+    for (int i = 13; i < 17; ++i) y[i] = fminf(fmaxf(y[i], k.rmin), k.rmax);
+
+    bool t = false;
+    if (c.termination_enabled) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t |= fabsf(y[i]) > c.termination_position;
+#pragma unroll
+        for (int i = 7; i < 10; ++i) t |= fabsf(y[i]) > c.termination_linear_velocity;
+#pragma unroll
+        for (int i = 10; i < 13; ++i) t |= fabsf(y[i]) > c.termination_angular_velocity;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) t |= !finite_(y[i]);
+    }
+    term = t;
+    const float pc = fmaf(y[2], y[2], fmaf(y[1], y[1], y[0] * y[0]));
+    const float oc = fmaf(-y[3], y[3], 1.0f);
+    const float vc = fmaf(y[9], y[9], fmaf(y[8], y[8], y[7] * y[7]));
+    const float wc = fmaf(y[12], y[12], fmaf(y[11], y[11], y[10] * y[10]));
+    const float d0 = ac[0] - k.ha, d1 = ac[1] - k.ha, d2 = ac[2] - k.ha, d3 = ac[3] - k.ha;
+    const float acst = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+    const float cost = fmaf(c.reward_action, acst,
+                       fmaf(c.reward_angular_velocity, wc,
+                       fmaf(c.reward_linear_velocity, vc,
+                       fmaf(c.reward_orientation, oc, c.reward_position * pc))));
+    return t ? c.reward_termination_penalty : fmaf(-c.reward_scale, cost, c.reward_constant);
+}
+
+// ------------------------------------------------------------------ observe ------------
+
+// policy-visible head: o[0..21] = [p, R(q) row-major, v, w_body, previous action]
+template <bool NOISE>
+__device__ __forceinline__ void observe_head(const float (&y)[17], const float (&last_action)[4],
+                                             const NoiseCfg& nc, uint64_t seed, uint32_t epoch, uint64_t genv,
+                                             float (&o)[22]) {
+    const float w = y[3], x = y[4], yy_ = y[5], z = y[6];
+    const float xx = x * x, yy = yy_ * yy_, zz = z * z, xy = x * yy_, xz = x * z, yz = yy_ * z;
+    const float wx = w * x, wy = w * yy_, wz = w * z;
+    o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
+    o[3] = fmaf(-2.0f, yy + zz, 1.0f); o[4] = 2.0f * (xy - wz);           o[5] = 2.0f * (xz + wy);
+    o[6] = 2.0f * (xy + wz);           o[7] = fmaf(-2.0f, xx + zz, 1.0f); o[8] = 2.0f * (yz - wx);
+    o[9] = 2.0f * (xz - wy);           o[10] = 2.0f * (yz + wx);          o[11] = fmaf(-2.0f, xx + yy, 1.0f);
+    o[12] = y[7]; o[13] = y[8]; o[14] = y[9];
+    o[15] = y[10]; o[16] = y[11]; o[17] = y[12];
+    if (NOISE) {
+        float nrm[20];
+#pragma unroll
+        for (uint32_t b = 0; b < 5; ++b) {
+            const u32x4 r = rng_block(seed, b, epoch, genv, PURPOSE_OBS);
+            box_muller(u01(r.x), u01(r.y), nrm[4 * b + 0], nrm[4 * b + 1]);
+            box_muller(u01(r.z), u01(r.w), nrm[4 * b + 2], nrm[4 * b + 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = fmaf(nc.position, nrm[i], o[i]);
+#pragma unroll
+        for (int i = 3; i < 12; ++i) o[i] = fmaf(nc.orientation, nrm[i], o[i]);
+#pragma unroll
+        for (int i = 12; i < 15; ++i) o[i] = fmaf(nc.linear_velocity, nrm[i], o[i]);
+#pragma unroll
+        for (int i = 15; i < 18; ++i) o[i] = fmaf(nc.angular_velocity, nrm[i], o[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[18 + i] = last_action[i];
+}
+
+// ------------------------------------------------------------------ parameter sampling -
+
+__device__ __forceinline__ void sample_params(const SampleCfg& c, uint64_t seed, uint32_t epoch, uint64_t genv,
+                                              float (&p)[RQ_PARAM_DIM]) {
+    float arm;
+    if (!c.domain_randomization) {   // nominal Crazyflie
+        p[RQ_P_MASS] = 0.027f;
+        p[RQ_P_JXX] = 3.85e-6f; p[RQ_P_JYY] = 3.85e-6f; p[RQ_P_JZZ] = 5.9675e-6f;
+        arm = 0.028f;
+        p[RQ_P_THRUST_C0] = 0.0f; p[RQ_P_THRUST_C1] = 0.0f; p[RQ_P_THRUST_C2] = 3.16e-10f;
+        p[RQ_P_TORQUE_CONST] = 0.005964552f;
+        p[RQ_P_TAU_RISE] = 0.15f; p[RQ_P_TAU_FALL] = 0.15f;
+        p[RQ_P_RPM_MIN] = 0.0f; p[RQ_P_RPM_MAX] = 21702.0f;
+    } else {
+        const u32x4 r = rng_block(seed, 0, epoch, genv, PURPOSE_PARAMS);
+        const float s = lerpf(c.dr_scale_min, c.dr_scale_max, u01(r.x));
+        const float s2 = s * s, s3 = s2 * s, s5 = s3 * s2;
+        const float m = 0.027f * s3;
+        const float t2w = lerpf(c.dr_t2w_min, c.dr_t2w_max, u01(r.y));
+        const float rpm_max = 20000.0f / sqrtf(s);
+        p[RQ_P_MASS] = m;
+        p[RQ_P_JXX] = 3.85e-6f * s5; p[RQ_P_JYY] = 3.85e-6f * s5; p[RQ_P_JZZ] = 5.9675e-6f * s5;
+        arm = 0.028f * s;
+        p[RQ_P_THRUST_C0] = 0.0f; p[RQ_P_THRUST_C1] = 0.0f;
+        p[RQ_P_THRUST_C2] = ((t2w * m) * c.gravity) / (4.0f * (rpm_max * rpm_max));
+        p[RQ_P_TORQUE_CONST] = lerpf(c.dr_kq_min, c.dr_kq_max, u01(r.z)) * s;
+        const float tau = lerpf(c.dr_tau_min, c.dr_tau_max, u01(r.w));
+        p[RQ_P_TAU_RISE] = tau; p[RQ_P_TAU_FALL] = tau;
+        p[RQ_P_RPM_MIN] = 0.0f; p[RQ_P_RPM_MAX] = rpm_max;
+    }
+    // FR, BR, BL, FL in FLU (x forward, y left)
+    const float sx[4] = {1.f, -1.f, -1.f, 1.f}, sy[4] = {-1.f, -1.f, 1.f, 1.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[RQ_P_ROTOR_POS + 3 * i + 0] = sx[i] * arm;
+        p[RQ_P_ROTOR_POS + 3 * i + 1] = sy[i] * arm;
+        p[RQ_P_ROTOR_POS + 3 * i + 2] = 0.0f;
+    }
+    const float m = p[RQ_P_MASS], c0 = p[RQ_P_THRUST_C0], c1 = p[RQ_P_THRUST_C1], c2 = p[RQ_P_THRUST_C2];
+    const float T = (m * c.gravity) * 0.25f;
+    float hover;
+    if (c2 > 0.0f) {
+        const float disc = c1 * c1 - (4.0f * c2) * (c0 - T);
+        hover = (sqrtf(disc) - c1) / (2.0f * c2);
+    } else {
+        hover = (T - c0) / c1;
+    }
+    p[RQ_P_HOVER_RPM] = hover;
+    p[RQ_P_HOVER_ACTION] = (2.0f * (hover - p[RQ_P_RPM_MIN])) / (p[RQ_P_RPM_MAX] - p[RQ_P_RPM_MIN]) - 1.0f;
+}
+
+// ------------------------------------------------------------------ initial state ------
+// s[0..16] dynamic state, la[4] previous action, f[6] disturbance (force world, torque body)
+__device__ __forceinline__ void sample_state(const SampleCfg& c, uint64_t seed, uint32_t episode, uint64_t genv,
+                                             float mass, float hover_rpm, float pos0x, float pos0y,
+                                             float (&s)[17], float (&la)[4], float (&f)[6]) {
+    const u32x4 r0 = rng_block(seed, 0, episode, genv, PURPOSE_STATE);
+    const u32x4 r1 = rng_block(seed, 1, episode, genv, PURPOSE_STATE);
+    const u32x4 r2 = rng_block(seed, 2, episode, genv, PURPOSE_STATE);
+    const u32x4 r3 = rng_block(seed, 3, episode, genv, PURPOSE_STATE);
+    const bool guided = u01(r0.x) < c.init_guidance;
+    const float mp = c.init_max_position, mv = c.init_max_linear_velocity, mw = c.init_max_angular_velocity;
+    s[0] = lerpf(-mp, mp, u01(r0.y));
+    s[1] = lerpf(-mp, mp, u01(r0.z));
+    s[2] = lerpf(-mp, mp, u01(r0.w));
+    const float az = lerpf(-1.0f, 1.0f, u01(r1.x));
+    const float phi = 6.2831853071795865f * u01(r1.y);
+    const float ang = c.init_max_angle * u01(r1.z);
+    const float rxy = sqrtf(fmaxf(1.0f - az * az, 0.0f));
+    const float ax = rxy * cosf(phi), ay = rxy * sinf(phi);
+    const float half = 0.5f * ang;
+    const float sh = sinf(half), ch = cosf(half);
+    s[3] = ch; s[4] = ax * sh; s[5] = ay * sh; s[6] = az * sh;
+    s[7] = lerpf(-mv, mv, u01(r2.x));
+    s[8] = lerpf(-mv, mv, u01(r2.y));
+    s[9] = lerpf(-mv, mv, u01(r2.z));
+    s[10] = lerpf(-mw, mw, u01(r3.x));
+    s[11] = lerpf(-mw, mw, u01(r3.y));
+    s[12] = lerpf(-mw, mw, u01(r3.z));
+    if (guided) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s[i] = 0.0f;
+        s[3] = 1.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[13 + i] = hover_rpm; la[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f[i] = 0.0f;
+    if (c.disturbance_force_std > 0.0f || c.disturbance_torque_std > 0.0f) {
+        const u32x4 r4 = rng_block(seed, 4, episode, genv, PURPOSE_STATE);
+        const u32x4 r5 = rng_block(seed, 5, episode, genv, PURPOSE_STATE);
+        float n[6];
+        box_muller(u01(r4.x), u01(r4.y), n[0], n[1]);
+        box_muller(u01(r4.z), u01(r4.w), n[2], n[3]);
+        box_muller(u01(r5.x), u01(r5.y), n[4], n[5]);
+        const float mg = mass * c.gravity;
+        const float arm = sqrtf(pos0x * pos0x + pos0y * pos0y);
+        const float fs = c.disturbance_force_std * mg;
+        const float ts = (c.disturbance_torque_std * mg) * arm;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { f[i] = fs * n[i]; f[3 + i] = ts * n[3 + i]; }
+    }
+}
+
+// ------------------------------------------------------------------ actor --------------
+// flat weight vector offsets (order of checkpoint.h:39,50,75,87,99,111,123,149,160)
+enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF_BH = 1952,
+       OFF_H0 = 2000, OFF_W2 = 2016, OFF_B2 = 2080 };
+
+// weights are read through the constant address space so that uniform indices select s_load
+typedef const float __attribute__((address_space(4))) * wptr_t;
+
+// sigma(x) = 1 / (1 + 2^(-x log2 e)) on v_exp_f32 + v_rcp_f32 (1 ulp each)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// tanh(x) = 2 sigma(2x) - 1
+__device__ __forceinline__ float fast_tanh(float x) {
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
+}
+
+// One recurrent step for this lane's env.  `w` is wave-uniform (kernel argument), every index
+// is a compile-time constant, so the weights arrive by scalar loads (s_load_dwordx*) and feed
+// v_fma_f32 as SGPR operands: no LDS traffic, no VGPRs for weights.
+// Dense: acc = b; acc = fma(W[o][k], x[k], acc), k ascending (same chain as the oracle).
+__device__ __forceinline__ void actor_step(wptr_t w, const float (&x)[22], float (&h)[16], float (&a)[4]) {
+    float y0[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        float acc = w[OFF_B0 + o];
+#pragma unroll
+        for (int k = 0; k < 22; ++k) acc = fmaf(w[OFF_W0 + o * 22 + k], x[k], acc);
+        y0[o] = fmaxf(acc, 0.0f);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float hn[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float gir = w[OFF_BI + j], giz = w[OFF_BI + 16 + j], gin = w[OFF_BI + 32 + j];
+        float ghr = w[OFF_BH + j], ghz = w[OFF_BH + 16 + j], ghn = w[OFF_BH + 32 + j];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            gir = fmaf(w[OFF_WI + (j) * 16 + k], y0[k], gir);
+            giz = fmaf(w[OFF_WI + (16 + j) * 16 + k], y0[k], giz);
+            gin = fmaf(w[OFF_WI + (32 + j) * 16 + k], y0[k], gin);
+            ghr = fmaf(w[OFF_WH + (j) * 16 + k], h[k], ghr);
+            ghz = fmaf(w[OFF_WH + (16 + j) * 16 + k], h[k], ghz);
+            ghn = fmaf(w[OFF_WH + (32 + j) * 16 + k], h[k], ghn);
+        }
+        const float r = fast_sigmoid(gir + ghr);
+        const float z = fast_sigmoid(giz + ghz);
+        const float n = fast_tanh(fmaf(r, ghn, gin));
+        hn[j] = fmaf(z, h[j] - n, n);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h[j] = hn[j];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float acc = w[OFF_B2 + o];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(w[OFF_W2 + o * 16 + k], h[k], acc);
+        a[o] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ episode statistics -
+struct Stats { float ret; uint32_t steps; float fin_ret; uint32_t fin_len, fin_cnt, fin_term; };
+
+// returns true when the episode ended with this transition
+__device__ __forceinline__ bool stats_update(uint32_t step_limit, float r, bool term, Stats& st) {
+    st.ret += r;
+    st.steps += 1;
+    if (term || st.steps >= step_limit) {
+        st.fin_ret = st.ret; st.fin_len = st.steps; st.fin_cnt += 1; st.fin_term += term ? 1u : 0u;
+        st.ret = 0.0f; st.steps = 0;
+        return true;
+    }
+    return false;
+}
+
+}  // namespace rq

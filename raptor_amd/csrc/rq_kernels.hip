@@ -1,0 +1,318 @@
+// rq_kernels.hip — CDNA4 (gfx950) kernels of the quadrotor rollout path.
+//
+// Mapping: one wavefront lane = one environment; env i of a batch reads field f at
+// base[f*ld + i], so every vector memory instruction of a wave touches 256 contiguous bytes.
+// No inter-block data reuse exists (envs are independent), so block->XCD placement is
+// irrelevant for these kernels; the grid is simply ceil(n / block).
+//
+//   kernel               replaces (reference call site)                          bound
+//   k_sample_params      vector.sample_initial_parameters   README.md:60         HBM (write 104 B/env)
+//   k_sample_state       vector.sample_initial_state        README.md:61         HBM
+//   k_observe            vector.observe                     README.md:96         HBM (read 84 B, write 104 B /env)
+//   k_actor_step         Raptor.evaluate_step               README.md:97         HBM at large n (232 B/env, 3.9 kFLOP)
+//   k_step               vector.step + state.assign         README.md:98-99      HBM (~320 B/env)
+//   k_rollout_fused      the loop body README.md:95-99 x K                       fp32 VALU (state in registers)
+#include "rq_device_math.hpp"
+
+namespace rq {
+
+static constexpr int kBlock = 256;      // 4 waves; streaming kernels
+static constexpr int kFusedBlock = 64;  // 1 wave per workgroup: spreads 65 536 envs as 1024 WGs over 256 CUs
+
+__device__ __forceinline__ uint32_t env_index() { return blockIdx.x * blockDim.x + threadIdx.x; }
+
+// ------------------------------------------------------------------ sampling -----------
+__global__ __launch_bounds__(kBlock) void k_sample_params(Batch b, SampleCfg c, uint64_t seed, uint32_t epoch,
+                                                          float* __restrict__ params) {
+    const uint32_t i = env_index();
+    if (i >= b.n) return;
+    float p[RQ_PARAM_DIM];
+    sample_params(c, seed, epoch, b.env_offset + i, p);
+#pragma unroll
+    for (int f = 0; f < RQ_PARAM_DIM; ++f) params[(size_t)f * b.ld + i] = p[f];
+}
+
+__global__ __launch_bounds__(kBlock) void k_sample_state(Batch b, SampleCfg c, uint64_t seed,
+                                                         const float* __restrict__ params, float* __restrict__ state,
+                                                         uint32_t* __restrict__ episode, uint8_t* __restrict__ frozen) {
+    const uint32_t i = env_index();
+    if (i >= b.n) return;
+    const uint32_t ep = episode[i];
+    float s[17], la[4], f[6];
+    sample_state(c, seed, ep, b.env_offset + i, params[(size_t)RQ_P_MASS * b.ld + i],
+                 params[(size_t)RQ_P_HOVER_RPM * b.ld + i], params[(size_t)RQ_P_ROTOR_POS * b.ld + i],
+                 params[(size_t)(RQ_P_ROTOR_POS + 1) * b.ld + i], s, la, f);
+#pragma unroll
+    for (int k = 0; k < 17; ++k) state[(size_t)k * b.ld + i] = s[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) state[(size_t)(RQ_S_LAST_ACTION + k) * b.ld + i] = la[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) state[(size_t)(RQ_S_FORCE + k) * b.ld + i] = f[k];
+    episode[i] = ep + 1;
+    frozen[i] = 0;
+}
+
+// ------------------------------------------------------------------ observe ------------
+template <bool NOISE>
+__global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64_t seed, uint32_t epoch,
+                                                    const float* __restrict__ params,
+                                                    const float* __restrict__ state, float* __restrict__ obs) {
+    const uint32_t i = env_index();
+    if (i >= b.n) return;
+    float y[17], la[4];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) y[k] = state[(size_t)k * b.ld + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) la[k] = state[(size_t)(RQ_S_LAST_ACTION + k) * b.ld + i];
+    const float rmin = params[(size_t)RQ_P_RPM_MIN * b.ld + i];
+    const float rmax = params[(size_t)RQ_P_RPM_MAX * b.ld + i];
+    float o[22];
+    observe_head<NOISE>(y, la, nc, seed, epoch, b.env_offset + i, o);
+#pragma unroll
+    for (int k = 0; k < 22; ++k) obs[(size_t)k * b.ld + i] = o[k];
+    // privileged tail: normalised rotor speeds
+    const float inv = 2.0f / (rmax - rmin);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) obs[(size_t)(22 + k) * b.ld + i] = fmaf(y[13 + k] - rmin, inv, -1.0f);
+}
+
+// ------------------------------------------------------------------ actor --------------
+__global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* __restrict__ w,
+                                                       const float* __restrict__ obs, uint32_t ld_obs,
+                                                       float* __restrict__ hidden, uint32_t ld_h,
+                                                       float* __restrict__ act, uint32_t ld_act,
+                                                       const uint8_t* __restrict__ frozen) {
+    const uint32_t i = env_index();
+    if (i >= n) return;
+    if (frozen != nullptr && frozen[i]) return;
+    float x[22], h[16], a[4];
+#pragma unroll
+    for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) h[k] = hidden[(size_t)k * ld_h + i];
+    actor_step((wptr_t)(uint64_t)w, x, h, a);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hidden[(size_t)k * ld_h + i] = h[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
+}
+
+// ------------------------------------------------------------------ step ---------------
+__device__ __forceinline__ Stats load_stats(const StatsPtrs& st, uint32_t i) {
+    return {st.returns[i], st.steps[i], st.fin_returns[i], st.fin_lengths[i], st.fin_counts[i], st.fin_terminated[i]};
+}
+__device__ __forceinline__ void store_stats(const StatsPtrs& st, uint32_t i, const Stats& s, bool ended) {
+    st.returns[i] = s.ret;
+    st.steps[i] = s.steps;
+    if (ended) {
+        st.fin_returns[i] = s.fin_ret; st.fin_lengths[i] = s.fin_len;
+        st.fin_counts[i] = s.fin_cnt; st.fin_terminated[i] = s.fin_term;
+    }
+}
+
+template <bool ROLLOUT>
+__global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float* __restrict__ params,
+                                                 const float* state, const float* __restrict__ action,
+                                                 float* next_state, StatsPtrs st, uint32_t flags, SampleCfg sc,
+                                                 uint64_t seed, float* __restrict__ hidden,
+                                                 const float* __restrict__ weights) {
+    const uint32_t i = env_index();
+    if (i >= b.n) return;
+    if (ROLLOUT && st.frozen[i]) return;
+    const size_t ld = b.ld;
+    const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
+    float y[17], f6[6], a[4], ac[4];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) y[j] = state[(size_t)j * ld + i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) f6[j] = state[(size_t)(RQ_S_FORCE + j) * ld + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = action[(size_t)j * ld + i];
+    Stats s = load_stats(st, i);
+    const Disturbance ds = make_disturbance(k, c.gravity, f6);
+    bool term;
+    const float r = step_inplace(c, k, ds, y, a, ac, term);
+    const bool ended = stats_update(c.episode_step_limit, r, term, s);
+    st.last_reward[i] = r;
+    st.last_terminated[i] = term ? 1 : 0;
+    store_stats(st, i, s, ended);
+    bool write_dist = (next_state != state);
+    if (ROLLOUT && ended) {
+        if (flags & RQ_ROLLOUT_AUTORESET) {
+            const uint32_t ep = st.episode[i];
+            sample_state(sc, seed, ep, b.env_offset + i, params[(size_t)RQ_P_MASS * ld + i],
+                         params[(size_t)RQ_P_HOVER_RPM * ld + i], params[(size_t)RQ_P_ROTOR_POS * ld + i],
+                         params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], y, ac, f6);
+            st.episode[i] = ep + 1;
+            write_dist = true;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = ((wptr_t)(uint64_t)weights)[OFF_H0 + j];
+        } else {
+            st.frozen[i] = 1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 17; ++j) next_state[(size_t)j * ld + i] = y[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) next_state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i] = ac[j];
+    if (write_dist) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) next_state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
+    }
+}
+
+// ------------------------------------------------------------------ fused rollout ------
+// K iterations of observe -> evaluate_step -> step -> assign with the env state, the GRU
+// hidden state, the per-env constants and the episode statistics resident in VGPRs; HBM is
+// touched once before and once after the K steps.
+template <bool NOISE, bool AUTORESET>
+__global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
+                                                               uint64_t seed, uint32_t epoch0, uint32_t n_steps,
+                                                               const float* __restrict__ params,
+                                                               float* __restrict__ state,
+                                                               float* __restrict__ hidden,
+                                                               const float* __restrict__ w, StatsPtrs st) {
+    const uint32_t i = env_index();
+    if (i >= b.n) return;
+    if (st.frozen[i]) return;
+    const size_t ld = b.ld;
+    const uint64_t genv = b.env_offset + i;
+    const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
+    float y[17], la[4], f6[6], h[16];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) y[j] = state[(size_t)j * ld + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) la[j] = state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) f6[j] = state[(size_t)(RQ_S_FORCE + j) * ld + i];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h[j] = hidden[(size_t)j * ld + i];
+    Stats s = load_stats(st, i);
+    Disturbance ds = make_disturbance(k, c.gravity, f6);
+    float last_r = st.last_reward[i];
+    bool last_t = st.last_terminated[i] != 0;
+    bool frozen = false, any_end = false, dist_changed = false;
+    uint32_t ep = AUTORESET ? st.episode[i] : 0u;
+
+    for (uint32_t t = 0; t < n_steps; ++t) {
+        float o[22], a[4], ac[4];
+        observe_head<NOISE>(y, la, nc, seed, epoch0 + t, genv, o);
+        // launder the (wave-uniform) weight pointer once per step: otherwise LICM hoists all
+        // 2 084 scalar weight loads out of the loop and spills them
+        uint64_t wbits = (uint64_t)w;
+        asm volatile("" : "+s"(wbits));
+        actor_step((wptr_t)wbits, o, h, a);
+        bool term;
+        const float r = step_inplace(c, k, ds, y, a, ac, term);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) la[j] = ac[j];
+        last_r = r; last_t = term;
+        if (stats_update(c.episode_step_limit, r, term, s)) {
+            any_end = true;
+            if (AUTORESET) {
+                sample_state(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
+                             params[(size_t)RQ_P_HOVER_RPM * ld + i], params[(size_t)RQ_P_ROTOR_POS * ld + i],
+                             params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], y, la, f6);
+                ep += 1;
+                ds = make_disturbance(k, c.gravity, f6);
+                dist_changed = true;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) h[j] = ((wptr_t)(uint64_t)w)[OFF_H0 + j];
+            } else {
+                frozen = true;
+                break;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 17; ++j) state[(size_t)j * ld + i] = y[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i] = la[j];
+    if (dist_changed) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = h[j];
+    store_stats(st, i, s, any_end);
+    st.last_reward[i] = last_r;
+    st.last_terminated[i] = last_t ? 1 : 0;
+    if (AUTORESET) st.episode[i] = ep;
+    if (frozen) st.frozen[i] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, float v, uint32_t count) {
+    const uint32_t i = env_index();
+    if (i < count) p[i] = v;
+}
+
+// ------------------------------------------------------------------ launchers ----------
+static inline unsigned grid_for(uint32_t n, int block) { return (n + block - 1) / block; }
+
+hipError_t launch_sample_params(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, uint32_t epoch, float* params) {
+    if (b.n == 0) return hipSuccess;
+    k_sample_params<<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, seed, epoch, params);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params,
+                               float* state, uint32_t* episode, uint8_t* frozen) {
+    if (b.n == 0) return hipSuccess;
+    k_sample_state<<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, seed, params, state, episode, frozen);
+    return hipGetLastError();
+}
+
+hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint64_t seed, uint32_t epoch,
+                          const float* params, const float* state, float* obs) {
+    if (b.n == 0) return hipSuccess;
+    if (noise) k_observe<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, params, state, obs);
+    else       k_observe<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, params, state, obs);
+    return hipGetLastError();
+}
+
+hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* weights, const float* obs, uint32_t ld_obs,
+                             float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
+                             int precision) {
+    if (n == 0) return hipSuccess;
+    (void)precision;
+    k_actor_step<<<grid_for(n, kBlock), kBlock, 0, s>>>(n, weights, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+    return hipGetLastError();
+}
+
+hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
+                       const float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
+                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights) {
+    if (b.n == 0) return hipSuccess;
+    if (rollout)
+        k_step<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
+                                                              sc, seed, hidden, weights);
+    else
+        k_step<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
+                                                               sc, seed, hidden, weights);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
+                                uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
+                                const float* params, float* state, float* hidden, const float* weights,
+                                StatsPtrs st, int precision) {
+    if (b.n == 0 || n_steps == 0) return hipSuccess;
+    (void)precision;
+    const unsigned g = grid_for(b.n, kFusedBlock);
+    const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
+#define RQ_LAUNCH_FUSED(NZ, AR) \
+    k_rollout_fused<NZ, AR><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, st)
+    if (noise) { if (ar) RQ_LAUNCH_FUSED(true, true); else RQ_LAUNCH_FUSED(true, false); }
+    else       { if (ar) RQ_LAUNCH_FUSED(false, true); else RQ_LAUNCH_FUSED(false, false); }
+#undef RQ_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_f32(hipStream_t s, float* p, float v, uint32_t count) {
+    if (count == 0) return hipSuccess;
+    k_fill_f32<<<grid_for(count, kBlock), kBlock, 0, s>>>(p, v, count);
+    return hipGetLastError();
+}
+
+}  // namespace rq

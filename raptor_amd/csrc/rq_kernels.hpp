@@ -1,0 +1,91 @@
+// rq_kernels.hpp — host-visible interface of the HIP kernels (internal to libraptor_quad.so).
+// POD argument blocks are passed to the kernels by value (they land in SGPRs via the kernarg
+// segment); pointers are device pointers to field-major struct-of-arrays buffers.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "../../include/raptor_quad.h"
+
+namespace rq {
+
+struct StepCfg {   // the rq_env_config members one transition reads
+    float dt, gravity;
+    uint32_t episode_step_limit;
+    float reward_scale, reward_constant, reward_termination_penalty;
+    float reward_position, reward_orientation, reward_linear_velocity, reward_angular_velocity, reward_action;
+    uint32_t termination_enabled;
+    float termination_position, termination_linear_velocity, termination_angular_velocity;
+};
+
+struct NoiseCfg { float position, orientation, linear_velocity, angular_velocity; };
+
+struct SampleCfg {   // rq_env_config members the samplers read
+    float gravity;
+    uint32_t domain_randomization;
+    float dr_scale_min, dr_scale_max, dr_t2w_min, dr_t2w_max, dr_kq_min, dr_kq_max, dr_tau_min, dr_tau_max;
+    float init_guidance, init_max_position, init_max_angle, init_max_linear_velocity, init_max_angular_velocity;
+    float disturbance_force_std, disturbance_torque_std;
+};
+
+inline StepCfg step_cfg(const rq_env_config& c) {
+    return {c.dt, c.gravity, c.episode_step_limit, c.reward_scale, c.reward_constant,
+            c.reward_termination_penalty, c.reward_position, c.reward_orientation,
+            c.reward_linear_velocity, c.reward_angular_velocity, c.reward_action,
+            c.termination_enabled, c.termination_position, c.termination_linear_velocity,
+            c.termination_angular_velocity};
+}
+inline NoiseCfg noise_cfg(const rq_env_config& c) {
+    return {c.noise_position, c.noise_orientation, c.noise_linear_velocity, c.noise_angular_velocity};
+}
+inline bool noise_enabled(const rq_env_config& c) {
+    return c.noise_position > 0.f || c.noise_orientation > 0.f || c.noise_linear_velocity > 0.f ||
+           c.noise_angular_velocity > 0.f;
+}
+inline SampleCfg sample_cfg(const rq_env_config& c) {
+    return {c.gravity, c.domain_randomization, c.dr_scale_min, c.dr_scale_max,
+            c.dr_thrust_to_weight_min, c.dr_thrust_to_weight_max, c.dr_torque_const_min,
+            c.dr_torque_const_max, c.dr_motor_tau_min, c.dr_motor_tau_max, c.init_guidance,
+            c.init_max_position, c.init_max_angle, c.init_max_linear_velocity,
+            c.init_max_angular_velocity, c.disturbance_force_std, c.disturbance_torque_std};
+}
+
+// Episode statistics of one VectorEnvironment, all [ld] arrays on the device.
+struct StatsPtrs {
+    float* returns; uint32_t* steps;
+    float* fin_returns; uint32_t* fin_lengths; uint32_t* fin_counts; uint32_t* fin_terminated;
+    float* last_reward; uint8_t* last_terminated;
+    uint8_t* frozen; uint32_t* episode;
+};
+
+struct Batch {           // which envs a launch covers
+    uint32_t n, ld;      // envs, leading dimension of every SoA buffer
+    uint64_t env_offset; // global id of env 0 (RNG key)
+};
+
+// vector.sample_initial_parameters (README.md:60)
+hipError_t launch_sample_params(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, uint32_t epoch, float* params);
+// vector.sample_initial_state (README.md:61): uses episode[i] as the RNG counter, increments it, unfreezes
+hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params,
+                               float* state, uint32_t* episode, uint8_t* frozen);
+// vector.observe (README.md:96): obs [RQ_OBSERVATION_DIM][ld]
+hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint64_t seed, uint32_t epoch,
+                          const float* params, const float* state, float* obs);
+// Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.
+// frozen != nullptr: envs with frozen[i] != 0 are skipped (rollout semantics).
+hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* weights, const float* obs, uint32_t ld_obs,
+                             float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
+                             int precision);
+// vector.step (README.md:98) + reward/termination/statistics.  rollout != 0 adds the
+// episode-end handling of rq_rollout (freeze or auto-reset incl. hidden-state reset).
+hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
+                       const float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
+                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights);
+// the loop body README.md:95-99 x n_steps in one launch
+hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
+                                uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
+                                const float* params, float* state, float* hidden, const float* weights,
+                                StatsPtrs st, int precision);
+// out[i] = value for i < count (uint32 / float / uint8 fills on the stream)
+hipError_t launch_fill_f32(hipStream_t s, float* p, float v, uint32_t count);
+
+}  // namespace rq

@@ -1,0 +1,119 @@
+"""Drop-in for ``foundation_policy.Raptor`` (README.md:16-24,46-48,94,97).
+
+    from raptor_amd.foundation_policy import Raptor
+    policy = Raptor()
+    policy.reset()
+    action = policy.evaluate_step(observation[:, :22])     # [B,22] float32 -> [B,4]
+
+The policy is the published RAPTOR checkpoint: Dense(22->16, ReLU) -> GRU(16) -> Dense(16->4)
+(checkpoint.h:39-65,75-139,149-175; chain checkpoint.h:185), 2 084 float32 parameters shipped
+as ``raptor_amd/data/raptor_policy.bin`` (extracted by tests/golden/make_golden.py).  The
+output is the raw Dense output — the shipped actor has no squashing layer (checkpoint.h:170),
+clipping to [-1,1] happens in the consumer (``vector.step``).  The GRU hidden state is kept
+per batch element between calls; ``reset()`` restores ``initial_hidden_state``.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import POLICY_INPUT_DIM, POLICY_NUM_WEIGHTS, POLICY_OUTPUT_DIM, POLICY_HIDDEN_DIM
+
+WEIGHTS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "raptor_policy.bin")
+
+
+def load_weights(path=WEIGHTS_PATH):
+    w = np.fromfile(path, dtype="<f4")
+    if w.size != POLICY_NUM_WEIGHTS:
+        raise ValueError(f"{path}: expected {POLICY_NUM_WEIGHTS} float32 values, found {w.size}")
+    return np.ascontiguousarray(w, np.float32)
+
+
+_default_device = None
+
+
+def _get_default_device():
+    global _default_device
+    if _default_device is None:
+        from .l2f import Device
+        _default_device = Device(0)
+    return _default_device
+
+
+class Raptor:
+    def __init__(self, device=None, weights=None):
+        self._weights = load_weights() if weights is None else np.ascontiguousarray(weights, np.float32)
+        if self._weights.size != POLICY_NUM_WEIGHTS:
+            raise ValueError(f"expected {POLICY_NUM_WEIGHTS} weights")
+        self._device = device
+        self._h = None
+        self._fin = None
+
+    # the C object is created on first use so that ``Raptor()`` itself needs no device argument
+    def _handle(self, device=None):
+        if self._h is None:
+            if self._device is None:
+                self._device = device if device is not None else _get_default_device()
+            h = C.c_void_p()
+            _lib.call("rq_policy_create", self._device._h, _lib.fptr(self._weights), self._weights.size, C.byref(h))
+            self._h = h
+            self._fin = weakref.finalize(self, _lib.load().rq_policy_destroy, h)
+        elif device is not None and device is not self._device:
+            raise _lib.RaptorQuadError(-5, "policy was created on another device")
+        return self._h
+
+    @property
+    def weights(self):
+        return self._weights
+
+    def reset(self):
+        """README.md:21,94 — hidden state <- initial_hidden_state (checkpoint.h:123, zeros)."""
+        _lib.call("rq_policy_reset", self._handle())
+
+    def evaluate_step(self, observation):
+        """README.md:24,97 — one recurrent step; ``observation`` [B, >=22] -> action [B,4]."""
+        obs = np.asarray(observation, np.float32)
+        if obs.ndim != 2 or obs.shape[1] < POLICY_INPUT_DIM:
+            raise ValueError("observation must be [batch, >=22]")
+        if not obs.flags.c_contiguous:
+            # rows may be strided (e.g. observation[:, :22] of a wider array): keep the row stride
+            if obs.strides[1] == 4 and obs.strides[0] % 4 == 0 and obs.strides[0] >= 4 * POLICY_INPUT_DIM:
+                stride = obs.strides[0] // 4
+            else:
+                obs = np.ascontiguousarray(obs)
+                stride = obs.shape[1]
+        else:
+            stride = obs.shape[1]
+        batch = obs.shape[0]
+        act = np.empty((batch, POLICY_OUTPUT_DIM), np.float32)
+        _lib.call("rq_policy_evaluate_step", self._handle(), None, obs.ctypes.data_as(C.POINTER(C.c_float)),
+                  batch, stride, _lib.fptr(act))
+        return act
+
+    def evaluate_step_device(self, env):
+        """Device-resident variant: reads the env's observation buffer (``observe(..., None, ...)``)
+        and writes its action buffer (consumed by ``step(..., action=None, ...)``)."""
+        _lib.call("rq_policy_evaluate_step", self._handle(env._device), env._require("environment"), None,
+                  env.N_ENVIRONMENTS, 0, None)
+
+    def hidden_state(self, batch):
+        out = np.empty((batch, POLICY_HIDDEN_DIM), np.float32)
+        _lib.call("rq_policy_get_hidden", self._handle(), _lib.fptr(out), batch)
+        return out
+
+    def set_hidden_state(self, hidden):
+        h = np.ascontiguousarray(hidden, np.float32)
+        assert h.ndim == 2 and h.shape[1] == POLICY_HIDDEN_DIM
+        _lib.call("rq_policy_set_hidden", self._handle(), _lib.fptr(h), h.shape[0])
+
+    def selftest(self, input_seq, expected, tolerance=1e-5):
+        """Known-answer self-test (the embedded backend's boot test, README.md:136-139).
+        ``input_seq`` [T,B,22], ``expected`` [T,B,4]; returns max |out - expected|."""
+        x = np.ascontiguousarray(input_seq, np.float32)
+        y = np.ascontiguousarray(expected, np.float32)
+        err = C.c_float()
+        _lib.call("rq_policy_selftest", self._handle(), _lib.fptr(x), _lib.fptr(y), x.shape[0], x.shape[1],
+                  float(tolerance), C.byref(err))
+        return float(err.value)

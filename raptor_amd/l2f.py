@@ -1,0 +1,338 @@
+"""Drop-in for the ``l2f`` Python surface used by the rollout loop of rl-tools/raptor.
+
+The names, argument order and in-place semantics follow /root/reference/README.md:41-101:
+
+    import raptor_amd.l2f as l2f
+    from raptor_amd.l2f import vector8 as vector      # or: vector = l2f.vector(65536)
+    device = l2f.Device(); rng = vector.VectorRng(); env = vector.VectorEnvironment()
+    params = vector.VectorParameters(); state = vector.VectorState(); next_state = vector.VectorState()
+    observation = np.zeros((env.N_ENVIRONMENTS, env.OBSERVATION_DIM), dtype=np.float32)
+    vector.initialize_rng(device, rng, 0)
+    vector.initialize_environment(device, env)
+    vector.sample_initial_parameters(device, env, params, rng)
+    vector.sample_initial_state(device, env, params, state, rng)
+    vector.observe(device, env, params, state, observation, rng)
+    dts = vector.step(device, env, params, state, action, next_state, rng)
+    state.assign(next_state)
+
+Differences that are deliberate (DESIGN.md "Boundary"):
+  * the batch size is a runtime value: ``l2f.vector(N)`` builds the module-like object the
+    reference pre-compiles as ``vector1 ... vectorN``; ``vector8`` is ``vector(8)``;
+  * passing ``None`` for ``observation`` / ``action`` keeps the data in HBM (zero PCIe
+    traffic); ``vector.rollout`` runs the whole loop body on the device;
+  * everything executes on an MI355X through libraptor_quad.so — no CPU path exists here.
+
+The UI / JSON message helpers of l2f (README.md:63-92) are visualisation and out of scope.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ACTION_DIM, OBSERVATION_DIM, PARAM_DIM, STATE_DIM, ROLLOUT_AUTORESET, ROLLOUT_CHAINED,
+                   ROLLOUT_FUSED, EnvConfig, RaptorQuadError)
+
+__all__ = ["Device", "vector", "vector8", "EnvConfig", "RaptorQuadError"]
+
+
+class Device:
+    """``l2f.Device()`` (README.md:49): one HIP device + one stream."""
+
+    def __init__(self, ordinal=0):
+        h = C.c_void_p()
+        _lib.call("rq_device_create", int(ordinal), C.byref(h))
+        self._h = h
+        self.ordinal = int(ordinal)
+        self._fin = weakref.finalize(self, _lib.load().rq_device_destroy, h)
+
+    def synchronize(self):
+        _lib.call("rq_device_synchronize", self._h)
+
+    def timer_start(self):
+        """HIP-event stopwatch on this device's stream."""
+        _lib.call("rq_device_timer_start", self._h)
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.call("rq_device_timer_stop", self._h, C.byref(ms))
+        return float(ms.value)
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        _lib.call("rq_device_stream", self._h, C.byref(s))
+        return s.value
+
+    @staticmethod
+    def count():
+        n = C.c_int()
+        lib = _lib.load()
+        lib.rq_device_count(C.byref(n))
+        return n.value
+
+
+class _Handle:
+    """Lazily created C object (the reference's constructors take no device argument)."""
+    _destroy = None
+
+    def __init__(self):
+        self._h = None
+        self._fin = None
+
+    def _adopt(self, h):
+        self._h = h
+        self._fin = weakref.finalize(self, getattr(_lib.load(), self._destroy), h)
+
+    def _require(self, what):
+        if self._h is None:
+            raise RaptorQuadError(-6, f"{what} is not initialised yet")
+        return self._h
+
+
+class _StateView:
+    """One element of ``VectorState.states`` (README.md:73-75): a host-side snapshot."""
+    __slots__ = ("_row",)
+
+    def __init__(self, row):
+        self._row = row
+
+    position = property(lambda s: s._row[0:3])
+    orientation = property(lambda s: s._row[3:7])
+    linear_velocity = property(lambda s: s._row[7:10])
+    angular_velocity = property(lambda s: s._row[10:13])
+    rpm = property(lambda s: s._row[13:17])
+    last_action = property(lambda s: s._row[17:21])
+    force = property(lambda s: s._row[21:24])
+    torque = property(lambda s: s._row[24:27])
+
+
+class VectorModule:
+    """What ``from l2f import vector8 as vector`` gives, for a runtime batch size.
+
+    ``global_env_offset``: global id of env 0 when one logical batch is sharded over several
+    devices/processes — the RNG is keyed by global id, so results do not depend on sharding.
+    """
+
+    def __init__(self, n_environments, global_env_offset=0):
+        if n_environments <= 0:
+            raise ValueError("n_environments must be positive")
+        self.N_ENVIRONMENTS = int(n_environments)
+        self.OBSERVATION_DIM = OBSERVATION_DIM
+        self.ACTION_DIM = ACTION_DIM
+        self.global_env_offset = int(global_env_offset)
+        mod = self
+
+        class VectorRng(_Handle):
+            _destroy = "rq_rng_destroy"
+
+            def _ensure(self, device):
+                if self._h is None:
+                    h = C.c_void_p()
+                    _lib.call("rq_rng_create", device._h, C.byref(h))
+                    self._adopt(h)
+                    self._device = device
+                return self._h
+
+            @property
+            def epoch(self):
+                e = C.c_uint32()
+                _lib.call("rq_rng_get", self._require("rng"), None, C.byref(e))
+                return e.value
+
+            @property
+            def seed(self):
+                s = C.c_uint64()
+                _lib.call("rq_rng_get", self._require("rng"), C.byref(s), None)
+                return s.value
+
+        class VectorEnvironment(_Handle):
+            _destroy = "rq_env_destroy"
+            N_ENVIRONMENTS = mod.N_ENVIRONMENTS
+            OBSERVATION_DIM = OBSERVATION_DIM
+            ACTION_DIM = ACTION_DIM
+
+            def _ensure(self, device):
+                if self._h is None:
+                    h = C.c_void_p()
+                    _lib.call("rq_env_create", device._h, mod.N_ENVIRONMENTS, mod.global_env_offset, C.byref(h))
+                    self._adopt(h)
+                    self._device = device
+                return self._h
+
+            # --- configuration (the MDP constants initialize_environment fills) ---
+            @property
+            def config(self):
+                cfg = EnvConfig()
+                _lib.call("rq_env_get_config", self._require("environment"), C.byref(cfg))
+                return cfg
+
+            @config.setter
+            def config(self, cfg):
+                _lib.call("rq_env_set_config", self._require("environment"), C.byref(cfg))
+
+            # --- device-resident observation / action buffers ---
+            def observation(self):
+                out = np.empty((mod.N_ENVIRONMENTS, OBSERVATION_DIM), np.float32)
+                _lib.call("rq_env_get_observation", self._require("environment"), _lib.fptr(out))
+                return out
+
+            def action(self):
+                out = np.empty((mod.N_ENVIRONMENTS, ACTION_DIM), np.float32)
+                _lib.call("rq_env_get_action", self._require("environment"), _lib.fptr(out))
+                return out
+
+            def set_action(self, action):
+                a = np.ascontiguousarray(action, np.float32)
+                assert a.shape == (mod.N_ENVIRONMENTS, ACTION_DIM)
+                _lib.call("rq_env_set_action", self._require("environment"), _lib.fptr(a))
+
+            # --- episode statistics ---
+            def _stat(self, fn, dtype, out=None):
+                h = self._require("environment")
+                if out is not None:   # a torch tensor on the same HIP device
+                    _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1)
+                    return out
+                a = np.empty(mod.N_ENVIRONMENTS, dtype)
+                _lib.call(fn, h, a.ctypes.data_as(C.c_void_p), 0)
+                return a
+
+            def rewards(self, out=None): return self._stat("rq_env_get_rewards", np.float32, out)
+            def terminated(self, out=None): return self._stat("rq_env_get_terminated", np.uint8, out)
+            def returns(self, out=None): return self._stat("rq_env_get_returns", np.float32, out)
+            def episode_steps(self, out=None): return self._stat("rq_env_get_episode_steps", np.uint32, out)
+            def finished_returns(self, out=None): return self._stat("rq_env_get_finished_returns", np.float32, out)
+            def finished_lengths(self, out=None): return self._stat("rq_env_get_finished_lengths", np.uint32, out)
+            def finished_counts(self, out=None): return self._stat("rq_env_get_finished_counts", np.uint32, out)
+            def finished_terminated(self, out=None): return self._stat("rq_env_get_finished_terminated", np.uint32, out)
+
+            def reset_statistics(self):
+                _lib.call("rq_env_reset_statistics", self._require("environment"))
+
+        class _Container(_Handle):
+            _create = None
+            _get = None
+            _set = None
+            _dim = 0
+
+            def _ensure(self, env):
+                if self._h is None:
+                    h = C.c_void_p()
+                    _lib.call(self._create, env._require("environment"), C.byref(h))
+                    self._adopt(h)
+                    self._env = env
+                return self._h
+
+            def numpy(self):
+                out = np.empty((mod.N_ENVIRONMENTS, self._dim), np.float32)
+                _lib.call(self._get, self._require(type(self).__name__), _lib.fptr(out))
+                return out
+
+            def set(self, array):
+                a = np.ascontiguousarray(array, np.float32)
+                assert a.shape == (mod.N_ENVIRONMENTS, self._dim), a.shape
+                _lib.call(self._set, self._require(type(self).__name__), _lib.fptr(a))
+
+        class VectorParameters(_Container):
+            _destroy, _create, _get, _set, _dim = ("rq_params_destroy", "rq_params_create", "rq_params_get",
+                                                   "rq_params_set", PARAM_DIM)
+
+        class VectorState(_Container):
+            _destroy, _create, _get, _set, _dim = ("rq_state_destroy", "rq_state_create", "rq_state_get",
+                                                   "rq_state_set", STATE_DIM)
+
+            def assign(self, other):
+                """``state.assign(next_state)`` (README.md:99)."""
+                if self._h is None:
+                    self._ensure(other._env)
+                _lib.call("rq_state_assign", self._h, other._require("VectorState"))
+
+            @property
+            def states(self):
+                """Host snapshot, one view per env (``.position`` etc., README.md:73-75)."""
+                return [_StateView(r) for r in self.numpy()]
+
+            def __copy__(self):
+                c = VectorState()
+                if self._h is not None:
+                    c._ensure(self._env)
+                    c.assign(self)
+                return c
+
+        self.VectorRng = VectorRng
+        self.VectorEnvironment = VectorEnvironment
+        self.VectorParameters = VectorParameters
+        self.VectorState = VectorState
+
+    # ------------------------------------------------------------------ l2f vector:: functions
+    def initialize_rng(self, device, rng, seed):
+        """README.md:58"""
+        _lib.call("rq_initialize_rng", device._h, rng._ensure(device), int(seed))
+
+    def initialize_environment(self, device, env):
+        """README.md:59 — default MDP configuration."""
+        _lib.call("rq_initialize_environment", device._h, env._ensure(device))
+
+    def sample_initial_parameters(self, device, env, params, rng):
+        """README.md:60 — per-env dynamics parameters (domain randomisation)."""
+        _lib.call("rq_sample_initial_parameters", device._h, env._require("environment"), params._ensure(env),
+                  rng._require("rng"))
+
+    def sample_initial_state(self, device, env, params, state, rng):
+        """README.md:61"""
+        _lib.call("rq_sample_initial_state", device._h, env._require("environment"),
+                  params._require("VectorParameters"), state._ensure(env), rng._require("rng"))
+
+    def observe(self, device, env, params, state, observation, rng):
+        """README.md:96 — fills ``observation`` [N, OBSERVATION_DIM] float32 in place
+        (``None``: keep it in the env's device buffer)."""
+        ptr = None
+        if observation is not None:
+            if (observation.dtype != np.float32 or not observation.flags.c_contiguous or
+                    observation.shape != (self.N_ENVIRONMENTS, OBSERVATION_DIM)):
+                raise ValueError("observation must be C-contiguous float32 [N_ENVIRONMENTS, OBSERVATION_DIM]")
+            ptr = _lib.fptr(observation)
+        _lib.call("rq_observe", device._h, env._require("environment"), params._require("VectorParameters"),
+                  state._require("VectorState"), ptr, rng._require("rng"))
+
+    def step(self, device, env, params, state, action, next_state, rng):
+        """README.md:98 — returns the list of per-env dt in seconds.
+        ``action`` [N,4] (``None``: the env's device action buffer, e.g. written by
+        ``Raptor.evaluate_step_device``)."""
+        aptr = None
+        if action is not None:
+            a = np.ascontiguousarray(action, np.float32)
+            if a.shape != (self.N_ENVIRONMENTS, ACTION_DIM):
+                raise ValueError("action must be [N_ENVIRONMENTS, 4]")
+            aptr = _lib.fptr(a)
+        dts = np.empty(self.N_ENVIRONMENTS, np.float32)
+        _lib.call("rq_step", device._h, env._require("environment"), params._require("VectorParameters"),
+                  state._require("VectorState"), aptr, next_state._ensure(env), rng._require("rng"),
+                  _lib.fptr(dts))
+        return dts.tolist()
+
+    def step_device(self, device, env, params, state, next_state, rng):
+        """``step`` without host traffic: action from the env's device buffer, no dt list."""
+        _lib.call("rq_step", device._h, env._require("environment"), params._require("VectorParameters"),
+                  state._require("VectorState"), None, next_state._ensure(env), rng._require("rng"), None)
+
+    def rollout(self, device, env, params, state, policy, rng, n_steps, mode="fused", autoreset=False):
+        """The loop body README.md:95-99, ``n_steps`` times, entirely on the device."""
+        m = {"fused": ROLLOUT_FUSED, "chained": ROLLOUT_CHAINED}[mode]
+        _lib.call("rq_rollout", device._h, env._require("environment"), params._require("VectorParameters"),
+                  state._require("VectorState"), policy._handle(device), rng._require("rng"), int(n_steps), m,
+                  ROLLOUT_AUTORESET if autoreset else 0)
+
+
+_modules = {}
+
+
+def vector(n_environments, global_env_offset=0):
+    """Runtime-sized equivalent of the reference's ``l2f.vectorN`` modules."""
+    key = (int(n_environments), int(global_env_offset))
+    if key not in _modules:
+        _modules[key] = VectorModule(*key)
+    return _modules[key]
+
+
+vector8 = vector(8)   # README.md:45

@@ -1,0 +1,101 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every declared symbol, agrees with
+the oracle on the configuration defaults, and fails loudly without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HAS_GPU, ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "raptor_quad.h")).read()
+    return sorted(set(re.findall(r"^RQ_API\s+[\w\s\*]+?\b(rq_\w+)\(", hdr, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from raptor_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 55
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/raptor_quad.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, set(declared) ^ set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_abi_version_and_status_strings():
+    from raptor_amd import _lib
+    lib = _lib.load()
+    assert lib.rq_abi_version() == 1
+    assert lib.rq_status_string(0) == b"ok"
+    assert b"device" in lib.rq_status_string(-2)
+
+
+def test_default_config_matches_oracle(oracle):
+    from raptor_amd import _lib
+    cfg = _lib.EnvConfig()
+    _lib.call("rq_env_default_config", ctypes.byref(cfg))
+    ref = oracle.default_config()
+    assert ctypes.sizeof(cfg) == ctypes.sizeof(ref) == cfg.struct_size == 144
+    assert bytes(cfg) == bytes(ref)
+
+
+def test_field_enums_match_header():
+    hdr = open(os.path.join(ROOT, "include", "raptor_quad.h")).read()
+    from raptor_amd import _lib
+    assert int(re.search(r"RQ_PARAM_DIM = (\d+)", hdr).group(1)) == _lib.PARAM_DIM
+    assert int(re.search(r"RQ_STATE_DIM = (\d+)", hdr).group(1)) == _lib.STATE_DIM
+    assert int(re.search(r"#define RQ_OBSERVATION_DIM (\d+)", hdr).group(1)) == _lib.OBSERVATION_DIM
+    assert int(re.search(r"#define RQ_POLICY_NUM_WEIGHTS (\d+)", hdr).group(1)) == _lib.POLICY_NUM_WEIGHTS
+
+
+def test_null_arguments_are_rejected_not_crashing():
+    from raptor_amd import _lib
+    lib = _lib.load()
+    assert lib.rq_device_count(None) == -1
+    assert lib.rq_env_default_config(None) == -1
+    assert lib.rq_device_create(0, None) == -1
+    assert b"null" in lib.rq_last_error()
+    assert lib.rq_device_destroy(None) == 0
+    assert lib.rq_env_destroy(None) == 0
+
+
+@pytest.mark.skipif(HAS_GPU, reason="only meaningful on a box without a GPU")
+def test_no_gpu_means_loud_failure():
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+    with pytest.raises(l2f.RaptorQuadError) as e:
+        l2f.Device()
+    assert e.value.status == -2
+    with pytest.raises(l2f.RaptorQuadError):
+        Raptor().evaluate_step(np.zeros((2, 22), np.float32))
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "raptor_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "raptor_oracle" not in txt and "libraptor_oracle" not in txt, fn
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), fn
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libraptor_quad.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "amdhip64" in out
+
+
+def test_vector_module_surface():
+    """Names of the l2f vector API (README.md:44-61,96-99)."""
+    import raptor_amd.l2f as l2f
+    from raptor_amd.l2f import vector8 as vector
+    for name in ("VectorRng", "VectorEnvironment", "VectorParameters", "VectorState", "initialize_rng",
+                 "initialize_environment", "sample_initial_parameters", "sample_initial_state", "observe", "step"):
+        assert hasattr(vector, name), name
+    env = vector.VectorEnvironment()
+    assert env.N_ENVIRONMENTS == 8 and env.OBSERVATION_DIM >= 22
+    assert l2f.vector(65536).N_ENVIRONMENTS == 65536
+    from raptor_amd.foundation_policy import Raptor
+    assert hasattr(Raptor, "reset") and hasattr(Raptor, "evaluate_step")

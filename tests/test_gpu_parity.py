@@ -1,0 +1,390 @@
+"""Parity of the HIP path (through the C ABI of libraptor_quad.so) against the oracle.
+
+Bars (DESIGN.md "Parity"):
+  * integer / index / mask work, parameter sampling, observe (no noise) and env transitions
+    for identical inputs: BIT-EXACT;
+  * anything behind a transcendental (actor gates, sin/cos of the initial attitude,
+    Box-Muller noise): float32 tolerance stated per test;
+  * the actor additionally against the reference's own known-answer vectors (< 1e-5).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACTOR_TOL = 1e-5        # abs, raw actions in [-2.8, 3.4]; reference KATs (checkpoint.h:197-215, h5:/example)
+INIT_TOL = 2e-6         # abs, initial attitude via sinf/cosf (device vs libm)
+NOISE_TOL = 2e-5        # abs per unit std, Box-Muller via logf/sinf/cosf
+CLOSED_LOOP_TOL = 2e-3  # abs on p, q, v after 500 closed-loop steps (actor ulps fed back through the dynamics)
+
+
+class World:
+    """All l2f-shaped objects for one batch, on the GPU, plus the oracle-side mirror."""
+
+    def __init__(self, device, oracle, n, seed=0, offset=0, **cfg_over):
+        import raptor_amd.l2f as l2f
+        from raptor_amd.foundation_policy import Raptor
+        self.O = oracle
+        self.n, self.seed, self.offset = n, seed, offset
+        self.device = device
+        self.vector = v = l2f.VectorModule(n, offset)
+        self.rng, self.env = v.VectorRng(), v.VectorEnvironment()
+        self.params, self.state, self.next_state = v.VectorParameters(), v.VectorState(), v.VectorState()
+        v.initialize_rng(device, self.rng, seed)
+        v.initialize_environment(device, self.env)
+        cfg = self.env.config
+        for k, val in cfg_over.items():
+            setattr(cfg, k, val)
+        self.env.config = cfg
+        self.cfg = oracle.default_config()
+        for k, val in cfg_over.items():
+            setattr(self.cfg, k, val)
+        assert bytes(self.cfg) == bytes(self.env.config)
+        self.policy = Raptor(device)
+        v.sample_initial_parameters(device, self.env, self.params, self.rng)
+        v.sample_initial_state(device, self.env, self.params, self.state, self.rng)
+        # oracle mirror
+        self.P = oracle.sample_initial_parameters(self.cfg, seed, 0, offset, n)
+        self.st = oracle.Stats(n)
+        self.S = oracle.sample_initial_state(self.cfg, seed, self.st.episode, offset, self.P)
+        self.H = np.zeros((n, 16), np.float32)
+
+    def sync_oracle_to_gpu_state(self):
+        """Start both sides from the GPU's initial state (it differs from the oracle's by sin/cos ulps)."""
+        self.S = self.state.numpy()
+
+
+@pytest.fixture(scope="module")
+def w1k(device, oracle):
+    return World(device, oracle, 1000)
+
+
+# ------------------------------------------------------------------------------ actor ------
+def test_actor_selftest_against_reference_kats(device, kat):
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    err = Raptor(device).selftest(x, y, tolerance=ACTOR_TOL)
+    assert err < ACTOR_TOL
+
+
+def test_actor_boot_selftest_first_5_steps(device, kat):
+    """The embedded backend's boot test: TEST_SEQUENCE_LENGTH_ACTUAL = 5, batch 2 (README.md:136-139)."""
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    assert Raptor(device).selftest(x[:5], y[:5], tolerance=ACTOR_TOL) < ACTOR_TOL
+
+
+def test_actor_evaluate_step_loop_matches_kat_and_oracle(device, oracle, weights, kat):
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    pol = Raptor(device)
+    pol.reset()
+    h = np.zeros((2, 16), np.float32)
+    worst_kat = worst_orc = 0.0
+    for t in range(500):
+        a = pol.evaluate_step(x[t])
+        worst_kat = max(worst_kat, np.abs(a - y[t]).max())
+        worst_orc = max(worst_orc, np.abs(a - oracle.actor_batch_step(weights, x[t], h)).max())
+    assert worst_kat < ACTOR_TOL and worst_orc < ACTOR_TOL
+    assert np.abs(pol.hidden_state(2) - h).max() < ACTOR_TOL
+    # reset() restores the initial hidden state: the first step repeats
+    pol.reset()
+    assert np.abs(pol.evaluate_step(x[0]) - y[0]).max() < ACTOR_TOL
+
+
+@pytest.mark.parametrize("batch", [1, 63, 64, 65, 1000])
+def test_actor_ragged_batches_and_strided_input(device, oracle, weights, batch):
+    from raptor_amd.foundation_policy import Raptor
+    rng = np.random.default_rng(batch)
+    wide = rng.standard_normal((batch, 26)).astype(np.float32)
+    pol = Raptor(device)
+    pol.reset()
+    h = np.zeros((batch, 16), np.float32)
+    for _ in range(3):
+        a = pol.evaluate_step(wide[:, :22])            # non-contiguous view, as README.md:97
+        ref = oracle.actor_batch_step(weights, wide, h)
+        assert a.shape == (batch, 4) and np.abs(a - ref).max() < ACTOR_TOL
+
+
+def test_actor_batch_change_requires_reset(device):
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+    pol = Raptor(device)
+    pol.evaluate_step(np.zeros((4, 22), np.float32))
+    with pytest.raises(l2f.RaptorQuadError) as e:
+        pol.evaluate_step(np.zeros((5, 22), np.float32))
+    assert e.value.status == -5
+    pol.reset()
+    assert pol.evaluate_step(np.zeros((5, 22), np.float32)).shape == (5, 4)
+
+
+# ------------------------------------------------------------------------------ sampling ---
+@pytest.mark.parametrize("dr", [0, 1])
+def test_sample_initial_parameters_bit_exact(device, oracle, dr):
+    w = World(device, oracle, 1000, seed=3, offset=12345, domain_randomization=dr)
+    assert np.array_equal(w.params.numpy(), w.P)
+
+
+def test_sample_initial_state(device, oracle):
+    w = World(device, oracle, 1000, seed=4, disturbance_force_std=0.05, disturbance_torque_std=0.01)
+    S = w.state.numpy()
+    assert S.shape == (1000, 27)
+    # positions, velocities, rotor speeds, action history: no transcendental -> bit-exact
+    for sl in (slice(0, 3), slice(7, 13), slice(13, 21)):
+        assert np.array_equal(S[:, sl], w.S[:, sl])
+    assert np.abs(S[:, 3:7] - w.S[:, 3:7]).max() < INIT_TOL
+    scale = np.abs(w.S[:, 21:27]).max(axis=0) + 1e-30
+    assert (np.abs(S[:, 21:27] - w.S[:, 21:27]) / scale).max() < 1e-4     # Box-Muller
+    # second call = next episode, again in agreement
+    w.vector.sample_initial_state(device, w.env, w.params, w.state, w.rng)
+    S2 = oracle.sample_initial_state(w.cfg, 4, w.st.episode, 0, w.P)
+    assert np.array_equal(w.state.numpy()[:, 0:3], S2[:, 0:3]) and not np.array_equal(S2[:, 0:3], S[:, 0:3])
+
+
+# ------------------------------------------------------------------------------ observe ----
+def test_observe_bit_exact(w1k):
+    w = w1k
+    w.sync_oracle_to_gpu_state()
+    obs = np.zeros((w.n, 26), np.float32)
+    w.vector.observe(w.device, w.env, w.params, w.state, obs, w.rng)
+    assert np.array_equal(obs, w.O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+    # device-resident variant holds the same values
+    w.vector.observe(w.device, w.env, w.params, w.state, None, w.rng)
+    assert np.array_equal(w.env.observation(), obs)
+
+
+def test_observe_with_noise(device, oracle):
+    w = World(device, oracle, 1000, seed=9, noise_position=0.1, noise_orientation=0.02,
+              noise_linear_velocity=0.3, noise_angular_velocity=0.4)
+    w.sync_oracle_to_gpu_state()
+    for epoch in range(3):
+        obs = np.zeros((w.n, 26), np.float32)
+        w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+        ref = oracle.observe(w.cfg, 9, epoch, 0, w.P, w.S)
+        std = np.array([0.1] * 3 + [0.02] * 9 + [0.3] * 3 + [0.4] * 3 + [1] * 8, np.float32)
+        assert (np.abs(obs - ref) / std).max() < NOISE_TOL * 10
+        assert np.array_equal(obs[:, 18:], ref[:, 18:])
+    assert w.rng.epoch == 3
+
+
+# ------------------------------------------------------------------------------ step -------
+def test_step_bit_exact_with_fed_actions(device, oracle):
+    """README loop with identical actions on both sides: 100 transitions, every bit equal."""
+    w = World(device, oracle, 1000, seed=1, disturbance_force_std=0.05, disturbance_torque_std=0.01)
+    w.sync_oracle_to_gpu_state()
+    rng = np.random.default_rng(0)
+    for t in range(100):
+        act = rng.uniform(-1.5, 1.5, (w.n, 4)).astype(np.float32)
+        dts = w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+        w.state.assign(w.next_state)
+        ns, r, term = oracle.step(w.cfg, w.P, w.S, act)
+        oracle.stats_update(w.cfg, r, term, w.st)
+        w.S = ns
+        if t % 25 == 0 or t == 99:
+            assert np.array_equal(w.state.numpy(), ns), t
+            assert np.array_equal(w.env.rewards(), r) and np.array_equal(w.env.terminated(), term)
+            assert np.array_equal(w.env.returns(), w.st.returns)
+            assert np.array_equal(w.env.episode_steps(), w.st.steps)
+    assert len(dts) == w.n and dts[-1] == pytest.approx(0.01)
+    assert np.array_equal(w.env.finished_counts(), w.st.fin_counts)
+
+
+def test_step_termination_masks_and_nan(device, oracle):
+    w = World(device, oracle, 64, domain_randomization=0, init_guidance=1.0)
+    S = w.state.numpy()
+    S[1, 0], S[1, 7] = 2.999, 5.0
+    S[2, 10] = np.nan
+    S[3, 9] = 2000.0
+    w.state.set(S)
+    act = np.tile(w.P[:, 25:26], (1, 4)).astype(np.float32)
+    act[5] = np.nan
+    w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+    ns, r, term = oracle.step(w.cfg, w.P, S, act)
+    assert term[:6].tolist() == [0, 1, 1, 1, 0, 0]
+    assert np.array_equal(w.env.terminated(), term)
+    assert np.array_equal(w.env.rewards(), r, equal_nan=True)
+    assert np.array_equal(w.next_state.numpy(), ns, equal_nan=True)
+    assert np.array_equal(w.env.finished_terminated(), term.astype(np.uint32))
+
+
+def test_step_in_place_equals_out_of_place(device, oracle):
+    w = World(device, oracle, 300, seed=2)
+    act = np.random.default_rng(1).uniform(-1, 1, (300, 4)).astype(np.float32)
+    w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+    out = w.next_state.numpy()
+    w.vector.step(device, w.env, w.params, w.state, act, w.state, w.rng)
+    assert np.array_equal(w.state.numpy(), out)
+
+
+# ------------------------------------------------------------------------------ loops ------
+def test_readme_loop_runs_as_written(device):
+    """README.md:41-101 with the module names swapped; N = 8 (vector8), 500 steps."""
+    from copy import copy
+    import raptor_amd.l2f as l2f
+    from raptor_amd.l2f import vector8 as vector
+    from raptor_amd.foundation_policy import Raptor
+    policy = Raptor(device)
+    rng = vector.VectorRng()
+    env = vector.VectorEnvironment()
+    params = vector.VectorParameters()
+    state = vector.VectorState()
+    observation = np.zeros((env.N_ENVIRONMENTS, env.OBSERVATION_DIM), dtype=np.float32)
+    next_state = vector.VectorState()
+    vector.initialize_rng(device, rng, 0)
+    vector.initialize_environment(device, env)
+    vector.sample_initial_parameters(device, env, params, rng)
+    vector.sample_initial_state(device, env, params, state, rng)
+    ui_state = copy(state)
+    for i, s in enumerate(ui_state.states):
+        s.position[0] += i * 0.1
+    policy.reset()
+    for _ in range(500):
+        vector.observe(device, env, params, state, observation, rng)
+        action = policy.evaluate_step(observation[:, :22])
+        dts = vector.step(device, env, params, state, action, next_state, rng)
+        state.assign(next_state)
+    assert dts[-1] == pytest.approx(0.01)
+    p = np.array([s.position for s in state.states])
+    assert np.isfinite(p).all() and np.median(np.linalg.norm(p, axis=1)) < 0.2   # the policy hovers them
+
+
+def test_device_resident_chain_equals_host_chain(device, oracle):
+    """observe(None) -> evaluate_step_device -> step(None) == the NumPy-passing loop, bit for bit."""
+    a = World(device, oracle, 500, seed=6)
+    b = World(device, oracle, 500, seed=6)
+    obs = np.zeros((500, 26), np.float32)
+    a.policy.reset(); b.policy.reset()
+    for _ in range(20):
+        a.vector.observe(device, a.env, a.params, a.state, obs, a.rng)
+        act = a.policy.evaluate_step(obs[:, :22])
+        a.vector.step(device, a.env, a.params, a.state, act, a.next_state, a.rng)
+        a.state.assign(a.next_state)
+        b.vector.observe(device, b.env, b.params, b.state, None, b.rng)
+        b.policy.evaluate_step_device(b.env)
+        b.vector.step_device(device, b.env, b.params, b.state, b.state, b.rng)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.env.returns(), b.env.returns())
+
+
+@pytest.mark.parametrize("autoreset", [False, True])
+def test_rollout_fused_equals_chained_bit_exact(device, oracle, autoreset):
+    kw = dict(seed=8, episode_step_limit=40, noise_position=0.01, noise_angular_velocity=0.05)
+    a = World(device, oracle, 777, **kw)
+    b = World(device, oracle, 777, **kw)
+    for chunk in (30, 50, 45):
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", autoreset)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", autoreset)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(777), b.policy.hidden_state(777))
+    for name in ("returns", "episode_steps", "finished_returns", "finished_lengths", "finished_counts",
+                 "finished_terminated", "rewards", "terminated"):
+        assert np.array_equal(getattr(a.env, name)(), getattr(b.env, name)()), name
+    assert a.rng.epoch == b.rng.epoch == 125
+    if autoreset:
+        assert (a.env.finished_counts() >= 3).all()
+    else:
+        assert (a.env.finished_counts() == 1).all()
+
+
+def _closed_loop_agreement(w, n):
+    """Closed loop feeds the actor's few-ulp differences (v_exp_f32/v_rcp_f32 vs libm) back through
+    the dynamics: stable envs stay within CLOSED_LOOP_TOL; the few envs the policy cannot
+    stabilise diverge chaotically on either side, so those are compared as a population."""
+    S = w.state.numpy()
+    g_cnt, g_len, g_term = w.env.finished_counts(), w.env.finished_lengths(), w.env.finished_terminated()
+    same_history = (g_cnt == w.st.fin_counts) & (g_len == w.st.fin_lengths) & (g_term == w.st.fin_terminated)
+    assert same_history.mean() > 0.97, same_history.mean()
+    calm = same_history & (w.st.fin_terminated == 0) & (np.abs(w.S[:, :3]).max(axis=1) < 1.0)
+    assert calm.mean() > 0.85
+    d = np.abs(S[calm, :13] - w.S[calm, :13]).max(axis=1)
+    assert np.quantile(d, 0.99) < CLOSED_LOOP_TOL, np.quantile(d, [0.5, 0.99, 1.0])
+    assert np.allclose(w.env.finished_returns()[calm], w.st.fin_returns[calm], rtol=1e-3, atol=5e-2)
+    return calm
+
+
+@pytest.mark.parametrize("mode", ["fused", "chained"])
+@pytest.mark.parametrize("dr", [0, 1])
+def test_rollout_vs_oracle_closed_loop(device, oracle, weights, mode, dr):
+    """500 closed-loop steps, policy in the loop."""
+    w = World(device, oracle, 512, seed=11, domain_randomization=dr)
+    w.sync_oracle_to_gpu_state()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 500, mode, False)
+    oracle.rollout(w.cfg, weights, 11, 0, 0, w.P, w.S, w.H, 500, 0, w.st, 8)
+    calm = _closed_loop_agreement(w, 512)
+    assert (w.env.finished_counts() == 1).all()
+    assert (w.env.finished_lengths()[calm] == 500).all()
+    assert np.abs(w.policy.hidden_state(512)[calm] - w.H[calm]).max() < 1e-2
+
+
+def test_rollout_autoreset_vs_oracle(device, oracle, weights):
+    w = World(device, oracle, 256, seed=12, episode_step_limit=60)
+    w.sync_oracle_to_gpu_state()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 200, "fused", True)
+    oracle.rollout(w.cfg, weights, 12, 0, 0, w.P, w.S, w.H, 200, 1, w.st, 8)
+    _closed_loop_agreement(w, 256)
+    same = w.env.finished_counts() == w.st.fin_counts
+    assert np.array_equal(w.env.episode_steps()[same], w.st.steps[same])
+
+
+# ------------------------------------------------------------------------------ scale ------
+def test_sharding_invariance_and_determinism_at_full_size(device, oracle):
+    """65 536 envs (BASELINE config 2): one batch == two half batches with global offsets,
+    bit for bit (RNG keyed by global env id), and a repeated run reproduces itself."""
+    n = 65536
+    kw = dict(seed=21)
+    full = World(device, oracle, n, **kw)
+    lo = World(device, oracle, n // 2, offset=0, **kw)
+    hi = World(device, oracle, n // 2, offset=n // 2, **kw)
+    for w in (full, lo, hi):
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 100, "fused", True)
+    Sf = full.state.numpy()
+    assert np.array_equal(Sf, np.concatenate([lo.state.numpy(), hi.state.numpy()]))
+    assert np.array_equal(full.env.returns(), np.concatenate([lo.env.returns(), hi.env.returns()]))
+    again = World(device, oracle, n, **kw)
+    again.vector.rollout(device, again.env, again.params, again.state, again.policy, again.rng, 100, "fused", True)
+    assert np.array_equal(Sf, again.state.numpy())
+    # size-independent properties: unit quaternions, rotor speeds inside their limits
+    q = Sf[:, 3:7]
+    assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < 1e-5
+    P = full.params.numpy()
+    assert (Sf[:, 13:17] >= P[:, 22:23]).all() and (Sf[:, 13:17] <= P[:, 23:24]).all()
+
+
+def test_policy_stabilises_gpu_simulation(device, oracle):
+    """The functional pin of the conventions, on the HIP path itself."""
+    w = World(device, oracle, 4096, seed=5, termination_enabled=1)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 500, "fused", False)
+    term = w.env.finished_terminated()
+    assert (w.env.finished_counts() == 1).all()
+    assert term.mean() < 0.07
+    S = w.state.numpy()
+    assert np.median(np.linalg.norm(S[term == 0, :3], axis=1)) < 0.1
+
+
+# ------------------------------------------------------------------------------ errors -----
+def test_error_codes(device, oracle):
+    import raptor_amd.l2f as l2f
+    v = l2f.VectorModule(16)
+    rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+    with pytest.raises(l2f.RaptorQuadError) as e:      # env never initialised
+        v.sample_initial_parameters(device, env, params, rng)
+    assert e.value.status == -6
+    v.initialize_environment(device, env)
+    v.initialize_rng(device, rng, 0)
+    v.sample_initial_parameters(device, env, params, rng)
+    v.sample_initial_state(device, env, params, state, rng)
+    other = l2f.VectorModule(32)
+    env2 = other.VectorEnvironment()
+    other.initialize_environment(device, env2)
+    with pytest.raises(l2f.RaptorQuadError) as e:      # params of env used with env2
+        other.observe(device, env2, params, state, None, rng)
+    assert e.value.status == -5
+    with pytest.raises(ValueError):
+        v.observe(device, env, params, state, np.zeros((16, 22), np.float32), rng)
+    cfg = env.config
+    cfg.struct_size = 12
+    with pytest.raises(l2f.RaptorQuadError) as e:
+        env.config = cfg
+    assert e.value.status == -1

@@ -1,0 +1,300 @@
+"""Properties of the oracle's environment restatement (its l2f parity is unpinned — see
+oracle/raptor_oracle.c header; these tests pin the spec's own invariants and the conventions
+the reference states in README.md:23-27)."""
+import numpy as np
+import pytest
+
+N = 512
+
+
+def _setup(O, dr=1, seed=0, n=N, **cfg_over):
+    cfg = O.default_config()
+    cfg.domain_randomization = dr
+    for k, v in cfg_over.items():
+        setattr(cfg, k, v)
+    P = O.sample_initial_parameters(cfg, seed, 0, 0, n)
+    ep = np.zeros(n, np.uint32)
+    S = O.sample_initial_state(cfg, seed, ep, 0, P)
+    return cfg, P, S, ep
+
+
+def test_philox_random123_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_default_config_struct(oracle):
+    cfg = oracle.default_config()
+    import ctypes
+    assert cfg.struct_size == ctypes.sizeof(oracle.EnvConfig) == 144
+    assert cfg.dt == pytest.approx(0.01) and cfg.episode_step_limit == 500   # README.md:25,95
+
+
+def test_nominal_parameters_are_crazyflie(oracle):
+    cfg, P, _, _ = _setup(oracle, dr=0, n=4)
+    assert np.all(P == P[0])
+    assert P[0, 0] == np.float32(0.027)
+    assert np.allclose(P[0, 4:16].reshape(4, 3),
+                       [[0.028, -0.028, 0], [-0.028, -0.028, 0], [-0.028, 0.028, 0], [0.028, 0.028, 0]])
+    # hover: 4 * c2 * rpm^2 == m g
+    assert 4 * P[0, 18] * P[0, 24] ** 2 == pytest.approx(0.027 * 9.81, rel=1e-5)
+    assert P[0, 25] == pytest.approx(2 * P[0, 24] / 21702.0 - 1, rel=1e-6)
+
+
+def test_randomised_parameters_ranges_and_hover(oracle):
+    cfg, P, _, _ = _setup(oracle, dr=1, n=4096)
+    m = P[:, 0]
+    s = np.cbrt(m / 0.027)
+    assert s.min() >= 0.5 - 1e-4 and s.max() <= 8.0 + 1e-3
+    assert np.allclose(P[:, 4], 0.028 * s, rtol=1e-5)
+    t2w = 4 * P[:, 18] * P[:, 23] ** 2 / (m * 9.81)
+    assert t2w.min() >= 1.5 - 1e-3 and t2w.max() <= 5.0 + 1e-3
+    assert np.allclose(4 * P[:, 18] * P[:, 24] ** 2, m * 9.81, rtol=1e-4)
+    assert (P[:, 20] >= 0.03 - 1e-6).all() and (P[:, 20] <= 0.2 + 1e-6).all()
+    assert (np.abs(P[:, 25]) < 1).all()
+    # distinct envs get distinct parameters; same (seed, id) reproduces
+    assert len(np.unique(m)) > 4000
+    P2 = oracle.sample_initial_parameters(cfg, 0, 0, 0, 4096)
+    assert np.array_equal(P, P2)
+
+
+def test_rng_is_keyed_by_global_env_id(oracle):
+    cfg = oracle.default_config()
+    full = oracle.sample_initial_parameters(cfg, 7, 0, 0, 100)
+    a = oracle.sample_initial_parameters(cfg, 7, 0, 0, 37)
+    b = oracle.sample_initial_parameters(cfg, 7, 0, 37, 63)
+    assert np.array_equal(full, np.concatenate([a, b]))
+    other_seed = oracle.sample_initial_parameters(cfg, 8, 0, 0, 100)
+    assert not np.array_equal(full, other_seed)
+    # ids above 2^32 use the high bits too
+    hi = oracle.sample_initial_parameters(cfg, 7, 0, (1 << 32), 4)
+    assert not np.array_equal(hi, full[:4])
+
+
+def test_initial_state_ranges(oracle):
+    cfg, P, S, ep = _setup(oracle, n=4096)
+    assert (ep == 1).all()
+    q = S[:, 3:7]
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+    assert np.abs(S[:, 0:3]).max() <= 0.5 and np.abs(S[:, 7:13]).max() <= 1.0
+    ang = 2 * np.arccos(np.clip(q[:, 0], -1, 1))
+    assert ang.max() <= np.pi / 2 + 1e-5
+    guided = (S[:, 0:3] == 0).all(axis=1) & (q[:, 0] == 1)
+    assert 0.05 < guided.mean() < 0.15          # init_guidance = 0.1
+    assert np.array_equal(S[:, 13:17], np.repeat(P[:, 24:25], 4, axis=1))   # hover rpm
+    assert (S[:, 17:27] == 0).all()
+    # next episode differs
+    S2 = oracle.sample_initial_state(cfg, 0, ep, 0, P)
+    assert (ep == 2).all() and not np.array_equal(S, S2)
+
+
+def test_disturbance_sampling(oracle):
+    cfg, P, S, _ = _setup(oracle, n=4096, disturbance_force_std=0.05, disturbance_torque_std=0.01)
+    f = S[:, 21:24] / (P[:, 0:1] * 9.81)
+    assert abs(f.std() - 0.05) < 0.005 and abs(f.mean()) < 0.005
+
+
+def test_observation_layout(oracle):
+    """[p, R(q) row-major, v, w_body, previous action] (README.md:23) + rotor-speed tail."""
+    cfg, P, S, _ = _setup(oracle)
+    S[:, 17:21] = np.random.default_rng(0).uniform(-1, 1, (N, 4)).astype(np.float32)
+    O = oracle.observe(cfg, 0, 0, 0, P, S)
+    assert O.shape == (N, 26)
+    assert np.array_equal(O[:, 0:3], S[:, 0:3])
+    R = O[:, 3:12].reshape(N, 3, 3)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-5)
+    assert np.allclose(np.linalg.det(R), 1.0, atol=1e-5)
+    # body z axis in world frame is the third COLUMN (row-major flatten, not transposed)
+    w, x, y, z = S[:, 3], S[:, 4], S[:, 5], S[:, 6]
+    assert np.allclose(R[:, 0, 2], 2 * (x * z + w * y), atol=1e-6)
+    assert np.array_equal(O[:, 12:15], S[:, 7:10]) and np.array_equal(O[:, 15:18], S[:, 10:13])
+    assert np.array_equal(O[:, 18:22], S[:, 17:21])
+    assert np.allclose(O[:, 22:26], P[:, 25:26], atol=1e-5)   # hovering rotors read the hover action
+
+
+def test_observation_noise(oracle):
+    cfg, P, S, _ = _setup(oracle, n=8192, noise_position=0.1, noise_orientation=0.02,
+                          noise_linear_velocity=0.3, noise_angular_velocity=0.4)
+    clean_cfg = oracle.default_config()
+    clean = oracle.observe(clean_cfg, 0, 0, 0, P, S)
+    noisy0 = oracle.observe(cfg, 0, 0, 0, P, S)
+    noisy1 = oracle.observe(cfg, 0, 1, 0, P, S)
+    d = noisy0 - clean
+    for sl, std in ((slice(0, 3), 0.1), (slice(3, 12), 0.02), (slice(12, 15), 0.3), (slice(15, 18), 0.4)):
+        assert abs(d[:, sl].std() - std) < 0.05 * std and abs(d[:, sl].mean()) < 0.05 * std
+    assert (d[:, 18:] == 0).all()
+    assert not np.array_equal(noisy0, noisy1)                      # epoch advances the stream
+    assert np.array_equal(noisy0, oracle.observe(cfg, 0, 0, 0, P, S))   # and is reproducible
+
+
+def test_step_free_fall_and_hover(oracle):
+    """Zero thrust -> ballistic; hover command -> stays put (nominal Crazyflie)."""
+    cfg, P, S, _ = _setup(oracle, dr=0, n=2, init_guidance=1.0)
+    S[0, 13:17] = 0.0                       # rotors stopped
+    a = np.array([[-1, -1, -1, -1], [P[1, 25]] * 4], np.float32)
+    s = S.copy()
+    for _ in range(100):
+        s, r, t = oracle.step(cfg, P, s, a)
+    tt = 1.0
+    assert s[0, 2] == pytest.approx(-0.5 * 9.81 * tt ** 2, rel=1e-4)
+    assert s[0, 9] == pytest.approx(-9.81 * tt, rel=1e-4)
+    assert np.abs(s[1, 0:3]).max() < 1e-4 and np.abs(s[1, 7:10]).max() < 1e-4
+    assert np.allclose(s[:, 3:7], [1, 0, 0, 0], atol=1e-4)
+    assert np.array_equal(s[:, 17:21], a)   # action history
+
+
+def test_step_motor_order_and_spin(oracle):
+    """Motor order FR,BR,BL,FL (README.md:27): more thrust in front pitches the nose up
+    (rotation about +y in FLU is nose DOWN, so w_y < 0); more thrust on the left rolls right
+    (w_x < 0)... and the yaw reaction follows the spin pattern (-,+,-,+)."""
+    cfg, P, S, _ = _setup(oracle, dr=0, n=3, init_guidance=1.0)
+    ha = P[0, 25]
+    hi, lo = ha + 0.2, ha - 0.2
+    a = np.array([[hi, lo, lo, hi],     # front pair up
+                  [lo, lo, hi, hi],     # left pair (BL, FL) up
+                  [lo, hi, lo, hi]], np.float32)   # rotors 1,3 up
+    s = S.copy()
+    for _ in range(5):
+        s, _, _ = oracle.step(cfg, P, s, a)
+    assert s[0, 11] < -1e-3 and abs(s[0, 10]) < 1e-6      # pitch: front up -> w_y negative
+    assert s[1, 10] > 1e-3 and abs(s[1, 11]) < 1e-6       # left side up -> roll to the right... positive w_x
+    assert s[2, 12] > 1e-4 and abs(s[2, 10]) < 1e-6       # yaw
+
+
+def test_step_action_clipping_and_rotor_limits(oracle):
+    cfg, P, S, _ = _setup(oracle, dr=0, n=2, init_guidance=1.0)
+    a = np.array([[5, 5, 5, 5], [-7, -7, -7, -7]], np.float32)
+    s = S.copy()
+    for _ in range(300):
+        s, _, _ = oracle.step(cfg, P, s, a)
+    assert np.array_equal(s[:, 17:21], np.clip(a, -1, 1))
+    assert np.allclose(s[0, 13:17], 21702.0, rtol=1e-4) and (s[0, 13:17] <= 21702.0).all()
+    assert np.allclose(s[1, 13:17], 0.0, atol=1.0) and (s[1, 13:17] >= 0.0).all()
+
+
+def test_step_nan_action_and_termination(oracle):
+    cfg, P, S, _ = _setup(oracle, dr=0, n=3, init_guidance=1.0)
+    S[1, 0] = 2.999
+    S[1, 7] = 5.0          # will cross the 3 m position threshold
+    S[2, 10] = np.nan      # non-finite state terminates
+    a = np.full((3, 4), P[0, 25], np.float32)
+    s, r, t = oracle.step(cfg, P, S, a)
+    assert t.tolist() == [0, 1, 1]
+    assert r[1] == cfg.reward_termination_penalty
+    assert r[0] == pytest.approx(cfg.reward_constant, abs=1e-3)
+    cfg.termination_enabled = 0
+    _, _, t2 = oracle.step(cfg, P, S, a)
+    assert t2.tolist() == [0, 0, 0]
+
+
+def _reference_ode(P, sp, force, torque, g=9.81):
+    """Independent float64 statement of the rigid-body + first-order-rotor ODE, written with
+    matrices and cross products (not the component formulas of the oracle)."""
+    m = float(P[0])
+    J = np.diag(P[1:4].astype(np.float64))
+    Jinv = np.linalg.inv(J)
+    pos = P[4:16].astype(np.float64).reshape(4, 3)
+    c0, c1, c2, kq = (float(v) for v in P[16:20])
+    tr, tf = float(P[20]), float(P[21])
+    spin = np.array([-1.0, 1.0, -1.0, 1.0])
+
+    def f(t, y):
+        p, q, v, w, r = y[0:3], y[3:7], y[7:10], y[10:13], y[13:17]
+        qw, qx, qy, qz = q
+        R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+                      [2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)],
+                      [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)]])
+        T = c0 + c1 * r + c2 * r * r
+        Fb = np.array([0.0, 0.0, T.sum()])
+        tau = sum(np.cross(pos[i], [0.0, 0.0, T[i]]) for i in range(4)) + np.array([0, 0, kq * (spin * T).sum()])
+        tau = tau + torque
+        dq = 0.5 * np.array([-(qx * w[0] + qy * w[1] + qz * w[2]),
+                             qw * w[0] + qy * w[2] - qz * w[1],
+                             qw * w[1] + qz * w[0] - qx * w[2],
+                             qw * w[2] + qx * w[1] - qy * w[0]])
+        dv = R @ Fb / m + np.array([0, 0, -g]) + force / m
+        dw = Jinv @ (tau - np.cross(w, J @ w))
+        dr = (sp - r) / np.where(sp >= r, tr, tf)
+        return np.concatenate([v, dq, dv, dw, dr])
+    return f
+
+
+@pytest.mark.parametrize("dr", [0, 1])
+def test_step_matches_independent_float64_integration(oracle, dr):
+    """30 RK4 steps of the oracle vs scipy's adaptive integrator on an independently written
+    float64 ODE: pins the equations of motion (frames, signs, motor geometry)."""
+    from scipy.integrate import solve_ivp
+    cfg, P, S, _ = _setup(oracle, dr=dr, n=4, init_guidance=0.0, seed=11,
+                          disturbance_force_std=0.05, disturbance_torque_std=0.02)
+    cfg.termination_enabled = 0
+    a = np.array([[0.5, 0.2, 0.4, 0.3], [-0.2, 0.1, 0.0, 0.3], [0.9, 0.8, 1.0, 0.7], [0.0, 0.0, 0.0, 0.0]],
+                 np.float32)
+    s = S.copy()
+    for _ in range(30):
+        s, _, _ = oracle.step(cfg, P, s, a)
+    cfg.dt = 0.0025                      # same equations, 4x finer: truncation error out of the way
+    sf = S.copy()
+    for _ in range(120):
+        sf, _, _ = oracle.step(cfg, P, sf, a)
+    for i in range(4):
+        sp = (np.clip(a[i], -1, 1).astype(np.float64) + 1) / 2 * (P[i, 23] - P[i, 22]) + P[i, 22]
+        f = _reference_ode(P[i], sp, S[i, 21:24].astype(np.float64), S[i, 24:27].astype(np.float64))
+        sol = solve_ivp(f, (0, 0.3), S[i, :17].astype(np.float64), rtol=1e-10, atol=1e-12)
+        ref = sol.y[:, -1]
+        ref[3:7] /= np.linalg.norm(ref[3:7])
+        scale = np.maximum(np.abs(ref), 1.0)
+        err = np.abs(s[i, :17] - ref) / scale
+        err_fine = np.abs(sf[i, :17] - ref) / scale
+        assert err.max() < 2e-2, (i, err)          # dt = 10 ms: RK4 truncation on the stiff small frames
+        assert err_fine.max() < 1e-3, (i, err_fine)
+
+
+def test_stats_and_freeze_semantics(oracle, weights):
+    cfg, P, S, ep = _setup(oracle, n=64)
+    cfg.episode_step_limit = 50
+    st = oracle.Stats(64)
+    st.episode[:] = ep
+    H = np.zeros((64, 16), np.float32)
+    oracle.rollout(cfg, weights, 0, 0, 0, P, S, H, 80, 0, st)
+    assert (st.frozen == 1).all() and (st.fin_counts == 1).all()
+    assert (st.fin_lengths <= 50).all() and (st.fin_lengths[st.fin_terminated == 0] == 50).all()
+    assert (st.returns == 0).all() and (st.steps == 0).all()
+    S_frozen = S.copy()
+    oracle.rollout(cfg, weights, 0, 80, 0, P, S, H, 10, 0, st)      # frozen envs do not move
+    assert np.array_equal(S, S_frozen) and (st.fin_counts == 1).all()
+
+
+def test_autoreset_semantics(oracle, weights):
+    cfg, P, S, ep = _setup(oracle, n=64)
+    cfg.episode_step_limit = 20
+    st = oracle.Stats(64)
+    st.episode[:] = ep
+    H = np.zeros((64, 16), np.float32)
+    oracle.rollout(cfg, weights, 0, 0, 0, P, S, H, 65, 1, st)
+    assert (st.frozen == 0).all()
+    assert (st.fin_counts >= 3).all()
+    assert (st.episode == 1 + st.fin_counts).all()
+    # split rollouts == one rollout (state carried in S, H, st)
+    cfg2, P2, S2, ep2 = _setup(oracle, n=64)
+    cfg2.episode_step_limit = 20
+    st2 = oracle.Stats(64)
+    st2.episode[:] = ep2
+    H2 = np.zeros((64, 16), np.float32)
+    oracle.rollout(cfg2, weights, 0, 0, 0, P2, S2, H2, 30, 1, st2)
+    oracle.rollout(cfg2, weights, 0, 30, 0, P2, S2, H2, 35, 1, st2)
+    assert np.array_equal(S, S2) and np.array_equal(H, H2) and np.array_equal(st.fin_returns, st2.fin_returns)
+
+
+def test_threads_do_not_change_results(oracle, weights):
+    res = []
+    for nt in (1, 4):
+        cfg, P, S, ep = _setup(oracle, n=256)
+        st = oracle.Stats(256)
+        st.episode[:] = ep
+        H = np.zeros((256, 16), np.float32)
+        oracle.rollout(cfg, weights, 0, 0, 0, P, S, H, 100, 1, st, nthreads=nt)
+        res.append((S.copy(), st.returns.copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
