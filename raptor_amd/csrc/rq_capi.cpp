@@ -61,6 +61,7 @@ struct rq_rng {
 
 struct rq_env {
     rq_device* dev = nullptr;
+    int ordinal = 0;            // copy: destruction must not dereference the parent (GC order is arbitrary)
     uint32_t n = 0, ld = 0;
     uint64_t offset = 0;
     rq_env_config cfg{};
@@ -71,11 +72,12 @@ struct rq_env {
     rq::StatsPtrs st{};
 };
 
-struct rq_params { rq_env* env = nullptr; float* d = nullptr; };
-struct rq_state { rq_env* env = nullptr; float* d = nullptr; };
+struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
+struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
 
 struct rq_policy {
     rq_device* dev = nullptr;
+    int ordinal = 0;
     float* w_dev = nullptr;
     float w_host[RQ_POLICY_NUM_WEIGHTS];
     int precision = RQ_POLICY_FP32;
@@ -355,7 +357,7 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
     int rc = set_device(dev); if (rc) return rc;
     rq_env* e = new (std::nothrow) rq_env();
     RQ_REQUIRE(e, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
-    e->dev = dev; e->n = n_envs; e->ld = round_up64(n_envs); e->offset = global_env_offset;
+    e->dev = dev; e->ordinal = dev->ordinal; e->n = n_envs; e->ld = round_up64(n_envs); e->offset = global_env_offset;
     const size_t ld = e->ld;
     // one block for all statistics: 8 x 4-byte arrays + 2 x 1-byte arrays
     const size_t stats_bytes = ld * (8 * 4 + 2 * 1);
@@ -393,8 +395,7 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
 
 RQ_API int rq_env_destroy(rq_env* env) {
     if (!env) return RQ_OK;
-    (void)hipSetDevice(env->dev->ordinal);
-    (void)hipStreamSynchronize(env->dev->stream);
+    (void)hipSetDevice(env->ordinal);   // hipFree synchronises the device; the parent is not touched
     if (env->obs) (void)hipFree(env->obs);
     if (env->act) (void)hipFree(env->act);
     if (env->stats_block) (void)hipFree(env->stats_block);
@@ -443,7 +444,7 @@ RQ_API int rq_params_create(rq_env* env, rq_params** out) {
     int rc = set_device(env->dev); if (rc) return rc;
     rq_params* p = new (std::nothrow) rq_params();
     RQ_REQUIRE(p, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
-    p->env = env;
+    p->env = env; p->ordinal = env->ordinal;
     const size_t bytes = (size_t)RQ_PARAM_DIM * env->ld * sizeof(float);
     hipError_t e = hipMalloc(&p->d, bytes);
     if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_params_create: device allocation failed"); }
@@ -453,8 +454,7 @@ RQ_API int rq_params_create(rq_env* env, rq_params** out) {
 }
 RQ_API int rq_params_destroy(rq_params* p) {
     if (!p) return RQ_OK;
-    (void)hipSetDevice(p->env->dev->ordinal);
-    (void)hipStreamSynchronize(p->env->dev->stream);
+    (void)hipSetDevice(p->ordinal);
     if (p->d) (void)hipFree(p->d);
     delete p;
     return RQ_OK;
@@ -477,7 +477,7 @@ RQ_API int rq_state_create(rq_env* env, rq_state** out) {
     int rc = set_device(env->dev); if (rc) return rc;
     rq_state* s = new (std::nothrow) rq_state();
     RQ_REQUIRE(s, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
-    s->env = env;
+    s->env = env; s->ordinal = env->ordinal;
     const size_t bytes = (size_t)RQ_STATE_DIM * env->ld * sizeof(float);
     hipError_t e = hipMalloc(&s->d, bytes);
     if (e != hipSuccess) { delete s; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_state_create: device allocation failed"); }
@@ -487,8 +487,7 @@ RQ_API int rq_state_create(rq_env* env, rq_state** out) {
 }
 RQ_API int rq_state_destroy(rq_state* s) {
     if (!s) return RQ_OK;
-    (void)hipSetDevice(s->env->dev->ordinal);
-    (void)hipStreamSynchronize(s->env->dev->stream);
+    (void)hipSetDevice(s->ordinal);
     if (s->d) (void)hipFree(s->d);
     delete s;
     return RQ_OK;
@@ -617,7 +616,7 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
     int rc = set_device(dev); if (rc) return rc;
     rq_policy* p = new (std::nothrow) rq_policy();
     RQ_REQUIRE(p, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
-    p->dev = dev;
+    p->dev = dev; p->ordinal = dev->ordinal;
     std::memcpy(p->w_host, weights, sizeof(p->w_host));
     hipError_t e = hipMalloc(&p->w_dev, sizeof(p->w_host));
     if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed"); }
@@ -630,8 +629,7 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
 
 RQ_API int rq_policy_destroy(rq_policy* pol) {
     if (!pol) return RQ_OK;
-    (void)hipSetDevice(pol->dev->ordinal);
-    (void)hipStreamSynchronize(pol->dev->stream);
+    (void)hipSetDevice(pol->ordinal);
     policy_free_buffers(pol);
     if (pol->w_dev) (void)hipFree(pol->w_dev);
     delete pol;

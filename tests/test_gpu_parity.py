@@ -288,20 +288,43 @@ def test_rollout_fused_equals_chained_bit_exact(device, oracle, autoreset):
         assert (a.env.finished_counts() == 1).all()
 
 
-def _closed_loop_agreement(w, n):
-    """Closed loop feeds the actor's few-ulp differences (v_exp_f32/v_rcp_f32 vs libm) back through
-    the dynamics: stable envs stay within CLOSED_LOOP_TOL; the few envs the policy cannot
-    stabilise diverge chaotically on either side, so those are compared as a population."""
+def _well_conditioned(w, weights, steps, flags, threads=8):
+    """The closed loop is chaotic for a few percent of the randomised quadrotors (fast motors on
+    small frames: a 1-ulp change of the initial x position grows to O(1) rad/s within 1-2 s —
+    measured with the oracle against itself).  Parity over a long horizon is therefore asserted
+    on the envs whose own sensitivity is small; the one-step-ahead test below covers all envs."""
+    O = w.O
+    Sp = w.S.copy()
+    Sp[:, 0] = np.nextafter(Sp[:, 0], np.float32(10))
+    Hp = w.H.copy()
+    stp = O.Stats(w.n)
+    stp.episode[:] = w.st.episode
+    O.rollout(w.cfg, weights, w.seed, 0, w.offset, w.P, Sp, Hp, steps, flags, stp, threads)
+    return Sp, stp
+
+
+def _closed_loop_agreement(w, weights, steps, flags):
+    S0 = w.S.copy()
+    Sp, stp = _well_conditioned(w, weights, steps, flags)
+    w.O.rollout(w.cfg, weights, w.seed, 0, w.offset, w.P, w.S, w.H, steps, flags, w.st, 8)
     S = w.state.numpy()
     g_cnt, g_len, g_term = w.env.finished_counts(), w.env.finished_lengths(), w.env.finished_terminated()
     same_history = (g_cnt == w.st.fin_counts) & (g_len == w.st.fin_lengths) & (g_term == w.st.fin_terminated)
     assert same_history.mean() > 0.97, same_history.mean()
-    calm = same_history & (w.st.fin_terminated == 0) & (np.abs(w.S[:, :3]).max(axis=1) < 1.0)
-    assert calm.mean() > 0.85
-    d = np.abs(S[calm, :13] - w.S[calm, :13]).max(axis=1)
+    insensitive = (np.abs(Sp[:, :13] - w.S[:, :13]).max(axis=1) < 1e-5) & \
+                  (stp.fin_counts == w.st.fin_counts) & (stp.fin_lengths == w.st.fin_lengths)
+    assert insensitive.mean() > 0.7, insensitive.mean()
+    sel = insensitive & same_history
+    # the 1-ulp-of-x probe is a proxy for sensitivity to the actor's ulps: allow 1 % escapes
+    assert same_history[insensitive].mean() > 0.99
+    d = np.abs(S[sel, :13] - w.S[sel, :13]).max(axis=1)
     assert np.quantile(d, 0.99) < CLOSED_LOOP_TOL, np.quantile(d, [0.5, 0.99, 1.0])
-    assert np.allclose(w.env.finished_returns()[calm], w.st.fin_returns[calm], rtol=1e-3, atol=5e-2)
-    return calm
+    assert np.allclose(w.env.finished_returns()[sel], w.st.fin_returns[sel], rtol=1e-4, atol=1e-2)
+    # population level: the GPU's spread vs the oracle is no worse than the oracle's own 1-ulp spread
+    all_d = np.abs(S[:, :13] - w.S[:, :13]).max(axis=1)
+    ref_d = np.abs(Sp[:, :13] - w.S[:, :13]).max(axis=1)
+    assert np.nanmedian(all_d) < 1e-4 and (all_d > 1e-2).mean() <= (ref_d > 1e-2).mean() + 0.05
+    return sel
 
 
 @pytest.mark.parametrize("mode", ["fused", "chained"])
@@ -311,21 +334,52 @@ def test_rollout_vs_oracle_closed_loop(device, oracle, weights, mode, dr):
     w = World(device, oracle, 512, seed=11, domain_randomization=dr)
     w.sync_oracle_to_gpu_state()
     w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 500, mode, False)
-    oracle.rollout(w.cfg, weights, 11, 0, 0, w.P, w.S, w.H, 500, 0, w.st, 8)
-    calm = _closed_loop_agreement(w, 512)
+    sel = _closed_loop_agreement(w, weights, 500, 0)
     assert (w.env.finished_counts() == 1).all()
-    assert (w.env.finished_lengths()[calm] == 500).all()
-    assert np.abs(w.policy.hidden_state(512)[calm] - w.H[calm]).max() < 1e-2
+    assert np.abs(w.policy.hidden_state(512)[sel] - w.H[sel]).max() < 1e-2
 
 
 def test_rollout_autoreset_vs_oracle(device, oracle, weights):
     w = World(device, oracle, 256, seed=12, episode_step_limit=60)
     w.sync_oracle_to_gpu_state()
     w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 200, "fused", True)
-    oracle.rollout(w.cfg, weights, 12, 0, 0, w.P, w.S, w.H, 200, 1, w.st, 8)
-    _closed_loop_agreement(w, 256)
-    same = w.env.finished_counts() == w.st.fin_counts
-    assert np.array_equal(w.env.episode_steps()[same], w.st.steps[same])
+    sel = _closed_loop_agreement(w, weights, 200, 1)
+    assert np.array_equal(w.env.episode_steps()[sel], w.st.steps[sel])
+
+
+@pytest.mark.parametrize("mode", ["fused", "chained"])
+def test_rollout_two_steps_ahead_everywhere(device, oracle, weights, mode):
+    """Teacher-forced closed loop: along a 300-step oracle trajectory, every 20 steps load the
+    oracle's (state, hidden) into the GPU and advance 2 steps with the policy in the loop.
+    No horizon for chaos to act on, so EVERY env must agree: floats within 1e-4 abs / 1e-4 rel
+    (actor transcendental ulps only), termination masks exactly."""
+    w = World(device, oracle, 640, seed=13, episode_step_limit=10 ** 6, noise_position=0.01,
+              noise_linear_velocity=0.02)
+    w.sync_oracle_to_gpu_state()
+    for t in range(0, 300, 20):
+        w.state.set(w.S)
+        w.policy.set_hidden_state(w.H)
+        w.env.reset_statistics()
+        assert w.rng.epoch == t
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 2, mode, False)
+        S2, H2 = w.S.copy(), w.H.copy()
+        st2 = oracle.Stats(w.n)
+        oracle.rollout(w.cfg, weights, 13, t, 0, w.P, S2, H2, 2, 0, st2, 8)
+        G = w.state.numpy()
+        live = st2.frozen == 0
+        assert np.array_equal(w.env.terminated(), st2.last_terminated)
+        scale = np.maximum(np.abs(S2[live, :17]), 1.0)
+        assert (np.abs(G[live, :17] - S2[live, :17]) / scale).max() < 1e-4, t
+        assert np.abs(w.policy.hidden_state(w.n)[live] - H2[live]).max() < 1e-5
+        assert np.abs(w.env.rewards()[live] - st2.last_reward[live]).max() < 1e-4
+        # advance the oracle trajectory by 20 steps (frozen envs stay where they are)
+        oracle.rollout(w.cfg, weights, 13, t, 0, w.P, w.S, w.H, 20, 0, w.st, 8)
+        _lib_set_epoch(w, t + 20)
+
+
+def _lib_set_epoch(w, epoch):
+    from raptor_amd import _lib
+    _lib.call("rq_rng_set_epoch", w.rng._h, epoch)
 
 
 # ------------------------------------------------------------------------------ scale ------
