@@ -78,7 +78,8 @@ struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
 struct rq_policy {
     rq_device* dev = nullptr;
     int ordinal = 0;
-    float* w_dev = nullptr;
+    float* w_dev = nullptr;       // raw parameters (checkpoint order)
+    float* w_packed = nullptr;    // MFMA A-operand image, rq::RQ_PACKED_FLOATS floats
     float w_host[RQ_POLICY_NUM_WEIGHTS];
     int precision = RQ_POLICY_FP32;
     uint32_t batch = 0, ld = 0;   // 0 = not sized yet
@@ -195,6 +196,30 @@ void policy_free_buffers(rq_policy* pol) {
 }
 
 }  // namespace
+
+namespace rq {
+
+// pair p = (layer, group g of 4 output rows, column c) with c = 0 the bias and c = 1 + k input k;
+// lanes 4*(p%16) + i of VGPR image p/16 hold row 4g + i.  See rq_device_math.hpp "actor".
+void pack_policy(const float* w, float* packed) {
+    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, W2 = 2016, B2 = 2080 };
+    for (int i = 0; i < RQ_PACKED_FLOATS; ++i) packed[i] = 0.0f;
+    int pair = 0;
+    auto emit = [&](const float* W, const float* bias, int groups, int K) {
+        for (int g = 0; g < groups; ++g)
+            for (int c = 0; c <= K; ++c, ++pair)
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * g + i;
+                    packed[(pair / 16) * 64 + 4 * (pair % 16) + i] = (c == 0) ? bias[row] : W[row * K + (c - 1)];
+                }
+    };
+    emit(w + W0, w + B0, 4, 22);
+    emit(w + WI, w + BI, 12, 16);
+    emit(w + WH, w + BH, 12, 16);
+    emit(w + W2, w + B2, 1, 16);
+}
+
+}  // namespace rq
 
 extern "C" {
 
@@ -620,9 +645,16 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
     std::memcpy(p->w_host, weights, sizeof(p->w_host));
     hipError_t e = hipMalloc(&p->w_dev, sizeof(p->w_host));
     if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed"); }
-    e = hipMemcpyAsync(p->w_dev, p->w_host, sizeof(p->w_host), hipMemcpyHostToDevice, dev->stream);
+    std::vector<float> packed(rq::RQ_PACKED_FLOATS);
+    rq::pack_policy(p->w_host, packed.data());
+    e = hipMalloc(&p->w_packed, packed.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(p->w_dev, p->w_host, sizeof(p->w_host), hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->w_packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
-    if (e != hipSuccess) { (void)hipFree(p->w_dev); delete p; return fail(RQ_ERR_HIP, "rq_policy_create: weight upload failed"); }
+    if (e != hipSuccess) {
+        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed); delete p;
+        return fail(RQ_ERR_HIP, "rq_policy_create: weight upload failed");
+    }
     *out = p;
     return RQ_OK;
 }
@@ -632,6 +664,7 @@ RQ_API int rq_policy_destroy(rq_policy* pol) {
     (void)hipSetDevice(pol->ordinal);
     policy_free_buffers(pol);
     if (pol->w_dev) (void)hipFree(pol->w_dev);
+    if (pol->w_packed) (void)hipFree(pol->w_packed);
     delete pol;
     return RQ_OK;
 }
@@ -676,7 +709,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     }
     float* d_act = action ? pol->act : env->act;
     const uint32_t ld_act = action ? pol->ld : env->ld;
-    RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, pol->w_dev, d_obs, ld_obs, pol->hidden, pol->ld, d_act,
+    RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, pol->w_packed, d_obs, ld_obs, pol->hidden, pol->ld, d_act,
                                  ld_act, nullptr, pol->precision));
     if (action) return soa_to_host(pol->dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
     return RQ_OK;
@@ -742,13 +775,13 @@ RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_s
     const bool noise = rq::noise_enabled(env->cfg);
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
-                                        params->d, state->d, policy->hidden, policy->w_dev, env->st,
+                                        params->d, state->d, policy->hidden, policy->w_dev, policy->w_packed, env->st,
                                         policy->precision));
     } else {
         for (uint32_t t = 0; t < n_steps; ++t) {
             RQ_HIP(rq::launch_observe(dev->stream, b, nc, noise, rng->seed, rng->epoch + t, params->d, state->d,
                                       env->obs));
-            RQ_HIP(rq::launch_actor_step(dev->stream, env->n, policy->w_dev, env->obs, env->ld, policy->hidden,
+            RQ_HIP(rq::launch_actor_step(dev->stream, env->n, policy->w_packed, env->obs, env->ld, policy->hidden,
                                          policy->ld, env->act, env->ld, env->st.frozen, policy->precision));
             RQ_HIP(rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
                                    /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev));

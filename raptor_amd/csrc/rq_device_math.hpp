@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "../../include/raptor_quad.h"
 #include "rq_kernels.hpp"
 
@@ -340,9 +341,6 @@ __device__ __forceinline__ void sample_state(const SampleCfg& c, uint64_t seed, 
 enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF_BH = 1952,
        OFF_H0 = 2000, OFF_W2 = 2016, OFF_B2 = 2080 };
 
-// weights are read through the constant address space so that uniform indices select s_load
-typedef const float __attribute__((address_space(4))) * wptr_t;
-
 // sigma(x) = 1 / (1 + 2^(-x log2 e)) on v_exp_f32 + v_rcp_f32 (1 ulp each)
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -352,49 +350,89 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
 }
 
-// One recurrent step for this lane's env.  `w` is wave-uniform (kernel argument), every index
-// is a compile-time constant, so the weights arrive by scalar loads (s_load_dwordx*) and feed
-// v_fma_f32 as SGPR operands: no LDS traffic, no VGPRs for weights.
-// Dense: acc = b; acc = fma(W[o][k], x[k], acc), k ascending (same chain as the oracle).
-__device__ __forceinline__ void actor_step(wptr_t w, const float (&x)[22], float (&h)[16], float (&a)[4]) {
+// The dense contractions run on the matrix cores with the lane-per-env layout left intact:
+// v_mfma_f32_4x4x1_16b_f32 computes, for each of the 16 four-lane blocks of a wave,
+// D[i][j] += A[i] * B[j]  (i = output row, j = lane within the block).  With B = this lane's
+// activation x_k and A = four weights W[4g..4g+3][k], accumulator register r of lane l ends up
+// holding sum_k W[4g+r][k] * x_k(env l): four output features of the lane's own env, no
+// cross-lane traffic.  cbsz:4 broadcasts the A block selected by abid to all 16 blocks, so ONE
+// VGPR carries 16 different (g,k) weight quadruples: the whole policy (2 084 parameters) is
+// register-stationary in 33 VGPRs for the entire rollout — no LDS, no scalar loads.
+// K = 1 per instruction, so each accumulator follows exactly the chain
+//   acc = b; acc = fma(W[o][k], x[k], acc), k ascending
+// of the oracle (an f32 MFMA is one correctly rounded fma per product).
+//
+// Packed layout (built by the host, rq_capi.cpp pack_policy): "pair" p = one (bias|k, g)
+// quadruple; value for lane 4*(p%16)+i of VGPR p/16 is row 4g+i.  Pair order:
+//   layer_0 : g = 0..3   x [bias, k = 0..21]   -> pairs   0 ..  91
+//   gru W_i : g = 0..11  x [bias, k = 0..15]   -> pairs  92 .. 295
+//   gru W_h : g = 0..11  x [bias, k = 0..15]   -> pairs 296 .. 499
+//   layer_2 : g = 0      x [bias, k = 0..15]   -> pairs 500 .. 516
+enum { PAIR_L0 = 0, PAIR_GI = 92, PAIR_GH = 296, PAIR_L2 = 500, NUM_PAIRS = 517, WP_REGS = 33 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int PAIR>
+__device__ __forceinline__ f32x4 mfma_pair(const float (&wp)[WP_REGS], float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(wp[PAIR / 16], b, c, /*cbsz=*/4, /*abid=*/PAIR % 16, 0);
+}
+
+// every lane loads its slice of the packed weights; MUST run with all 64 lanes active (the MFMA
+// reads the A operand from the lanes of block abid whatever the EXEC mask is)
+__device__ __forceinline__ void load_packed_weights(const float* __restrict__ packed, float (&wp)[WP_REGS]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int v = 0; v < WP_REGS; ++v) wp[v] = packed[v * 64 + lane];
+}
+
+// acc[g] = bias + W x for NG groups of 4 output rows, K inputs; k outer / g inner so that
+// consecutive MFMAs are independent
+template <int BASE, int NG, int K>
+__device__ __forceinline__ void dense_mfma(const float (&wp)[WP_REGS], const float (&x)[K], f32x4 (&acc)[NG]) {
+    static_for<NG>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        acc[g] = mfma_pair<BASE + g * (K + 1)>(wp, 1.0f, f32x4{0.f, 0.f, 0.f, 0.f});
+    });
+    static_for<K>([&](auto KK) {
+        constexpr int k = decltype(KK)::value;
+        static_for<NG>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            acc[g] = mfma_pair<BASE + g * (K + 1) + 1 + k>(wp, x[k], acc[g]);
+        });
+    });
+}
+
+// One recurrent step for this lane's env: x[22] -> a[4], h[16] updated in place.
+__device__ __forceinline__ void actor_step(const float (&wp)[WP_REGS], const float (&x)[22], float (&h)[16],
+                                           float (&a)[4]) {
+    f32x4 l0[4];
+    dense_mfma<PAIR_L0, 4, 22>(wp, x, l0);
     float y0[16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-        float acc = w[OFF_B0 + o];
-#pragma unroll
-        for (int k = 0; k < 22; ++k) acc = fmaf(w[OFF_W0 + o * 22 + k], x[k], acc);
-        y0[o] = fmaxf(acc, 0.0f);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float hn[16];
+    for (int o = 0; o < 16; ++o) y0[o] = fmaxf(l0[o / 4][o % 4], 0.0f);
+    f32x4 gi[12], gh[12];
+    dense_mfma<PAIR_GI, 12, 16>(wp, y0, gi);
+    dense_mfma<PAIR_GH, 12, 16>(wp, h, gh);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        float gir = w[OFF_BI + j], giz = w[OFF_BI + 16 + j], gin = w[OFF_BI + 32 + j];
-        float ghr = w[OFF_BH + j], ghz = w[OFF_BH + 16 + j], ghn = w[OFF_BH + 32 + j];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            gir = fmaf(w[OFF_WI + (j) * 16 + k], y0[k], gir);
-            giz = fmaf(w[OFF_WI + (16 + j) * 16 + k], y0[k], giz);
-            gin = fmaf(w[OFF_WI + (32 + j) * 16 + k], y0[k], gin);
-            ghr = fmaf(w[OFF_WH + (j) * 16 + k], h[k], ghr);
-            ghz = fmaf(w[OFF_WH + (16 + j) * 16 + k], h[k], ghz);
-            ghn = fmaf(w[OFF_WH + (32 + j) * 16 + k], h[k], ghn);
-        }
-        const float r = fast_sigmoid(gir + ghr);
-        const float z = fast_sigmoid(giz + ghz);
-        const float n = fast_tanh(fmaf(r, ghn, gin));
-        hn[j] = fmaf(z, h[j] - n, n);
-        __builtin_amdgcn_sched_barrier(0);
+        const float r = fast_sigmoid(gi[j / 4][j % 4] + gh[j / 4][j % 4]);
+        const float z = fast_sigmoid(gi[4 + j / 4][j % 4] + gh[4 + j / 4][j % 4]);
+        const float n = fast_tanh(fmaf(r, gh[8 + j / 4][j % 4], gi[8 + j / 4][j % 4]));
+        h[j] = fmaf(z, h[j] - n, n);
     }
+    f32x4 l2[1];
+    dense_mfma<PAIR_L2, 1, 16>(wp, h, l2);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) h[j] = hn[j];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        float acc = w[OFF_B2 + o];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fmaf(w[OFF_W2 + o * 16 + k], h[k], acc);
-        a[o] = acc;
-    }
+    for (int o = 0; o < 4; ++o) a[o] = l2[0][o];
 }
 
 // ------------------------------------------------------------------ episode statistics -

@@ -77,24 +77,32 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 }
 
 // ------------------------------------------------------------------ actor --------------
-__global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* __restrict__ w,
+// MFMA ignores the EXEC mask and reads its A operand from the lanes of block `abid`, so every
+// MFMA must execute in wave-uniform control flow with all 64 lanes holding valid data: lanes
+// past the end of the batch (and frozen envs) compute on a clamped index and only their STORES
+// are predicated — no lane leaves early.
+__global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen) {
-    const uint32_t i = env_index();
-    if (i >= n) return;
-    if (frozen != nullptr && frozen[i]) return;
+    float wp[WP_REGS];
+    load_packed_weights(packed, wp);
+    const uint32_t i0 = env_index();
+    const uint32_t i = i0 < n ? i0 : n - 1;
+    const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
     float x[22], h[16], a[4];
 #pragma unroll
     for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
 #pragma unroll
     for (int k = 0; k < 16; ++k) h[k] = hidden[(size_t)k * ld_h + i];
-    actor_step((wptr_t)(uint64_t)w, x, h, a);
+    actor_step(wp, x, h, a);
+    if (commit) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) hidden[(size_t)k * ld_h + i] = h[k];
+        for (int k = 0; k < 16; ++k) hidden[(size_t)k * ld_h + i] = h[k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
+        for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
+    }
 }
 
 // ------------------------------------------------------------------ step ---------------
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
             st.episode[i] = ep + 1;
             write_dist = true;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = ((wptr_t)(uint64_t)weights)[OFF_H0 + j];
+            for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = weights[OFF_H0 + j];
         } else {
             st.frozen[i] = 1;
         }
@@ -163,18 +171,24 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 
 // ------------------------------------------------------------------ fused rollout ------
 // K iterations of observe -> evaluate_step -> step -> assign with the env state, the GRU
-// hidden state, the per-env constants and the episode statistics resident in VGPRs; HBM is
-// touched once before and once after the K steps.
+// hidden state, the per-env constants, the policy weights and the episode statistics resident
+// in VGPRs; HBM is touched once before and once after the K steps.
+// Control flow is wave-uniform around the MFMAs (see k_actor_step): lanes past the end of the
+// batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
+// the rare auto-reset branch (no MFMA inside) diverges.
 template <bool NOISE, bool AUTORESET>
 __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
                                                                uint64_t seed, uint32_t epoch0, uint32_t n_steps,
                                                                const float* __restrict__ params,
                                                                float* __restrict__ state,
                                                                float* __restrict__ hidden,
-                                                               const float* __restrict__ w, StatsPtrs st) {
-    const uint32_t i = env_index();
-    if (i >= b.n) return;
-    if (st.frozen[i]) return;
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ packed, StatsPtrs st) {
+    float wp[WP_REGS];
+    load_packed_weights(packed, wp);
+    const uint32_t i0 = env_index();
+    const uint32_t i = i0 < b.n ? i0 : b.n - 1;
+    const bool valid = i0 < b.n;
     const size_t ld = b.ld;
     const uint64_t genv = b.env_offset + i;
     const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
@@ -191,55 +205,66 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     float last_r = st.last_reward[i];
     bool last_t = st.last_terminated[i] != 0;
-    bool frozen = false, any_end = false, dist_changed = false;
+    const bool was_frozen = st.frozen[i] != 0;
+    bool frozen = was_frozen, any_end = false, dist_changed = false;
     uint32_t ep = AUTORESET ? st.episode[i] : 0u;
 
     for (uint32_t t = 0; t < n_steps; ++t) {
+        if (!AUTORESET && __builtin_amdgcn_ballot_w64(!frozen) == 0) break;   // wave-uniform exit
         float o[22], a[4], ac[4];
         observe_head<NOISE>(y, la, nc, seed, epoch0 + t, genv, o);
-        // launder the (wave-uniform) weight pointer once per step: otherwise LICM hoists all
-        // 2 084 scalar weight loads out of the loop and spills them
-        uint64_t wbits = (uint64_t)w;
-        asm volatile("" : "+s"(wbits));
-        actor_step((wptr_t)wbits, o, h, a);
+        float hn[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hn[j] = h[j];
+        actor_step(wp, o, hn, a);
+        float yn[17];
+#pragma unroll
+        for (int j = 0; j < 17; ++j) yn[j] = y[j];
         bool term;
-        const float r = step_inplace(c, k, ds, y, a, ac, term);
+        const float r = step_inplace(c, k, ds, yn, a, ac, term);
+        if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) la[j] = ac[j];
-        last_r = r; last_t = term;
-        if (stats_update(c.episode_step_limit, r, term, s)) {
-            any_end = true;
-            if (AUTORESET) {
-                sample_state(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
-                             params[(size_t)RQ_P_HOVER_RPM * ld + i], params[(size_t)RQ_P_ROTOR_POS * ld + i],
-                             params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], y, la, f6);
-                ep += 1;
-                ds = make_disturbance(k, c.gravity, f6);
-                dist_changed = true;
+            for (int j = 0; j < 17; ++j) y[j] = yn[j];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) h[j] = ((wptr_t)(uint64_t)w)[OFF_H0 + j];
-            } else {
-                frozen = true;
-                break;
+            for (int j = 0; j < 16; ++j) h[j] = hn[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) la[j] = ac[j];
+            last_r = r; last_t = term;
+            if (stats_update(c.episode_step_limit, r, term, s)) {
+                any_end = true;
+                if (AUTORESET) {
+                    sample_state(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
+                                 params[(size_t)RQ_P_HOVER_RPM * ld + i], params[(size_t)RQ_P_ROTOR_POS * ld + i],
+                                 params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], y, la, f6);
+                    ep += 1;
+                    ds = make_disturbance(k, c.gravity, f6);
+                    dist_changed = true;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) h[j] = w[OFF_H0 + j];
+                } else {
+                    frozen = true;
+                }
             }
         }
     }
 
+    if (valid && !was_frozen) {
 #pragma unroll
-    for (int j = 0; j < 17; ++j) state[(size_t)j * ld + i] = y[j];
+        for (int j = 0; j < 17; ++j) state[(size_t)j * ld + i] = y[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i] = la[j];
-    if (dist_changed) {
+        for (int j = 0; j < 4; ++j) state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i] = la[j];
+        if (dist_changed) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
+            for (int j = 0; j < 6; ++j) state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = h[j];
+        store_stats(st, i, s, any_end);
+        st.last_reward[i] = last_r;
+        st.last_terminated[i] = last_t ? 1 : 0;
+        if (AUTORESET) st.episode[i] = ep;
+        if (frozen) st.frozen[i] = 1;
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = h[j];
-    store_stats(st, i, s, any_end);
-    st.last_reward[i] = last_r;
-    st.last_terminated[i] = last_t ? 1 : 0;
-    if (AUTORESET) st.episode[i] = ep;
-    if (frozen) st.frozen[i] = 1;
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, float v, uint32_t count) {
@@ -271,12 +296,12 @@ hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint6
     return hipGetLastError();
 }
 
-hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* weights, const float* obs, uint32_t ld_obs,
+hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
                              int precision) {
     if (n == 0) return hipSuccess;
     (void)precision;
-    k_actor_step<<<grid_for(n, kBlock), kBlock, 0, s>>>(n, weights, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+    k_actor_step<<<grid_for(n, kBlock), kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
     return hipGetLastError();
 }
 
@@ -296,13 +321,13 @@ hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, c
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                StatsPtrs st, int precision) {
+                                const float* packed, StatsPtrs st, int precision) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
     (void)precision;
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
 #define RQ_LAUNCH_FUSED(NZ, AR) \
-    k_rollout_fused<NZ, AR><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, st)
+    k_rollout_fused<NZ, AR><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st)
     if (noise) { if (ar) RQ_LAUNCH_FUSED(true, true); else RQ_LAUNCH_FUSED(true, false); }
     else       { if (ar) RQ_LAUNCH_FUSED(false, true); else RQ_LAUNCH_FUSED(false, false); }
 #undef RQ_LAUNCH_FUSED

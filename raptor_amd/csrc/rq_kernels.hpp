@@ -72,7 +72,8 @@ hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint6
                           const float* params, const float* state, float* obs);
 // Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.
 // frozen != nullptr: envs with frozen[i] != 0 are skipped (rollout semantics).
-hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* weights, const float* obs, uint32_t ld_obs,
+// `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
+hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
                              int precision);
 // vector.step (README.md:98) + reward/termination/statistics.  rollout != 0 adds the
@@ -84,7 +85,12 @@ hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, c
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                StatsPtrs st, int precision);
+                                const float* packed, StatsPtrs st, int precision);
+// Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
+// v_mfma_f32_4x4x1_16b_f32 instructions read as A operands (layout: rq_device_math.hpp "actor").
+enum { RQ_PACKED_REGS = 33, RQ_PACKED_FLOATS = 33 * 64 };
+void pack_policy(const float* weights, float* packed);
+
 // out[i] = value for i < count (uint32 / float / uint8 fills on the stream)
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, uint32_t count);
 

@@ -1,0 +1,121 @@
+// tools/kbench.hip — developer micro-benchmark: ablations of the fused rollout loop body
+// (not part of the product library).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17
+//   -ffp-contract=off tools/kbench.hip raptor_amd/csrc/rq_capi.cpp(pack only) ...
+// Usage: kbench <n_envs> <steps>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../raptor_amd/csrc/rq_device_math.hpp"
+
+using namespace rq;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+static void pack_policy_host(const float* w, float* packed) {
+    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, W2 = 2016, B2 = 2080 };
+    for (int i = 0; i < 33 * 64; ++i) packed[i] = 0.0f;
+    int pair = 0;
+    auto emit = [&](const float* W, const float* bias, int groups, int K) {
+        for (int g = 0; g < groups; ++g)
+            for (int c = 0; c <= K; ++c, ++pair)
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * g + i;
+                    packed[(pair / 16) * 64 + 4 * (pair % 16) + i] = (c == 0) ? bias[row] : W[row * K + (c - 1)];
+                }
+    };
+    emit(w + W0, w + B0, 4, 22); emit(w + WI, w + BI, 12, 16); emit(w + WH, w + BH, 12, 16); emit(w + W2, w + B2, 1, 16);
+}
+
+// MODE 0: full step; 1: actor only; 2: env only (observe + step); 3: MFMA only (no gates); 4: gates only
+template <int MODE>
+__global__ __launch_bounds__(64) void k_loop(uint32_t n, uint32_t steps, const float* __restrict__ packed,
+                                             float* __restrict__ out, StepCfg c) {
+    float wp[WP_REGS];
+    load_packed_weights(packed, wp);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const float fi = (float)(i & 1023) * 1e-3f;
+    EnvConsts k;
+    k.inv_m = 1.0f / 0.027f; k.jx = 3.85e-6f; k.jy = 3.85e-6f; k.jz = 5.9675e-6f;
+    k.ijx = 1.0f / k.jx; k.ijy = 1.0f / k.jy; k.ijz = 1.0f / k.jz;
+    const float sx[4] = {1.f, -1.f, -1.f, 1.f}, sy[4] = {-1.f, -1.f, 1.f, 1.f};
+    for (int r = 0; r < 4; ++r) { k.px[r] = sx[r] * 0.028f; k.py[r] = sy[r] * 0.028f; }
+    k.c0 = 0; k.c1 = 0; k.c2 = 3.16e-10f; k.kq = 0.005964552f; k.itr = 1.0f / 0.15f; k.itf = 1.0f / 0.15f;
+    k.rmin = 0; k.rmax = 21702.0f; k.half = 10851.0f; k.mid = 10851.0f; k.ha = 0.334f;
+    float f6[6] = {0, 0, 0, 0, 0, 0};
+    Disturbance ds = make_disturbance(k, c.gravity, f6);
+    float y[17] = {fi, -fi, 0.1f * fi, 1, 0, 0, 0, 0.1f, 0, 0, 0, 0, 0, 14500.f, 14500.f, 14500.f, 14500.f};
+    float la[4] = {0, 0, 0, 0}, h[16];
+    for (int j = 0; j < 16; ++j) h[j] = 0.0f;
+    NoiseCfg nc = {0, 0, 0, 0};
+    float sink = 0.0f;
+    for (uint32_t t = 0; t < steps; ++t) {
+        float o[22], a[4], ac[4];
+        if (MODE == 0 || MODE == 2) observe_head<false>(y, la, nc, 0, t, i, o);
+        else { for (int j = 0; j < 22; ++j) o[j] = y[j % 17] + (float)j; }
+        if (MODE == 0 || MODE == 1) actor_step(wp, o, h, a);
+        else if (MODE == 3) {
+            f32x4 l0[4]; dense_mfma<PAIR_L0, 4, 22>(wp, o, l0);
+            float y0[16]; for (int q = 0; q < 16; ++q) y0[q] = fmaxf(l0[q / 4][q % 4], 0.0f);
+            f32x4 gi[12], gh[12];
+            dense_mfma<PAIR_GI, 12, 16>(wp, y0, gi); dense_mfma<PAIR_GH, 12, 16>(wp, h, gh);
+            for (int j = 0; j < 16; ++j) h[j] = 0.001f * (gi[j / 4][j % 4] + gh[j / 4][j % 4] + gi[4 + j / 4][j % 4] + gh[4 + j / 4][j % 4] + gi[8 + j / 4][j % 4] + gh[8 + j / 4][j % 4]);
+            f32x4 l2[1]; dense_mfma<PAIR_L2, 1, 16>(wp, h, l2);
+            for (int q = 0; q < 4; ++q) a[q] = l2[0][q];
+        } else if (MODE == 4) {
+            for (int j = 0; j < 16; ++j) {
+                const float r = fast_sigmoid(o[j] + h[j]);
+                const float z = fast_sigmoid(o[(j + 3) % 22] - h[j]);
+                const float nn = fast_tanh(fmaf(r, o[(j + 7) % 22], h[(j + 1) % 16]));
+                h[j] = fmaf(z, h[j] - nn, nn);
+            }
+            for (int q = 0; q < 4; ++q) a[q] = h[q];
+        } else { for (int q = 0; q < 4; ++q) a[q] = o[q] * 0.01f + 0.3f; }
+        if (MODE == 0 || MODE == 2) {
+            bool term;
+            const float r = step_inplace(c, k, ds, y, a, ac, term);
+            sink += r + (term ? 1.f : 0.f);
+            for (int j = 0; j < 4; ++j) la[j] = ac[j];
+        } else { for (int q = 0; q < 4; ++q) y[q] = fmaf(a[q], 1e-3f, y[q] * 0.999f); }
+    }
+    float acc = sink;
+    for (int j = 0; j < 17; ++j) acc += y[j];
+    for (int j = 0; j < 16; ++j) acc += h[j];
+    out[i] = acc;
+}
+
+template <int MODE>
+static void run(const char* name, uint32_t n, uint32_t steps, const float* packed, float* out, StepCfg c) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    k_loop<MODE><<<n / 64, 64>>>(n, 50, packed, out, c);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        k_loop<MODE><<<n / 64, 64>>>(n, steps, packed, out, c);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    printf("%-14s n=%u steps=%u  %.3f ms  %.3f us/step  %.0f cycles/step@2.4GHz  %.3e env-steps/s\n", name, n, steps, best,
+           best * 1e3 / steps, best * 1e-3 / steps * 2.4e9, (double)n * steps / (best * 1e-3));
+}
+
+int main(int argc, char** argv) {
+    uint32_t n = argc > 1 ? atoi(argv[1]) : 65536, steps = argc > 2 ? atoi(argv[2]) : 500;
+    std::vector<float> w(2084), packed(33 * 64);
+    FILE* f = fopen("raptor_amd/data/raptor_policy.bin", "rb");
+    if (!f || fread(w.data(), 4, 2084, f) != 2084) { printf("weights?\n"); return 1; }
+    fclose(f);
+    pack_policy_host(w.data(), packed.data());
+    float *dp, *dout;
+    CK(hipMalloc(&dp, packed.size() * 4)); CK(hipMalloc(&dout, n * 4));
+    CK(hipMemcpy(dp, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    StepCfg c = {0.01f, 9.81f, 500, 1.f, 1.5f, 0.f, 1.f, 0.1f, 0.01f, 0.001f, 0.01f, 1, 3.f, 1000.f, 1000.f};
+    run<0>("full", n, steps, dp, dout, c);
+    run<1>("actor", n, steps, dp, dout, c);
+    run<2>("env", n, steps, dp, dout, c);
+    run<3>("mfma-only", n, steps, dp, dout, c);
+    run<4>("gates-only", n, steps, dp, dout, c);
+    return 0;
+}
