@@ -199,24 +199,35 @@ void policy_free_buffers(rq_policy* pol) {
 
 namespace rq {
 
-// pair p = (layer, group g of 4 output rows, column c) with c = 0 the bias and c = 1 + k input k;
-// lanes 4*(p%16) + i of VGPR image p/16 hold row 4g + i.  See rq_device_math.hpp "actor".
+// One 64-lane VGPR image per MFMA A operand / bias vector; lane l = (q = l >> 4, j = l & 15).
+// Layout table: rq_device_math.hpp "actor" (enum QW_*).
 void pack_policy(const float* w, float* packed) {
-    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, W2 = 2016, B2 = 2080 };
+    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, H0 = 2000, W2 = 2016, B2 = 2080 };
     for (int i = 0; i < RQ_PACKED_FLOATS; ++i) packed[i] = 0.0f;
-    int pair = 0;
-    auto emit = [&](const float* W, const float* bias, int groups, int K) {
-        for (int g = 0; g < groups; ++g)
-            for (int c = 0; c <= K; ++c, ++pair)
-                for (int i = 0; i < 4; ++i) {
-                    const int row = 4 * g + i;
-                    packed[(pair / 16) * 64 + 4 * (pair % 16) + i] = (c == 0) ? bias[row] : W[row * K + (c - 1)];
-                }
-    };
-    emit(w + W0, w + B0, 4, 22);
-    emit(w + WI, w + BI, 12, 16);
-    emit(w + WH, w + BH, 12, 16);
-    emit(w + W2, w + B2, 1, 16);
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, j = l & 15;
+        auto img = [&](int v) -> float& { return packed[v * 64 + l]; };
+        for (int s = 0; s < 6; ++s) {
+            const int f = 4 * s + q;     // input feature of k-slot q in K-step s
+            img(0 + s) = f < 22 ? w[W0 + j * 22 + f] : (f == 22 ? w[B0 + j] : 0.0f);
+        }
+        for (int m = 0; m < 3; ++m)
+            for (int s = 0; s < 4; ++s) {
+                img(6 + 4 * m + s) = w[WI + (16 * m + j) * 16 + 4 * q + s];
+                img(18 + 4 * m + s) = w[WH + (16 * m + j) * 16 + 4 * q + s];
+            }
+        for (int t = 0; t < 4; ++t)
+            for (int s = 0; s < 4; ++s) img(30 + 4 * t + s) = ((j >> 2) == t) ? w[W2 + (j & 3) * 16 + 4 * q + s] : 0.0f;
+        const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+        for (int r = 0; r < 4; ++r) {
+            img(46 + r) = kS * (w[BI + 4 * q + r] + w[BH + 4 * q + r]);
+            img(50 + r) = kS * (w[BI + 16 + 4 * q + r] + w[BH + 16 + 4 * q + r]);
+            img(54 + r) = kT * w[BI + 32 + 4 * q + r];
+            img(58 + r) = kT * w[BH + 32 + 4 * q + r];
+            img(62 + r) = w[H0 + 4 * q + r];
+            img(66 + r) = w[B2 + r];
+        }
+    }
 }
 
 }  // namespace rq

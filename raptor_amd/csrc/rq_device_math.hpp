@@ -350,89 +350,197 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
 }
 
-// The dense contractions run on the matrix cores with the lane-per-env layout left intact:
-// v_mfma_f32_4x4x1_16b_f32 computes, for each of the 16 four-lane blocks of a wave,
-// D[i][j] += A[i] * B[j]  (i = output row, j = lane within the block).  With B = this lane's
-// activation x_k and A = four weights W[4g..4g+3][k], accumulator register r of lane l ends up
-// holding sum_k W[4g+r][k] * x_k(env l): four output features of the lane's own env, no
-// cross-lane traffic.  cbsz:4 broadcasts the A block selected by abid to all 16 blocks, so ONE
-// VGPR carries 16 different (g,k) weight quadruples: the whole policy (2 084 parameters) is
-// register-stationary in 33 VGPRs for the entire rollout — no LDS, no scalar loads.
-// K = 1 per instruction, so each accumulator follows exactly the chain
-//   acc = b; acc = fma(W[o][k], x[k], acc), k ascending
-// of the oracle (an f32 MFMA is one correctly rounded fma per product).
+// The dense contractions of the actor run on the matrix cores as v_mfma_f32_16x16x4_f32 (exact
+// f32: one correctly rounded fma per product, the only f32 MFMA shape that reaches the full
+// 64 FLOP/clk/SIMD rate from a single wave — measured: the multi-block 4x4x1 form issues at
+// 12-16 cycles instead of 8).  A wave owns 64 envs = 4 tiles of 16 envs.  With lane l = (q, j),
+// q = l >> 4, j = l & 15:
 //
-// Packed layout (built by the host, rq_capi.cpp pack_policy): "pair" p = one (bias|k, g)
-// quadruple; value for lane 4*(p%16)+i of VGPR p/16 is row 4g+i.  Pair order:
-//   layer_0 : g = 0..3   x [bias, k = 0..21]   -> pairs   0 ..  91
-//   gru W_i : g = 0..11  x [bias, k = 0..15]   -> pairs  92 .. 295
-//   gru W_h : g = 0..11  x [bias, k = 0..15]   -> pairs 296 .. 499
-//   layer_2 : g = 0      x [bias, k = 0..15]   -> pairs 500 .. 516
-enum { PAIR_L0 = 0, PAIR_GI = 92, PAIR_GH = 296, PAIR_L2 = 500, NUM_PAIRS = 517, WP_REGS = 33 };
+//   native layout   lane (t, j) holds every feature of env (tile t, j)      [dynamics, observe]
+//   Q layout        for a 16-vector u of tile t: uQ[t][r] at lane (q, j) = u[4q + r] of env (t, j)
+//
+// D = W X on the MFMA has exactly the Q layout (lane (q,j), reg r = row 4q+r, column j), and a
+// Q-layout vector is directly the B operand of the next contraction if K-step s uses register
+// s: k-slot q then carries input feature 4q+s and the A operand (weights, one VGPR per
+// (16-row tile, K-step)) is laid out to match: lane (q, j) holds W[row j][4q + s].  So hidden
+// state, layer_0 output and all gate values live in the Q layout for the whole rollout, the
+// policy parameters are register-stationary (QW_REGS VGPRs: no LDS, no scalar loads) and only
+// two layout changes exist:
+//   observation (native) -> B operands: six 4x4 lane-group transposes (v_permlane32_swap +
+//     v_permlane16_swap, 4 instructions each);
+//   action: free — tile t's W2 is placed in A rows 4t..4t+3, the four tiles accumulate into
+//     one D whose lane (q, j) then holds the 4 actions of env (q, j): the native layout.
+//
+// Per wave and step: 24 + 96 + 16 = 136 MFMAs (4352 matrix cycles for 64 envs).
+// Summation order inside a dot product is (s = 0..3 outer, q = 0..3 inner), i.e. input
+// features 0,4,8,12,1,5,...; r and z gates chain W_i y0 and W_h h into one accumulator and the
+// biases are added last.  These are fp32 re-associations of the oracle's k-ascending chains
+// (differences ~1e-7, covered by the actor tolerance).
+//
+// Packed weight image (host: rq::pack_policy, one 64-lane VGPR image each):
+enum {
+    QW_L0 = 0,    //  6: layer_0, K-step s: lane (q,j) = W0[j][4s+q]; input 22 -> b0[j], input 23 -> 0
+    QW_GI = 6,    // 12: W_input,  [m][s]: lane (q,j) = Wi[16m+j][4q+s]
+    QW_GH = 18,   // 12: W_hidden, [m][s]: lane (q,j) = Wh[16m+j][4q+s]
+    QW_L2 = 30,   // 16: layer_2,  [t][s]: lane (q,j) = (j>>2 == t) ? W2[j&3][4q+s] : 0
+    // biases never occupy an MFMA C operand (that costs a 4-register copy per chain): layer_0's
+    // bias rides in the spare K slot 22 (its B operand is the constant 1), the gate biases are
+    // folded, pre-scaled, into the fma that feeds v_exp_f32, layer_2's is added after the MFMAs
+    QW_BR = 46,   //  4: [r]: -log2(e)  * (bi[4q+r] + bh[4q+r])
+    QW_BZ = 50,   //  4: [r]: -log2(e)  * (bi[16+4q+r] + bh[16+4q+r])
+    QW_BNI = 54,  //  4: [r]: -2log2(e) * bi[32+4q+r]
+    QW_BNH = 58,  //  4: [r]: -2log2(e) * bh[32+4q+r]
+    QW_H0 = 62,   //  4: [r]: initial_hidden_state[4q+r]
+    QW_B2 = 66,   //  4: [r]: b2[r] on every lane
+    QW_REGS = 70
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int... Is, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int PAIR>
-__device__ __forceinline__ f32x4 mfma_pair(const float (&wp)[WP_REGS], float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(wp[PAIR / 16], b, c, /*cbsz=*/4, /*abid=*/PAIR % 16, 0);
-}
-
-// every lane loads its slice of the packed weights; MUST run with all 64 lanes active (the MFMA
-// reads the A operand from the lanes of block abid whatever the EXEC mask is)
-__device__ __forceinline__ void load_packed_weights(const float* __restrict__ packed, float (&wp)[WP_REGS]) {
+// every lane loads its slice of the packed weights; all 64 lanes must be active
+__device__ __forceinline__ void load_packed_weights(const float* __restrict__ packed, float (&W)[QW_REGS]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int v = 0; v < WP_REGS; ++v) wp[v] = packed[v * 64 + lane];
+    for (int v = 0; v < QW_REGS; ++v) W[v] = packed[v * 64 + lane];
 }
 
-// acc[g] = bias + W x for NG groups of 4 output rows, K inputs; k outer / g inner so that
-// consecutive MFMAs are independent
-template <int BASE, int NG, int K>
-__device__ __forceinline__ void dense_mfma(const float (&wp)[WP_REGS], const float (&x)[K], f32x4 (&acc)[NG]) {
-    static_for<NG>([&](auto G) {
-        constexpr int g = decltype(G)::value;
-        acc[g] = mfma_pair<BASE + g * (K + 1)>(wp, 1.0f, f32x4{0.f, 0.f, 0.f, 0.f});
-    });
-    static_for<K>([&](auto KK) {
-        constexpr int k = decltype(KK)::value;
-        static_for<NG>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            acc[g] = mfma_pair<BASE + g * (K + 1) + 1 + k>(wp, x[k], acc[g]);
-        });
-    });
+__device__ __forceinline__ void swap32(float& a, float& b) {   // a.lanes[32..63] <-> b.lanes[0..31]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {   // odd 16-lane rows of a <-> even rows of b
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// in : n[c] at lane-group g = feature c of the lane's own env (tile g)
+// out: n[t] at lane-group q = feature q of env (tile t, same j)
+__device__ __forceinline__ void transpose4(float& n0, float& n1, float& n2, float& n3) {
+    swap32(n0, n2); swap32(n1, n3);
+    swap16(n0, n1); swap16(n2, n3);
 }
 
-// One recurrent step for this lane's env: x[22] -> a[4], h[16] updated in place.
-__device__ __forceinline__ void actor_step(const float (&wp)[WP_REGS], const float (&x)[22], float (&h)[16],
+// One recurrent step for the 64 envs of this wave.  o: native observation; hQ[t][r]: hidden state
+// in the Q layout, updated in place; a: native action.  Wave-uniform control flow required.
+__device__ __forceinline__ void actor_step(const float (&W)[QW_REGS], const float (&o)[22], float (&hQ)[4][4],
                                            float (&a)[4]) {
-    f32x4 l0[4];
-    dense_mfma<PAIR_L0, 4, 22>(wp, x, l0);
-    float y0[16];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // observation -> B operands of layer_0: X[s][t] at lane (q,j) = o[4s+q] of env (t,j);
+    // input 22 is the constant 1 that carries the bias, input 23 is padding
+    float X[6][4];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) y0[o] = fmaxf(l0[o / 4][o % 4], 0.0f);
-    f32x4 gi[12], gh[12];
-    dense_mfma<PAIR_GI, 12, 16>(wp, y0, gi);
-    dense_mfma<PAIR_GH, 12, 16>(wp, h, gh);
+    for (int s = 0; s < 6; ++s) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float r = fast_sigmoid(gi[j / 4][j % 4] + gh[j / 4][j % 4]);
-        const float z = fast_sigmoid(gi[4 + j / 4][j % 4] + gh[4 + j / 4][j % 4]);
-        const float n = fast_tanh(fmaf(r, gh[8 + j / 4][j % 4], gi[8 + j / 4][j % 4]));
-        h[j] = fmaf(z, h[j] - n, n);
+        for (int c = 0; c < 4; ++c) {
+            const int f = 4 * s + c;
+            X[s][c] = f < 22 ? o[f < 22 ? f : 21] : (f == 22 ? 1.0f : 0.0f);
+        }
+        transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
     }
-    f32x4 l2[1];
-    dense_mfma<PAIR_L2, 1, 16>(wp, h, l2);
+    f32x4 y0[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) a[o] = l2[0][o];
+    for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0], X[0][t], zero);
+#pragma unroll
+    for (int s = 1; s < 6; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0 + s], X[s][t], y0[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y0[t][r] = fmaxf(y0[t][r], 0.0f);
+
+    f32x4 gr[4], gz[4], gni[4], gnh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        gr[t] = mfma16(W[QW_GI + 0], y0[t][0], zero);
+        gz[t] = mfma16(W[QW_GI + 4], y0[t][0], zero);
+        gni[t] = mfma16(W[QW_GI + 8], y0[t][0], zero);
+        gnh[t] = mfma16(W[QW_GH + 8], hQ[t][0], zero);
+    }
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            gr[t] = mfma16(W[QW_GI + 0 + s], y0[t][s], gr[t]);
+            gz[t] = mfma16(W[QW_GI + 4 + s], y0[t][s], gz[t]);
+            gni[t] = mfma16(W[QW_GI + 8 + s], y0[t][s], gni[t]);
+            gnh[t] = mfma16(W[QW_GH + 8 + s], hQ[t][s], gnh[t]);
+        }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            gr[t] = mfma16(W[QW_GH + 0 + s], hQ[t][s], gr[t]);
+            gz[t] = mfma16(W[QW_GH + 4 + s], hQ[t][s], gz[t]);
+        }
+    // gates: sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2log2e)) - 1,
+    // with the pre-scaled biases b' of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each)
+    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, W[QW_BR + r])));
+            const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, W[QW_BZ + r])));
+            const float u = fmaf(rr, gnh[t][r], gni[t][r]);
+            const float v = fmaf(rr, W[QW_BNH + r], W[QW_BNI + r]);
+            const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
+            hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
+        }
+    // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
+    f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], zero);
+    f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
+    d0 = mfma16(W[QW_L2 + 8], hQ[2][0], d0);
+    d1 = mfma16(W[QW_L2 + 12], hQ[3][0], d1);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        d0 = mfma16(W[QW_L2 + 0 + s], hQ[0][s], d0);
+        d1 = mfma16(W[QW_L2 + 4 + s], hQ[1][s], d1);
+        d0 = mfma16(W[QW_L2 + 8 + s], hQ[2][s], d0);
+        d1 = mfma16(W[QW_L2 + 12 + s], hQ[3][s], d1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + W[QW_B2 + r];
+}
+
+// Q-layout addressing helpers for a wave whose first env is wave_base: tile t of lane (q,j) is
+// env wave_base + 16 t + j (clamped to the batch), hidden feature 4q + r.
+__device__ __forceinline__ void load_hidden_q(const float* __restrict__ hidden, size_t ld, uint32_t wave_base,
+                                              uint32_t n, float (&hQ)[4][4]) {
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        uint32_t e = wave_base + 16 * t + j;
+        e = e < n ? e : n - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hQ[t][r] = hidden[(size_t)(4 * q + r) * ld + e];
+    }
+}
+// commit_mask: bit (16 t + j) set = env (t, j) of this wave may be written
+__device__ __forceinline__ void store_hidden_q(float* __restrict__ hidden, size_t ld, uint32_t wave_base,
+                                               uint64_t commit_mask, const float (&hQ)[4][4]) {
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if ((commit_mask >> (16 * t + j)) & 1ull) {
+            const uint32_t e = wave_base + 16 * t + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hidden[(size_t)(4 * q + r) * ld + e] = hQ[t][r];
+        }
+    }
+}
+// hQ[t][r] <- sel bit (16 t + j) ? src : hQ
+__device__ __forceinline__ void select_hidden_q(uint64_t mask, const float (&src)[4][4], float (&hQ)[4][4]) {
+    const uint32_t j = threadIdx.x & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool take = (mask >> (16 * t + j)) & 1ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hQ[t][r] = take ? src[t][r] : hQ[t][r];
+    }
 }
 
 // ------------------------------------------------------------------ episode statistics -

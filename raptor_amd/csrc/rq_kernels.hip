@@ -77,29 +77,29 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 }
 
 // ------------------------------------------------------------------ actor --------------
-// MFMA ignores the EXEC mask and reads its A operand from the lanes of block `abid`, so every
-// MFMA must execute in wave-uniform control flow with all 64 lanes holding valid data: lanes
-// past the end of the batch (and frozen envs) compute on a clamped index and only their STORES
-// are predicated — no lane leaves early.
+// MFMA ignores the EXEC mask and mixes the lanes of a wave, so every MFMA must execute in
+// wave-uniform control flow with all 64 lanes holding valid data: lanes past the end of the
+// batch (and frozen envs) compute on a clamped index and only their STORES are predicated —
+// no lane leaves early.
 __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen) {
-    float wp[WP_REGS];
-    load_packed_weights(packed, wp);
+    float W[QW_REGS];
+    load_packed_weights(packed, W);
     const uint32_t i0 = env_index();
+    const uint32_t wave_base = i0 & ~63u;
     const uint32_t i = i0 < n ? i0 : n - 1;
     const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
-    float x[22], h[16], a[4];
+    const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
+    float x[22], hQ[4][4], a[4];
 #pragma unroll
     for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) h[k] = hidden[(size_t)k * ld_h + i];
-    actor_step(wp, x, h, a);
+    load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+    actor_step(W, x, hQ, a);
+    store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
     if (commit) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) hidden[(size_t)k * ld_h + i] = h[k];
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
     }
@@ -184,23 +184,28 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
                                                                float* __restrict__ hidden,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ packed, StatsPtrs st) {
-    float wp[WP_REGS];
-    load_packed_weights(packed, wp);
+    float W[QW_REGS];
+    load_packed_weights(packed, W);
     const uint32_t i0 = env_index();
+    const uint32_t wave_base = i0 & ~63u;
     const uint32_t i = i0 < b.n ? i0 : b.n - 1;
     const bool valid = i0 < b.n;
     const size_t ld = b.ld;
     const uint64_t genv = b.env_offset + i;
     const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
-    float y[17], la[4], f6[6], h[16];
+    float y[17], la[4], f6[6], hQ[4][4];
 #pragma unroll
     for (int j = 0; j < 17; ++j) y[j] = state[(size_t)j * ld + i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) la[j] = state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i];
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = state[(size_t)(RQ_S_FORCE + j) * ld + i];
+    load_hidden_q(hidden, ld, wave_base, b.n, hQ);
+    float h0Q[4][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) h[j] = hidden[(size_t)j * ld + i];
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h0Q[t][r] = W[QW_H0 + r];
     Stats s = load_stats(st, i);
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     float last_r = st.last_reward[i];
@@ -210,27 +215,38 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
     uint32_t ep = AUTORESET ? st.episode[i] : 0u;
 
     for (uint32_t t = 0; t < n_steps; ++t) {
-        if (!AUTORESET && __builtin_amdgcn_ballot_w64(!frozen) == 0) break;   // wave-uniform exit
+        const uint64_t live = AUTORESET ? ~0ull : __builtin_amdgcn_ballot_w64(!frozen);
+        if (!AUTORESET && live == 0) break;   // wave-uniform exit: every env of the wave is frozen
         float o[22], a[4], ac[4];
         observe_head<NOISE>(y, la, nc, seed, epoch0 + t, genv, o);
-        float hn[16];
+        float hn[4][4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) hn[j] = h[j];
-        actor_step(wp, o, hn, a);
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
+        actor_step(W, o, hn, a);
+        if (AUTORESET) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hQ[tt][r] = hn[tt][r];
+        } else {
+            select_hidden_q(live, hn, hQ);    // frozen envs keep their hidden state
+        }
         float yn[17];
 #pragma unroll
         for (int j = 0; j < 17; ++j) yn[j] = y[j];
         bool term;
         const float r = step_inplace(c, k, ds, yn, a, ac, term);
+        bool ended = false;
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
 #pragma unroll
             for (int j = 0; j < 17; ++j) y[j] = yn[j];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) h[j] = hn[j];
-#pragma unroll
             for (int j = 0; j < 4; ++j) la[j] = ac[j];
             last_r = r; last_t = term;
-            if (stats_update(c.episode_step_limit, r, term, s)) {
+            ended = stats_update(c.episode_step_limit, r, term, s);
+            if (ended) {
                 any_end = true;
                 if (AUTORESET) {
                     sample_state(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
@@ -239,12 +255,14 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
                     ep += 1;
                     ds = make_disturbance(k, c.gravity, f6);
                     dist_changed = true;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) h[j] = w[OFF_H0 + j];
                 } else {
                     frozen = true;
                 }
             }
+        }
+        if (AUTORESET) {   // policy reset of the envs whose episode ended: h <- initial_hidden_state
+            const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
+            if (ended_mask != 0) select_hidden_q(ended_mask, h0Q, hQ);
         }
     }
 
@@ -257,14 +275,13 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
 #pragma unroll
             for (int j = 0; j < 6; ++j) state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
         }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = h[j];
         store_stats(st, i, s, any_end);
         st.last_reward[i] = last_r;
         st.last_terminated[i] = last_t ? 1 : 0;
         if (AUTORESET) st.episode[i] = ep;
         if (frozen) st.frozen[i] = 1;
     }
+    store_hidden_q(hidden, ld, wave_base, __builtin_amdgcn_ballot_w64(valid && !was_frozen), hQ);
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, float v, uint32_t count) {

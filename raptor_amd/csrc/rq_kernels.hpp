@@ -87,8 +87,8 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 const float* params, float* state, float* hidden, const float* weights,
                                 const float* packed, StatsPtrs st, int precision);
 // Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
-// v_mfma_f32_4x4x1_16b_f32 instructions read as A operands (layout: rq_device_math.hpp "actor").
-enum { RQ_PACKED_REGS = 33, RQ_PACKED_FLOATS = 33 * 64 };
+// v_mfma_f32_16x16x4_f32 instructions read as A / C operands (layout: rq_device_math.hpp "actor").
+enum { RQ_PACKED_REGS = 70, RQ_PACKED_FLOATS = 70 * 64 };
 void pack_policy(const float* weights, float* packed);
 
 // out[i] = value for i < count (uint32 / float / uint8 fills on the stream)

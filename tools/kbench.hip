@@ -12,27 +12,14 @@ using namespace rq;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
-static void pack_policy_host(const float* w, float* packed) {
-    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, W2 = 2016, B2 = 2080 };
-    for (int i = 0; i < 33 * 64; ++i) packed[i] = 0.0f;
-    int pair = 0;
-    auto emit = [&](const float* W, const float* bias, int groups, int K) {
-        for (int g = 0; g < groups; ++g)
-            for (int c = 0; c <= K; ++c, ++pair)
-                for (int i = 0; i < 4; ++i) {
-                    const int row = 4 * g + i;
-                    packed[(pair / 16) * 64 + 4 * (pair % 16) + i] = (c == 0) ? bias[row] : W[row * K + (c - 1)];
-                }
-    };
-    emit(w + W0, w + B0, 4, 22); emit(w + WI, w + BI, 12, 16); emit(w + WH, w + BH, 12, 16); emit(w + W2, w + B2, 1, 16);
-}
-
-// MODE 0: full step; 1: actor only; 2: env only (observe + step); 3: MFMA only (no gates); 4: gates only
+namespace rq { void pack_policy(const float* w, float* packed); }
+#define RQ_PACK_ONLY
+// MODE 0: full step; 1: actor only; 2: env only (observe + step); 4: gates only
 template <int MODE>
 __global__ __launch_bounds__(64) void k_loop(uint32_t n, uint32_t steps, const float* __restrict__ packed,
                                              float* __restrict__ out, StepCfg c) {
-    float wp[WP_REGS];
-    load_packed_weights(packed, wp);
+    float W[QW_REGS];
+    load_packed_weights(packed, W);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const float fi = (float)(i & 1023) * 1e-3f;
     EnvConsts k;
@@ -45,23 +32,16 @@ __global__ __launch_bounds__(64) void k_loop(uint32_t n, uint32_t steps, const f
     float f6[6] = {0, 0, 0, 0, 0, 0};
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     float y[17] = {fi, -fi, 0.1f * fi, 1, 0, 0, 0, 0.1f, 0, 0, 0, 0, 0, 14500.f, 14500.f, 14500.f, 14500.f};
-    float la[4] = {0, 0, 0, 0}, h[16];
-    for (int j = 0; j < 16; ++j) h[j] = 0.0f;
+    float la[4] = {0, 0, 0, 0}, h[16], hQ[4][4];
+    for (int j = 0; j < 16; ++j) { h[j] = 0.0f; hQ[j / 4][j % 4] = 0.0f; }
     NoiseCfg nc = {0, 0, 0, 0};
     float sink = 0.0f;
     for (uint32_t t = 0; t < steps; ++t) {
         float o[22], a[4], ac[4];
         if (MODE == 0 || MODE == 2) observe_head<false>(y, la, nc, 0, t, i, o);
         else { for (int j = 0; j < 22; ++j) o[j] = y[j % 17] + (float)j; }
-        if (MODE == 0 || MODE == 1) actor_step(wp, o, h, a);
-        else if (MODE == 3) {
-            f32x4 l0[4]; dense_mfma<PAIR_L0, 4, 22>(wp, o, l0);
-            float y0[16]; for (int q = 0; q < 16; ++q) y0[q] = fmaxf(l0[q / 4][q % 4], 0.0f);
-            f32x4 gi[12], gh[12];
-            dense_mfma<PAIR_GI, 12, 16>(wp, y0, gi); dense_mfma<PAIR_GH, 12, 16>(wp, h, gh);
-            for (int j = 0; j < 16; ++j) h[j] = 0.001f * (gi[j / 4][j % 4] + gh[j / 4][j % 4] + gi[4 + j / 4][j % 4] + gh[4 + j / 4][j % 4] + gi[8 + j / 4][j % 4] + gh[8 + j / 4][j % 4]);
-            f32x4 l2[1]; dense_mfma<PAIR_L2, 1, 16>(wp, h, l2);
-            for (int q = 0; q < 4; ++q) a[q] = l2[0][q];
+        if (MODE == 0 || MODE == 1) actor_step(W, o, hQ, a);
+        else if (MODE == 3) { for (int q = 0; q < 4; ++q) a[q] = o[q];
         } else if (MODE == 4) {
             for (int j = 0; j < 16; ++j) {
                 const float r = fast_sigmoid(o[j] + h[j]);
@@ -80,7 +60,7 @@ __global__ __launch_bounds__(64) void k_loop(uint32_t n, uint32_t steps, const f
     }
     float acc = sink;
     for (int j = 0; j < 17; ++j) acc += y[j];
-    for (int j = 0; j < 16; ++j) acc += h[j];
+    for (int j = 0; j < 16; ++j) acc += h[j] + hQ[j / 4][j % 4];
     out[i] = acc;
 }
 
@@ -103,11 +83,11 @@ static void run(const char* name, uint32_t n, uint32_t steps, const float* packe
 
 int main(int argc, char** argv) {
     uint32_t n = argc > 1 ? atoi(argv[1]) : 65536, steps = argc > 2 ? atoi(argv[2]) : 500;
-    std::vector<float> w(2084), packed(33 * 64);
+    std::vector<float> w(2084), packed(70 * 64);
     FILE* f = fopen("raptor_amd/data/raptor_policy.bin", "rb");
     if (!f || fread(w.data(), 4, 2084, f) != 2084) { printf("weights?\n"); return 1; }
     fclose(f);
-    pack_policy_host(w.data(), packed.data());
+    rq::pack_policy(w.data(), packed.data());
     float *dp, *dout;
     CK(hipMalloc(&dp, packed.size() * 4)); CK(hipMalloc(&dout, n * 4));
     CK(hipMemcpy(dp, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
@@ -115,7 +95,6 @@ int main(int argc, char** argv) {
     run<0>("full", n, steps, dp, dout, c);
     run<1>("actor", n, steps, dp, dout, c);
     run<2>("env", n, steps, dp, dout, c);
-    run<3>("mfma-only", n, steps, dp, dout, c);
     run<4>("gates-only", n, steps, dp, dout, c);
     return 0;
 }
