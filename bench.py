@@ -88,6 +88,21 @@ class Shard:
                             autoreset=True)
 
 
+def pmc_traffic(kernel, grid):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE
+    doubled per the gfx950 correction of MI355X_MICROARCH.md).  None when no profile covers it."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path)).get(f"{kernel}@{grid}")
+        except Exception:
+            d = None
+        if d and d.get("hbm_bytes_per_launch_corrected"):
+            return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path)}
+    return None
+
+
 def chunks(total, size):
     out = []
     while total > 0:
@@ -121,8 +136,12 @@ def kernel_probe(device, n, reps):
     ):
         us = timed(fn)
         gbps = nbytes * n / (us * 1e-6) / 1e9
-        out[name] = {"us_per_launch": round(us, 3), "bytes_per_env": nbytes, "achieved_GBps": round(gbps, 1),
-                     "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4)}
+        tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": "rq::k_actor_step",
+                          "k_step": "rq::k_step<false>"}[name], n)
+        out[name] = {"bound": "hbm", "us_per_launch": round(us, 3), "bytes_per_env": nbytes,
+                     "achieved_GBps": round(gbps, 1), "peak_GBps": PEAK_HBM_GBPS,
+                     "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                     "traffic": None if tr is None else tr["bytes_per_launch"]}
     return out
 
 
@@ -234,10 +253,12 @@ def main():
             steps_per_launch = args.steps / len(plan)
             flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
             achieved = flop_per_launch / avg_launch_s / 1e12
+            tr = pmc_traffic("rq::k_rollout_fused<false, true>", n)
             result["roofline"] = {
                 "kernel": "k_rollout_fused", "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": None,
+                "traffic": None if tr is None else tr["bytes_per_launch"],
+                "traffic_source": None if tr is None else tr["source"],
                 "note": "compute-bound: state, hidden and constants stay in VGPRs for the whole launch; "
                         f"algorithmic {FLOP_PER_ENV_STEP} FLOP/env-step (actor {FLOP_ACTOR} + gates {FLOP_GATES} + "
                         f"env {FLOP_ENV}) against the fp32 vector = f32-MFMA dense peak; HBM traffic is "
