@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--mode", default="fused", choices=["fused", "chained"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="actor operand precision: fp32 = BASELINE config 2 (headline), bf16 = config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -69,7 +71,7 @@ def parse_args():
 class Shard:
     """The l2f-shaped objects of one rank's shard."""
 
-    def __init__(self, device, n, offset, seed=0):
+    def __init__(self, device, n, offset, seed=0, precision="fp32"):
         import raptor_amd.l2f as l2f
         from raptor_amd.foundation_policy import Raptor
         self.device, self.n = device, n
@@ -80,7 +82,7 @@ class Shard:
         v.initialize_environment(device, self.env)
         v.sample_initial_parameters(device, self.env, self.params, self.rng)
         v.sample_initial_state(device, self.env, self.params, self.state, self.rng)
-        self.policy = Raptor(device)
+        self.policy = Raptor(device, precision=precision)
         self.policy.reset()
 
     def rollout(self, steps, mode):
@@ -196,7 +198,7 @@ def main():
     n = args.envs_per_gpu
     n_total = n * world
     device = l2f.Device(local_rank)
-    shard = Shard(device, n, rank * n)
+    shard = Shard(device, n, rank * n, precision=args.precision)
     returns_buf = torch.empty(n, dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def episode_exchange():
@@ -237,9 +239,10 @@ def main():
         "metric": "env-steps/sec (whole node) at 65536 quadrotors per GPU",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 6),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16 actor operands (fp32 accumulate) + f32 dynamics",
         "data": "synthetic",
-        "config": {"workload": f"{n} parallel quadrotors per GPU, fp32 RK4 dynamics + fp32 GRU actor "
+        "config": {"workload": f"{n} parallel quadrotors per GPU, fp32 RK4 dynamics + {args.precision} GRU actor "
                                f"(RAPTOR checkpoint), domain-randomised params, auto-reset, {args.mode} rollout",
                    "envs_per_gpu": n, "total_envs": n_total, "episode_length": EPISODE,
                    "parallelism": f"env-sharded x{world}, all-gather of returns per episode" if world > 1

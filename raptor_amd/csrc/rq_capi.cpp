@@ -79,7 +79,8 @@ struct rq_policy {
     rq_device* dev = nullptr;
     int ordinal = 0;
     float* w_dev = nullptr;       // raw parameters (checkpoint order)
-    float* w_packed = nullptr;    // MFMA A-operand image, rq::RQ_PACKED_FLOATS floats
+    float* w_packed = nullptr;    // f32 MFMA operand image, rq::RQ_PACKED_FLOATS floats
+    float* w_packed_bf16 = nullptr;   // bf16 MFMA operand image, rq::RQ_PACKED_BF16_FLOATS floats
     float w_host[RQ_POLICY_NUM_WEIGHTS];
     int precision = RQ_POLICY_FP32;
     uint32_t batch = 0, ld = 0;   // 0 = not sized yet
@@ -162,6 +163,10 @@ int check_env_objects(const rq_device* dev, const rq_env* env, const rq_params* 
 
 void policy_free_buffers(rq_policy* pol);
 
+const float* packed_of(const rq_policy* pol) {
+    return pol->precision == RQ_POLICY_BF16_MFMA ? pol->w_packed_bf16 : pol->w_packed;
+}
+
 // Size the per-batch buffers on first use (Raptor sizes its hidden state on the first
 // batch, README.md:24) and apply a pending reset(): h <- initial_hidden_state.
 int policy_size(rq_policy* pol, uint32_t batch) {
@@ -226,6 +231,53 @@ void pack_policy(const float* w, float* packed) {
             img(58 + r) = kT * w[BH + 32 + 4 * q + r];
             img(62 + r) = w[H0 + 4 * q + r];
             img(66 + r) = w[B2 + r];
+        }
+    }
+}
+
+
+static uint16_t to_bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Layout table: rq_device_math.hpp "bf16 operands" (enum BW_*).  A operands: element e (0..7) of lane
+// (q, i) is bf16 number e of the lane's 4 dwords (low half of dword e/2 first).
+void pack_policy_bf16(const float* w, float* packed) {
+    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, H0 = 2000, W2 = 2016, B2 = 2080 };
+    for (int i = 0; i < RQ_PACKED_BF16_FLOATS; ++i) packed[i] = 0.0f;
+    uint32_t* pu = reinterpret_cast<uint32_t*>(packed);
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, i = l & 15;
+        auto put = [&](int base, int e, float v) {      // bf16 element e of the A operand starting at image `base`
+            uint32_t& d = pu[(base + e / 2) * 64 + l];
+            const uint32_t h = to_bf16_rne(v);
+            d = (e & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
+        };
+        for (int e = 0; e < 8; ++e) {
+            const int f = 4 * e + q;
+            put(0, e, e < 6 ? (f < 22 ? w[W0 + i * 22 + f] : (f == 22 ? w[B0 + i] : 0.0f)) : 0.0f);
+            const float wi_r = e < 4 ? w[WI + (0 + i) * 16 + 4 * q + e] : w[WH + (0 + i) * 16 + 4 * q + e - 4];
+            const float wi_z = e < 4 ? w[WI + (16 + i) * 16 + 4 * q + e] : w[WH + (16 + i) * 16 + 4 * q + e - 4];
+            put(4, e, wi_r);
+            put(8, e, wi_z);
+            put(12, e, e < 4 ? w[WI + (32 + i) * 16 + 4 * q + e] : 0.0f);
+            put(16, e, e < 4 ? 0.0f : w[WH + (32 + i) * 16 + 4 * q + e - 4]);
+            for (int t = 0; t < 4; ++t)
+                put(20 + 4 * t, e, (e < 4 && (i >> 2) == t) ? w[W2 + (i & 3) * 16 + 4 * q + e] : 0.0f);
+        }
+        const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+        auto img = [&](int v) -> float& { return packed[v * 64 + l]; };
+        for (int r = 0; r < 4; ++r) {
+            img(36 + r) = kS * (w[BI + 4 * q + r] + w[BH + 4 * q + r]);
+            img(40 + r) = kS * (w[BI + 16 + 4 * q + r] + w[BH + 16 + 4 * q + r]);
+            img(44 + r) = kT * w[BI + 32 + 4 * q + r];
+            img(48 + r) = kT * w[BH + 32 + 4 * q + r];
+            img(52 + r) = w[H0 + 4 * q + r];
+            img(56 + r) = w[B2 + r];
         }
     }
 }
@@ -656,14 +708,17 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
     std::memcpy(p->w_host, weights, sizeof(p->w_host));
     hipError_t e = hipMalloc(&p->w_dev, sizeof(p->w_host));
     if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed"); }
-    std::vector<float> packed(rq::RQ_PACKED_FLOATS);
+    std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS);
     rq::pack_policy(p->w_host, packed.data());
+    rq::pack_policy_bf16(p->w_host, packed16.data());
     e = hipMalloc(&p->w_packed, packed.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p->w_packed_bf16, packed16.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(p->w_packed_bf16, packed16.data(), packed16.size() * sizeof(float), hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->w_dev, p->w_host, sizeof(p->w_host), hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->w_packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) {
-        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed); delete p;
+        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed); if (p->w_packed_bf16) (void)hipFree(p->w_packed_bf16); delete p;
         return fail(RQ_ERR_HIP, "rq_policy_create: weight upload failed");
     }
     *out = p;
@@ -676,6 +731,7 @@ RQ_API int rq_policy_destroy(rq_policy* pol) {
     policy_free_buffers(pol);
     if (pol->w_dev) (void)hipFree(pol->w_dev);
     if (pol->w_packed) (void)hipFree(pol->w_packed);
+    if (pol->w_packed_bf16) (void)hipFree(pol->w_packed_bf16);
     delete pol;
     return RQ_OK;
 }
@@ -684,8 +740,6 @@ RQ_API int rq_policy_set_precision(rq_policy* pol, int precision) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA, RQ_ERR_INVALID_ARGUMENT,
                "unknown precision");
-    RQ_REQUIRE(precision == RQ_POLICY_FP32, RQ_ERR_INVALID_ARGUMENT,
-               "RQ_POLICY_BF16_MFMA is not implemented in this build");
     pol->precision = precision;
     return RQ_OK;
 }
@@ -720,7 +774,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     }
     float* d_act = action ? pol->act : env->act;
     const uint32_t ld_act = action ? pol->ld : env->ld;
-    RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, pol->w_packed, d_obs, ld_obs, pol->hidden, pol->ld, d_act,
+    RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
                                  ld_act, nullptr, pol->precision));
     if (action) return soa_to_host(pol->dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
     return RQ_OK;
@@ -786,13 +840,13 @@ RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_s
     const bool noise = rq::noise_enabled(env->cfg);
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
-                                        params->d, state->d, policy->hidden, policy->w_dev, policy->w_packed, env->st,
+                                        params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
                                         policy->precision));
     } else {
         for (uint32_t t = 0; t < n_steps; ++t) {
             RQ_HIP(rq::launch_observe(dev->stream, b, nc, noise, rng->seed, rng->epoch + t, params->d, state->d,
                                       env->obs));
-            RQ_HIP(rq::launch_actor_step(dev->stream, env->n, policy->w_packed, env->obs, env->ld, policy->hidden,
+            RQ_HIP(rq::launch_actor_step(dev->stream, env->n, packed_of(policy), env->obs, env->ld, policy->hidden,
                                          policy->ld, env->act, env->ld, env->st.frozen, policy->precision));
             RQ_HIP(rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
                                    /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev));

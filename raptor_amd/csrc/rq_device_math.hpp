@@ -401,13 +401,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// every lane loads its slice of the packed weights; all 64 lanes must be active
-__device__ __forceinline__ void load_packed_weights(const float* __restrict__ packed, float (&W)[QW_REGS]) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int v = 0; v < QW_REGS; ++v) W[v] = packed[v * 64 + lane];
-}
-
 __device__ __forceinline__ void swap32(float& a, float& b) {   // a.lanes[32..63] <-> b.lanes[0..31]
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
@@ -425,86 +418,199 @@ __device__ __forceinline__ void transpose4(float& n0, float& n1, float& n2, floa
 
 // One recurrent step for the 64 envs of this wave.  o: native observation; hQ[t][r]: hidden state
 // in the Q layout, updated in place; a: native action.  Wave-uniform control flow required.
-__device__ __forceinline__ void actor_step(const float (&W)[QW_REGS], const float (&o)[22], float (&hQ)[4][4],
-                                           float (&a)[4]) {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    // observation -> B operands of layer_0: X[s][t] at lane (q,j) = o[4s+q] of env (t,j);
-    // input 22 is the constant 1 that carries the bias, input 23 is padding
-    float X[6][4];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int f = 4 * s + c;
-            X[s][c] = f < 22 ? o[f < 22 ? f : 21] : (f == 22 ? 1.0f : 0.0f);
-        }
-        transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
-    }
-    f32x4 y0[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0], X[0][t], zero);
-#pragma unroll
-    for (int s = 1; s < 6; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0 + s], X[s][t], y0[t]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y0[t][r] = fmaxf(y0[t][r], 0.0f);
+struct ActorF32 {
+    static constexpr int kPackedRegs = QW_REGS;
+    float W[QW_REGS];
 
-    f32x4 gr[4], gz[4], gni[4], gnh[4];
+    // every lane loads its slice of the packed image; all 64 lanes must be active
+    __device__ __forceinline__ void load(const float* __restrict__ packed) {
+        const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        gr[t] = mfma16(W[QW_GI + 0], y0[t][0], zero);
-        gz[t] = mfma16(W[QW_GI + 4], y0[t][0], zero);
-        gni[t] = mfma16(W[QW_GI + 8], y0[t][0], zero);
-        gnh[t] = mfma16(W[QW_GH + 8], hQ[t][0], zero);
+        for (int v = 0; v < QW_REGS; ++v) W[v] = packed[v * 64 + lane];
     }
+    __device__ __forceinline__ float h0(int r) const { return W[QW_H0 + r]; }
+
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // observation -> B operands of layer_0: X[s][t] at lane (q,j) = o[4s+q] of env (t,j);
+        // input 22 is the constant 1 that carries the bias, input 23 is padding
+        float X[6][4];
 #pragma unroll
-    for (int s = 1; s < 4; ++s)
+        for (int s = 0; s < 6; ++s) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int f = 4 * s + c;
+                X[s][c] = f < 22 ? o[f < 22 ? f : 21] : (f == 22 ? 1.0f : 0.0f);
+            }
+            transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
+        }
+        f32x4 y0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0], X[0][t], zero);
+#pragma unroll
+        for (int s = 1; s < 6; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0 + s], X[s][t], y0[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y0[t][r] = fmaxf(y0[t][r], 0.0f);
+
+        f32x4 gr[4], gz[4], gni[4], gnh[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            gr[t] = mfma16(W[QW_GI + 0 + s], y0[t][s], gr[t]);
-            gz[t] = mfma16(W[QW_GI + 4 + s], y0[t][s], gz[t]);
-            gni[t] = mfma16(W[QW_GI + 8 + s], y0[t][s], gni[t]);
-            gnh[t] = mfma16(W[QW_GH + 8 + s], hQ[t][s], gnh[t]);
+            gr[t] = mfma16(W[QW_GI + 0], y0[t][0], zero);
+            gz[t] = mfma16(W[QW_GI + 4], y0[t][0], zero);
+            gni[t] = mfma16(W[QW_GI + 8], y0[t][0], zero);
+            gnh[t] = mfma16(W[QW_GH + 8], hQ[t][0], zero);
         }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int s = 1; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            gr[t] = mfma16(W[QW_GH + 0 + s], hQ[t][s], gr[t]);
-            gz[t] = mfma16(W[QW_GH + 4 + s], hQ[t][s], gz[t]);
+            for (int t = 0; t < 4; ++t) {
+                gr[t] = mfma16(W[QW_GI + 0 + s], y0[t][s], gr[t]);
+                gz[t] = mfma16(W[QW_GI + 4 + s], y0[t][s], gz[t]);
+                gni[t] = mfma16(W[QW_GI + 8 + s], y0[t][s], gni[t]);
+                gnh[t] = mfma16(W[QW_GH + 8 + s], hQ[t][s], gnh[t]);
+            }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                gr[t] = mfma16(W[QW_GH + 0 + s], hQ[t][s], gr[t]);
+                gz[t] = mfma16(W[QW_GH + 4 + s], hQ[t][s], gz[t]);
+            }
+        // gates: sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2log2e)) - 1,
+        // with the pre-scaled biases b' of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each)
+        constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, W[QW_BR + r])));
+                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, W[QW_BZ + r])));
+                const float u = fmaf(rr, gnh[t][r], gni[t][r]);
+                const float v = fmaf(rr, W[QW_BNH + r], W[QW_BNI + r]);
+                const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
+                hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
+            }
+        // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
+        f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], zero);
+        f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
+        d0 = mfma16(W[QW_L2 + 8], hQ[2][0], d0);
+        d1 = mfma16(W[QW_L2 + 12], hQ[3][0], d1);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) {
+            d0 = mfma16(W[QW_L2 + 0 + s], hQ[0][s], d0);
+            d1 = mfma16(W[QW_L2 + 4 + s], hQ[1][s], d1);
+            d0 = mfma16(W[QW_L2 + 8 + s], hQ[2][s], d0);
+            d1 = mfma16(W[QW_L2 + 12 + s], hQ[3][s], d1);
         }
-    // gates: sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2log2e)) - 1,
-    // with the pre-scaled biases b' of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each)
-    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, W[QW_BR + r])));
-            const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, W[QW_BZ + r])));
-            const float u = fmaf(rr, gnh[t][r], gni[t][r]);
-            const float v = fmaf(rr, W[QW_BNH + r], W[QW_BNI + r]);
-            const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
-            hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
-        }
-    // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
-    f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], zero);
-    f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
-    d0 = mfma16(W[QW_L2 + 8], hQ[2][0], d0);
-    d1 = mfma16(W[QW_L2 + 12], hQ[3][0], d1);
-#pragma unroll
-    for (int s = 1; s < 4; ++s) {
-        d0 = mfma16(W[QW_L2 + 0 + s], hQ[0][s], d0);
-        d1 = mfma16(W[QW_L2 + 4 + s], hQ[1][s], d1);
-        d0 = mfma16(W[QW_L2 + 8 + s], hQ[2][s], d0);
-        d1 = mfma16(W[QW_L2 + 12 + s], hQ[3][s], d1);
+        for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + W[QW_B2 + r];
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + W[QW_B2 + r];
+};
+
+
+// ---- bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 gates (BASELINE config 5) -----
+// Same Q layout and the same register-stationary scheme; K = 32 per instruction and lane-group q
+// supplies k-slots e = 0..7 (hardware pairing A(q,e) <-> B(q,e), checked in tools/bf16test.hip):
+//   layer_0 : slots e < 6 of lane-group q carry observation feature 4e+q (22 -> the bias constant 1,
+//             23 and e = 6,7 -> 0): ONE MFMA per 16-env tile;
+//   GRU     : slots e < 4 carry y0[4q+e], e >= 4 carry h[4q+e-4]: r and z gates are ONE MFMA each
+//             ([W_i | W_h] against [y0 ; h]), the n gate needs gi_n and gh_n apart: two MFMAs whose A
+//             has the other half zeroed;
+//   layer_2 : slots e < 4 carry h[4q+e]; the four tiles accumulate into one D (native layout).
+// 4 + 16 + 4 = 24 MFMAs per wave-step instead of 136.  Operands are rounded to bf16 (RNE) by
+// v_cvt_pk_bf16_f32; products are exact in fp32 and accumulation is fp32.
+enum {
+    BW_L0 = 0, BW_R = 4, BW_Z = 8, BW_NI = 12, BW_NH = 16, BW_L2 = 20,   // bf16x8 A operands, 4 dwords each
+    BW_BR = 36, BW_BZ = 40, BW_BNI = 44, BW_BNH = 48, BW_H0 = 52, BW_B2 = 56,   // fp32, as in the f32 image
+    BW_REGS = 60
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t dwordx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(float f0, float f1, float f2, float f3, float f4, float f5,
+                                              float f6, float f7) {
+    bf16x8 v;
+    v[0] = (__bf16)f0; v[1] = (__bf16)f1; v[2] = (__bf16)f2; v[3] = (__bf16)f3;
+    v[4] = (__bf16)f4; v[5] = (__bf16)f5; v[6] = (__bf16)f6; v[7] = (__bf16)f7;
+    return v;
 }
+
+struct ActorBF16 {
+    static constexpr int kPackedRegs = BW_REGS;
+    uint32_t A[36];
+    float B[24];
+
+    __device__ __forceinline__ void load(const float* __restrict__ packed) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t* pu = reinterpret_cast<const uint32_t*>(packed);
+#pragma unroll
+        for (int v = 0; v < 36; ++v) A[v] = pu[v * 64 + lane];
+#pragma unroll
+        for (int v = 0; v < 24; ++v) B[v] = packed[(36 + v) * 64 + lane];
+    }
+    __device__ __forceinline__ float h0(int r) const { return B[BW_H0 - 36 + r]; }
+    __device__ __forceinline__ bf16x8 a_op(int base) const {
+        const dwordx4 u = {A[base], A[base + 1], A[base + 2], A[base + 3]};
+        return __builtin_bit_cast(bf16x8, u);
+    }
+    static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        float X[6][4];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int f = 4 * s + c;
+                X[s][c] = f < 22 ? o[f < 22 ? f : 21] : (f == 22 ? 1.0f : 0.0f);
+            }
+            transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
+        }
+        const bf16x8 wl0 = a_op(BW_L0), wr = a_op(BW_R), wz = a_op(BW_Z), wni = a_op(BW_NI), wnh = a_op(BW_NH);
+        f32x4 y0[4], gr[4], gz[4], gni[4], gnh[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            y0[t] = mfma(wl0, pack_bf16x8(X[0][t], X[1][t], X[2][t], X[3][t], X[4][t], X[5][t], 0.f, 0.f), zero);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 xh = pack_bf16x8(fmaxf(y0[t][0], 0.f), fmaxf(y0[t][1], 0.f), fmaxf(y0[t][2], 0.f),
+                                          fmaxf(y0[t][3], 0.f), hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3]);
+            gr[t] = mfma(wr, xh, zero);
+            gz[t] = mfma(wz, xh, zero);
+            gni[t] = mfma(wni, xh, zero);
+            gnh[t] = mfma(wnh, xh, zero);
+        }
+        constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, B[BW_BR - 36 + r])));
+                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, B[BW_BZ - 36 + r])));
+                const float u = fmaf(rr, gnh[t][r], gni[t][r]);
+                const float v = fmaf(rr, B[BW_BNH - 36 + r], B[BW_BNI - 36 + r]);
+                const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
+                hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
+            }
+        f32x4 d0 = zero, d1 = zero;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 hb = pack_bf16x8(hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3], 0.f, 0.f, 0.f, 0.f);
+            if (t & 1) d1 = mfma(a_op(BW_L2 + 4 * t), hb, d1);
+            else       d0 = mfma(a_op(BW_L2 + 4 * t), hb, d0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + B[BW_B2 - 36 + r];
+    }
+};
 
 // Q-layout addressing helpers for a wave whose first env is wave_base: tile t of lane (q,j) is
 // env wave_base + 16 t + j (clamped to the batch), hidden feature 4q + r.

@@ -81,13 +81,14 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 // wave-uniform control flow with all 64 lanes holding valid data: lanes past the end of the
 // batch (and frozen envs) compute on a clamped index and only their STORES are predicated —
 // no lane leaves early.
+template <typename ACTOR>
 __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen) {
-    float W[QW_REGS];
-    load_packed_weights(packed, W);
+    ACTOR actor;
+    actor.load(packed);
     const uint32_t i0 = env_index();
     const uint32_t wave_base = i0 & ~63u;
     const uint32_t i = i0 < n ? i0 : n - 1;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* 
 #pragma unroll
     for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
     load_hidden_q(hidden, ld_h, wave_base, n, hQ);
-    actor_step(W, x, hQ, a);
+    actor.step(x, hQ, a);
     store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
     if (commit) {
 #pragma unroll
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // Control flow is wave-uniform around the MFMAs (see k_actor_step): lanes past the end of the
 // batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
 // the rare auto-reset branch (no MFMA inside) diverges.
-template <bool NOISE, bool AUTORESET>
+template <bool NOISE, bool AUTORESET, typename ACTOR>
 __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
                                                                uint64_t seed, uint32_t epoch0, uint32_t n_steps,
                                                                const float* __restrict__ params,
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
                                                                float* __restrict__ hidden,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ packed, StatsPtrs st) {
-    float W[QW_REGS];
-    load_packed_weights(packed, W);
+    ACTOR actor;
+    actor.load(packed);
     const uint32_t i0 = env_index();
     const uint32_t wave_base = i0 & ~63u;
     const uint32_t i = i0 < b.n ? i0 : b.n - 1;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h0Q[t][r] = W[QW_H0 + r];
+        for (int r = 0; r < 4; ++r) h0Q[t][r] = actor.h0(r);
     Stats s = load_stats(st, i);
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     float last_r = st.last_reward[i];
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
-        actor_step(W, o, hn, a);
+        actor.step(o, hn, a);
         if (AUTORESET) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
@@ -317,8 +318,10 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
                              int precision) {
     if (n == 0) return hipSuccess;
-    (void)precision;
-    k_actor_step<<<grid_for(n, kBlock), kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+    if (precision == RQ_POLICY_BF16_MFMA)
+        k_actor_step<ActorBF16><<<grid_for(n, kBlock), kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+    else
+        k_actor_step<ActorF32><<<grid_for(n, kBlock), kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
     return hipGetLastError();
 }
 
@@ -340,13 +343,18 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 const float* params, float* state, float* hidden, const float* weights,
                                 const float* packed, StatsPtrs st, int precision) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
-    (void)precision;
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
-#define RQ_LAUNCH_FUSED(NZ, AR) \
-    k_rollout_fused<NZ, AR><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st)
-    if (noise) { if (ar) RQ_LAUNCH_FUSED(true, true); else RQ_LAUNCH_FUSED(true, false); }
-    else       { if (ar) RQ_LAUNCH_FUSED(false, true); else RQ_LAUNCH_FUSED(false, false); }
+#define RQ_LAUNCH_FUSED(NZ, AR, ACT) \
+    k_rollout_fused<NZ, AR, ACT><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st)
+#define RQ_LAUNCH_FUSED_ACT(ACT)                                                          \
+    do {                                                                                  \
+        if (noise) { if (ar) RQ_LAUNCH_FUSED(true, true, ACT); else RQ_LAUNCH_FUSED(true, false, ACT); }   \
+        else       { if (ar) RQ_LAUNCH_FUSED(false, true, ACT); else RQ_LAUNCH_FUSED(false, false, ACT); } \
+    } while (0)
+    if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_ACT(ActorBF16);
+    else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
+#undef RQ_LAUNCH_FUSED_ACT
 #undef RQ_LAUNCH_FUSED
     return hipGetLastError();
 }

@@ -88,8 +88,10 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 const float* packed, StatsPtrs st, int precision);
 // Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
 // v_mfma_f32_16x16x4_f32 instructions read as A / C operands (layout: rq_device_math.hpp "actor").
-enum { RQ_PACKED_REGS = 70, RQ_PACKED_FLOATS = 70 * 64 };
+enum { RQ_PACKED_REGS = 70, RQ_PACKED_FLOATS = 70 * 64, RQ_PACKED_BF16_REGS = 60, RQ_PACKED_BF16_FLOATS = 60 * 64 };
 void pack_policy(const float* weights, float* packed);
+// the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
+void pack_policy_bf16(const float* weights, float* packed);
 
 // out[i] = value for i < count (uint32 / float / uint8 fills on the stream)
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, uint32_t count);

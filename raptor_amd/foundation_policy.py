@@ -42,8 +42,18 @@ def _get_default_device():
     return _default_device
 
 
+PRECISIONS = {"fp32": _lib.POLICY_FP32, "bf16": _lib.POLICY_BF16_MFMA}
+
+
 class Raptor:
-    def __init__(self, device=None, weights=None):
+    """``precision``: "fp32" (exact-f32 MFMA, matches the reference KATs to < 1e-5) or "bf16"
+    (BASELINE config 5: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates;
+    ~2e-2 max abs action deviation on the KATs)."""
+
+    def __init__(self, device=None, weights=None, precision="fp32"):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self._precision = precision
         self._weights = load_weights() if weights is None else np.ascontiguousarray(weights, np.float32)
         if self._weights.size != POLICY_NUM_WEIGHTS:
             raise ValueError(f"expected {POLICY_NUM_WEIGHTS} weights")
@@ -60,6 +70,7 @@ class Raptor:
             _lib.call("rq_policy_create", self._device._h, _lib.fptr(self._weights), self._weights.size, C.byref(h))
             self._h = h
             self._fin = weakref.finalize(self, _lib.load().rq_policy_destroy, h)
+            _lib.call("rq_policy_set_precision", h, PRECISIONS[self._precision])
         elif device is not None and device is not self._device:
             raise _lib.RaptorQuadError(-5, "policy was created on another device")
         return self._h
@@ -67,6 +78,17 @@ class Raptor:
     @property
     def weights(self):
         return self._weights
+
+    @property
+    def precision(self):
+        return self._precision
+
+    def set_precision(self, precision):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self._precision = precision
+        if self._h is not None:
+            _lib.call("rq_policy_set_precision", self._h, PRECISIONS[precision])
 
     def reset(self):
         """README.md:21,94 — hidden state <- initial_hidden_state (checkpoint.h:123, zeros)."""

@@ -120,6 +120,94 @@ def test_actor_batch_change_requires_reset(device):
     assert pol.evaluate_step(np.zeros((5, 22), np.float32)).shape == (5, 4)
 
 
+# ------------------------------------------------------------------------------ bf16 actor --
+BF16_KAT_TOL = 5e-2     # abs on raw actions: bf16 operands (8-bit mantissa), fp32 accumulate (numpy model: 1.9e-2)
+
+
+def _bf16(x):
+    """round-to-nearest-even fp32 -> bf16 -> fp32 (numpy)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def _actor_bf16_model(w, x, h):
+    """The bf16 kernel's arithmetic in numpy: operands rounded to bf16, fp32 accumulate, fp32 gates."""
+    W0, b0 = w[0:352].reshape(16, 22), w[352:368]
+    Wi, Wh = w[368:1136].reshape(48, 16), w[1136:1904].reshape(48, 16)
+    bi, bh, W2, b2 = w[1904:1952], w[1952:2000], w[2016:2080].reshape(4, 16), w[2080:2084]
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    y0 = np.maximum(_bf16(x[:, :22]) @ _bf16(W0).T + _bf16(b0), 0).astype(np.float32)
+    gi, gh = _bf16(y0) @ _bf16(Wi).T, _bf16(h) @ _bf16(Wh).T
+    r = sig(gi[:, :16] + gh[:, :16] + bi[:16] + bh[:16])
+    z = sig(gi[:, 16:32] + gh[:, 16:32] + bi[16:32] + bh[16:32])
+    n = np.tanh(gi[:, 32:] + bi[32:] + r * (gh[:, 32:] + bh[32:]))
+    hn = ((1 - z) * n + z * h).astype(np.float32)
+    return (_bf16(hn) @ _bf16(W2).T + b2).astype(np.float32), hn
+
+
+def test_bf16_actor_against_kats_and_bf16_model(device, weights, kat):
+    """BASELINE config 5: bf16 operands on the MFMA.  Against the reference KATs within the bf16
+    tolerance, and within fp32 round-off of a numpy model of the same bf16-operand arithmetic."""
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    pol = Raptor(device, precision="bf16")
+    err = pol.selftest(x, y, tolerance=BF16_KAT_TOL)
+    assert 1e-4 < err < BF16_KAT_TOL       # really bf16 (not silently fp32), and within tolerance
+    pol.reset()
+    h = np.zeros((2, 16), np.float32)
+    worst = 0.0
+    for t in range(200):
+        a = pol.evaluate_step(x[t])
+        ref, h = _actor_bf16_model(weights, x[t], h)
+        worst = max(worst, np.abs(a - ref).max())
+        h = pol.hidden_state(2)             # teacher-force the model with the kernel's hidden state
+    assert worst < 2e-3, worst              # rounding-boundary flips of individual bf16 operands only
+
+
+def test_bf16_closed_loop_action_deviation(device, oracle):
+    """Config 5 report: along an fp32 closed-loop trajectory of 4 096 domain-randomised quadrotors,
+    the bf16 actor (own hidden state, same observations) deviates from the fp32 actor by a bounded
+    amount, and flying the bf16 policy itself keeps the fleet as stable as the fp32 one."""
+    from raptor_amd.foundation_policy import Raptor
+    w = World(device, oracle, 4096, seed=31)
+    p16 = Raptor(device, precision="bf16")
+    p16.reset(); w.policy.reset()
+    obs = np.zeros((4096, 26), np.float32)
+    devs = []
+    for t in range(500):
+        w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+        a32 = w.policy.evaluate_step(obs[:, :22])
+        a16 = p16.evaluate_step(obs[:, :22])
+        devs.append(np.abs(a16 - a32).max(axis=1))
+        w.vector.step(device, w.env, w.params, w.state, a32, w.state, w.rng)
+    devs = np.array(devs)
+    calm = np.abs(w.state.numpy()[:, :3]).max(axis=1) < 1.0
+    print(f"bf16 vs fp32 action deviation over 500 closed-loop steps: max {devs[:, calm].max():.4f} "
+          f"mean {devs[:, calm].mean():.5f}")
+    assert devs[:, calm].mean() < 1e-2 and np.quantile(devs[:, calm], 0.999) < 0.1
+    # and the bf16 policy in the loop (fused rollout)
+    b = World(device, oracle, 4096, seed=31)
+    b.policy.set_precision("bf16")
+    b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 500, "fused", False)
+    f = World(device, oracle, 4096, seed=31)
+    f.vector.rollout(device, f.env, f.params, f.state, f.policy, f.rng, 500, "fused", False)
+    t16, t32 = b.env.finished_terminated().mean(), f.env.finished_terminated().mean()
+    assert abs(t16 - t32) < 0.02 and t16 < 0.07
+    r16, r32 = b.env.finished_returns().mean(), f.env.finished_returns().mean()
+    assert abs(r16 - r32) / r32 < 0.02
+
+
+def test_bf16_fused_equals_chained(device, oracle):
+    a = World(device, oracle, 300, seed=8, episode_step_limit=40)
+    b = World(device, oracle, 300, seed=8, episode_step_limit=40)
+    a.policy.set_precision("bf16"); b.policy.set_precision("bf16")
+    a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 100, "fused", True)
+    b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 100, "chained", True)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(300), b.policy.hidden_state(300))
+
+
 # ------------------------------------------------------------------------------ sampling ---
 @pytest.mark.parametrize("dr", [0, 1])
 def test_sample_initial_parameters_bit_exact(device, oracle, dr):

@@ -3,10 +3,11 @@
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 // MODE bit0: MFMA 4x4x1 stream (16 per iter), bit1: VALU fma stream (NV per iter), bit2: use 16x16x4 instead (4 per iter = same flops as 16 4x4x1)
-// bit3: transcendental stream (8 exp per iter)
+// bit3: transcendental stream (8 exp per iter); bit4: bf16 16x16x32 MFMA stream (4 per iter)
 template <int MODE, int NV>
 __global__ __launch_bounds__(256) void k(int iters, const float* __restrict__ in, float* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -25,6 +26,12 @@ __global__ __launch_bounds__(256) void k(int iters, const float* __restrict__ in
         if (MODE & 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+        if (MODE & 16) {
+            bf16x8 av, bv;
+            for (int q = 0; q < 8; ++q) { av[q] = (__bf16)a; bv[q] = (__bf16)b; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i], 0, 0, 0);
         }
         if (MODE & 2) {
 #pragma unroll
@@ -61,7 +68,7 @@ int main() {
     float *in, *out; CK(hipMalloc(&in, 4096)); CK(hipMalloc(&out, 4 * 256 * 2048));
     CK(hipMemset(in, 0, 4096));
     const int it = 20000;
-    for (int blocks : {256, 512, 1024}) {
+    for (int blocks : {256, 512}) {
         run<1, 0>("mfma4x4x1 x16", blocks, it, in, out);
         run<4, 0>("mfma16x16x4 x4", blocks, it, in, out);
         run<2, 32>("valu fma x32", blocks, it, in, out);
@@ -72,6 +79,10 @@ int main() {
         run<8, 0>("exp x8", blocks, it, in, out);
         run<9, 0>("mfma4x4x1 x16 + exp x8", blocks, it, in, out);
         run<10, 32>("fma x32 + exp x8", blocks, it, in, out);
+        run<16, 0>("bf16 16x16x32 x4", blocks, it, in, out);
+        run<18, 64>("bf16 16x16x32 x4 + fma x64", blocks, it, in, out);
+        run<18, 32>("bf16 16x16x32 x4 + fma x32", blocks, it, in, out);
+        run<24, 0>("bf16 16x16x32 x4 + exp x8", blocks, it, in, out);
     }
     return 0;
 }
