@@ -190,7 +190,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -226,7 +226,7 @@ def main():
     for c in plan:
         shard.rollout(c, args.mode)
     kernel_ms = device.timer_stop()          # HIP events on the kernels' stream (also drains it)
-    gathered = episode_exchange() if world > 1 else None
+    gathered = episode_exchange() if dist is not None else None
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:

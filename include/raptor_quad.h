@@ -284,6 +284,25 @@ enum rq_rollout_flags {
 RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,
                rq_policy* policy, rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags);
 
+/* ---- Trajectory buffer: what a learner's data collection consumes (SURVEY.md section 8(f) row 1;
+ * the reference's post_training collects ~77.7 k transitions per epoch, README.md:208).  A rollout
+ * that records appends one entry per step and env: the 22 policy inputs, the raw action, the
+ * reward and a done code (0 running, 1 terminated, 2 step limit reached, 4 env frozen = not
+ * stepped; for code 4 the other fields are unspecified).  Device layout is step-major and
+ * field-major inside a step (coalesced stores); rq_trajectory_get returns the learner layout
+ * obs [T, N, 22], act [T, N, 4], rew [T, N], done [T, N]. */
+typedef struct rq_trajectory rq_trajectory;
+RQ_API int rq_trajectory_create(rq_env* env, uint32_t capacity_steps, rq_trajectory** out);
+RQ_API int rq_trajectory_destroy(rq_trajectory* t);
+RQ_API int rq_trajectory_reset(rq_trajectory* t);
+RQ_API int rq_trajectory_length(const rq_trajectory* t, uint32_t* steps, uint32_t* capacity);
+RQ_API int rq_trajectory_get(const rq_trajectory* t, float* obs, float* act, float* rew, uint8_t* done);
+RQ_API int rq_trajectory_device_ptrs(const rq_trajectory* t, float** obs, float** act, float** rew,
+                              uint8_t** done, uint32_t* ld);
+RQ_API int rq_rollout_record(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,
+                      rq_policy* policy, rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags,
+                      rq_trajectory* trajectory);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,5 +197,26 @@ def rollout(cfg, weights, seed, epoch0, env_offset, params, state, hidden, n_ste
                       C.c_int(nthreads))
 
 
+def rollout_record(cfg, weights, seed, epoch0, env_offset, params, state, hidden, n_steps, flags, st,
+                   nthreads=1):
+    """As ``rollout`` and returns the trajectory dict(obs [T,n,22], act [T,n,4], rew [T,n], done [T,n])."""
+    w, wp = _f(weights)
+    p, pp = _f(params)
+    n = p.shape[0]
+    tr = dict(obs=np.zeros((n_steps, n, 22), np.float32), act=np.zeros((n_steps, n, 4), np.float32),
+              rew=np.zeros((n_steps, n), np.float32), done=np.zeros((n_steps, n), np.uint8))
+    lib().orc_rollout_record(C.byref(cfg), wp, C.c_uint64(seed), C.c_uint32(epoch0), C.c_uint64(env_offset),
+                             C.c_uint32(n), pp, _p(state, C.c_float), _p(hidden, C.c_float),
+                             C.c_uint32(n_steps), C.c_uint32(flags),
+                             _p(st.returns, C.c_float), _p(st.steps, C.c_uint32),
+                             _p(st.fin_returns, C.c_float), _p(st.fin_lengths, C.c_uint32),
+                             _p(st.fin_counts, C.c_uint32), _p(st.fin_terminated, C.c_uint32),
+                             _p(st.frozen, C.c_uint8), _p(st.episode, C.c_uint32),
+                             _p(st.last_reward, C.c_float), _p(st.last_terminated, C.c_uint8),
+                             C.c_int(nthreads), _p(tr["obs"], C.c_float), _p(tr["act"], C.c_float),
+                             _p(tr["rew"], C.c_float), _p(tr["done"], C.c_uint8))
+    return tr
+
+
 def max_threads():
     return int(lib().orc_max_threads())

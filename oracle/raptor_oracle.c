@@ -501,14 +501,17 @@ ORC_EXPORT void orc_stats_update(const rq_env_config* c, uint32_t n, const float
 
 /* ---------------------------------------------------------------- rollout -------------- */
 /* K iterations of README.md:96-99 (observe -> evaluate_step -> step -> assign) per env,
- * observation noise epoch = epoch0 + k.  flags & 1: auto-reset (see raptor_quad.h). */
-ORC_EXPORT void orc_rollout(const rq_env_config* c, const float* w, uint64_t seed, uint32_t epoch0,
-                            uint64_t env_offset, uint32_t n, const float* params, float* state,
-                            float* hidden, uint32_t K, uint32_t flags,
-                            float* returns, uint32_t* steps, float* fin_returns, uint32_t* fin_lengths,
-                            uint32_t* fin_counts, uint32_t* fin_terminated, uint8_t* frozen,
-                            uint32_t* episode, float* last_reward, uint8_t* last_terminated,
-                            int nthreads) {
+ * observation noise epoch = epoch0 + k.  flags & 1: auto-reset (see raptor_quad.h).
+ * Optional trajectory (any pointer may be NULL): obs [K][n][22], act [K][n][4] (raw actor output),
+ * rew [K][n], done [K][n] with codes 0 running, 1 terminated, 2 step limit, 4 frozen (not stepped). */
+ORC_EXPORT void orc_rollout_record(const rq_env_config* c, const float* w, uint64_t seed, uint32_t epoch0,
+                                   uint64_t env_offset, uint32_t n, const float* params, float* state,
+                                   float* hidden, uint32_t K, uint32_t flags,
+                                   float* returns, uint32_t* steps, float* fin_returns, uint32_t* fin_lengths,
+                                   uint32_t* fin_counts, uint32_t* fin_terminated, uint8_t* frozen,
+                                   uint32_t* episode, float* last_reward, uint8_t* last_terminated,
+                                   int nthreads, float* traj_obs, float* traj_act, float* traj_rew,
+                                   uint8_t* traj_done) {
     orc_stats st = {returns, steps, fin_returns, fin_lengths, fin_counts, fin_terminated, frozen, episode};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -521,13 +524,22 @@ ORC_EXPORT void orc_rollout(const rq_env_config* c, const float* w, uint64_t see
         float* h = hidden + (size_t)i * 16;
         float obs[RQ_OBSERVATION_DIM], act[4];
         for (uint32_t k = 0; k < K; ++k) {
-            if (st.frozen[i]) break;
+            const size_t slot = (size_t)k * n + i;
+            if (st.frozen[i]) {
+                if (traj_done) traj_done[slot] = 4;
+                continue;
+            }
             observe_one(c, seed, epoch0 + k, env_offset + i, p, s, obs);
             orc_actor_step(w, obs, h, act);
             float r; uint8_t t;
             step_one(c, p, s, act, s, &r, &t);
             last_reward[i] = r; last_terminated[i] = t;
-            if (stats_update(c, i, r, t, &st)) {
+            const int ended = stats_update(c, i, r, t, &st);
+            if (traj_obs) memcpy(traj_obs + slot * 22, obs, 22 * sizeof(float));
+            if (traj_act) memcpy(traj_act + slot * 4, act, 4 * sizeof(float));
+            if (traj_rew) traj_rew[slot] = r;
+            if (traj_done) traj_done[slot] = t ? 1 : (ended ? 2 : 0);
+            if (ended) {
                 if (flags & 1u) {
                     sample_state_one(c, seed, st.episode[i], env_offset + i, p, s);
                     st.episode[i] += 1;
@@ -538,6 +550,18 @@ ORC_EXPORT void orc_rollout(const rq_env_config* c, const float* w, uint64_t see
             }
         }
     }
+}
+
+ORC_EXPORT void orc_rollout(const rq_env_config* c, const float* w, uint64_t seed, uint32_t epoch0,
+                            uint64_t env_offset, uint32_t n, const float* params, float* state,
+                            float* hidden, uint32_t K, uint32_t flags,
+                            float* returns, uint32_t* steps, float* fin_returns, uint32_t* fin_lengths,
+                            uint32_t* fin_counts, uint32_t* fin_terminated, uint8_t* frozen,
+                            uint32_t* episode, float* last_reward, uint8_t* last_terminated,
+                            int nthreads) {
+    orc_rollout_record(c, w, seed, epoch0, env_offset, n, params, state, hidden, K, flags, returns, steps,
+                       fin_returns, fin_lengths, fin_counts, fin_terminated, frozen, episode, last_reward,
+                       last_terminated, nthreads, 0, 0, 0, 0);
 }
 
 ORC_EXPORT int orc_max_threads(void) {

@@ -126,6 +126,13 @@ _SIGNATURES = {
     "rq_policy_set_hidden": [_vp, _fp, C.c_uint32],
     "rq_policy_selftest": [_vp, _fp, _fp, C.c_uint32, C.c_uint32, C.c_float, _fp],
     "rq_rollout": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32],
+    "rq_trajectory_create": [_vp, C.c_uint32, C.POINTER(_vp)],
+    "rq_trajectory_destroy": [_vp],
+    "rq_trajectory_reset": [_vp],
+    "rq_trajectory_length": [_vp, _u32p, _u32p],
+    "rq_trajectory_get": [_vp, _fp, _fp, _fp, _u8p],
+    "rq_trajectory_device_ptrs": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u32p],
+    "rq_rollout_record": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32, _vp],
 }
 _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 

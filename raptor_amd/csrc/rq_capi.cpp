@@ -75,6 +75,16 @@ struct rq_env {
 struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
 struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
 
+struct rq_trajectory {
+    rq_env* env = nullptr;
+    int ordinal = 0;
+    uint32_t capacity = 0, length = 0;
+    float* obs = nullptr;    // [capacity][22][ld]
+    float* act = nullptr;    // [capacity][4][ld]
+    float* rew = nullptr;    // [capacity][ld]
+    uint8_t* done = nullptr; // [capacity][ld]
+};
+
 struct rq_policy {
     rq_device* dev = nullptr;
     int ordinal = 0;
@@ -447,8 +457,8 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
     RQ_REQUIRE(e, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     e->dev = dev; e->ordinal = dev->ordinal; e->n = n_envs; e->ld = round_up64(n_envs); e->offset = global_env_offset;
     const size_t ld = e->ld;
-    // one block for all statistics: 8 x 4-byte arrays + 2 x 1-byte arrays
-    const size_t stats_bytes = ld * (8 * 4 + 2 * 1);
+    // one block for all statistics: 8 x 4-byte arrays + 3 x 1-byte arrays
+    const size_t stats_bytes = ld * (8 * 4 + 3 * 1);
     hipError_t e1 = hipMalloc(&e->obs, (size_t)RQ_OBSERVATION_DIM * ld * sizeof(float));
     hipError_t e2 = hipMalloc(&e->act, (size_t)RQ_ACTION_DIM * ld * sizeof(float));
     hipError_t e3 = hipMalloc(&e->stats_block, stats_bytes);
@@ -470,6 +480,7 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
     e->st.episode = (uint32_t*)(b + 7 * 4 * ld);
     e->st.last_terminated = (uint8_t*)(b + 8 * 4 * ld);
     e->st.frozen = (uint8_t*)(b + 8 * 4 * ld + ld);
+    e->st.last_done = (uint8_t*)(b + 8 * 4 * ld + 2 * ld);
     hipError_t m1 = hipMemsetAsync(e->stats_block, 0, stats_bytes, dev->stream);
     hipError_t m2 = hipMemsetAsync(e->obs, 0, (size_t)RQ_OBSERVATION_DIM * ld * sizeof(float), dev->stream);
     hipError_t m3 = hipMemsetAsync(e->act, 0, (size_t)RQ_ACTION_DIM * ld * sizeof(float), dev->stream);
@@ -691,7 +702,7 @@ RQ_API int rq_env_reset_statistics(rq_env* env) {
     const size_t ld = env->ld;
     // everything except the per-env episode counters (they key the initial-state RNG)
     RQ_HIP(hipMemsetAsync(env->stats_block, 0, 7 * 4 * ld, env->dev->stream));
-    RQ_HIP(hipMemsetAsync(env->st.last_terminated, 0, 2 * ld, env->dev->stream));
+    RQ_HIP(hipMemsetAsync(env->st.last_terminated, 0, 3 * ld, env->dev->stream));
     return RQ_OK;
 }
 
@@ -822,14 +833,21 @@ RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* e
 }
 
 // ---------------------------------------------------------------------------- Rollout ---
-RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
-               rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags) {
+static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
+                        rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags, rq_trajectory* traj) {
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
     RQ_REQUIRE(params && state && policy && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(policy->dev == dev, RQ_ERR_SHAPE_MISMATCH, "policy lives on another device");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
     RQ_REQUIRE(mode == RQ_ROLLOUT_FUSED || mode == RQ_ROLLOUT_CHAINED, RQ_ERR_INVALID_ARGUMENT, "unknown mode");
     RQ_REQUIRE((flags & ~(uint32_t)RQ_ROLLOUT_AUTORESET) == 0, RQ_ERR_INVALID_ARGUMENT, "unknown flags");
+    rq::TrajPtrs tp{nullptr, nullptr, nullptr, nullptr, 0};
+    if (traj) {
+        RQ_REQUIRE(traj->env == env, RQ_ERR_SHAPE_MISMATCH, "trajectory belongs to another env");
+        RQ_REQUIRE((uint64_t)traj->length + n_steps <= traj->capacity, RQ_ERR_INVALID_ARGUMENT,
+                   "trajectory buffer too small for this rollout");
+        tp = {traj->obs, traj->act, traj->rew, traj->done, traj->length};
+    }
     rc = set_device(dev); if (rc) return rc;
     rc = policy_size(policy, env->n); if (rc) return rc;
     RQ_REQUIRE(policy->ld == env->ld, RQ_ERR_SHAPE_MISMATCH, "policy batch does not match the env");
@@ -838,10 +856,12 @@ RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_s
     const rq::NoiseCfg nc = rq::noise_cfg(env->cfg);
     const rq::SampleCfg smp = rq::sample_cfg(env->cfg);
     const bool noise = rq::noise_enabled(env->cfg);
+    if (traj && n_steps)   // steps a frozen wave never reaches read as "not stepped"
+        RQ_HIP(hipMemsetAsync(traj->done + (size_t)traj->length * env->ld, 4, (size_t)n_steps * env->ld, dev->stream));
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
-                                        policy->precision));
+                                        policy->precision, tp));
     } else {
         for (uint32_t t = 0; t < n_steps; ++t) {
             RQ_HIP(rq::launch_observe(dev->stream, b, nc, noise, rng->seed, rng->epoch + t, params->d, state->d,
@@ -850,9 +870,104 @@ RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_s
                                          policy->ld, env->act, env->ld, env->st.frozen, policy->precision));
             RQ_HIP(rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
                                    /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev));
+            if (traj) {
+                rq::TrajPtrs tt = tp; tt.t0 = tp.t0 + t;
+                RQ_HIP(rq::launch_record(dev->stream, b, env->obs, env->act, env->st, tt));
+            }
         }
     }
     rng->epoch += n_steps;
+    if (traj) traj->length += n_steps;
+    return RQ_OK;
+}
+
+RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
+               rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags) {
+    return rollout_impl(dev, env, params, state, policy, rng, n_steps, mode, flags, nullptr);
+}
+
+RQ_API int rq_rollout_record(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
+                      rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags, rq_trajectory* trajectory) {
+    RQ_REQUIRE(trajectory, RQ_ERR_INVALID_ARGUMENT, "null trajectory");
+    return rollout_impl(dev, env, params, state, policy, rng, n_steps, mode, flags, trajectory);
+}
+
+// ---------------------------------------------------------------------------- Trajectory
+RQ_API int rq_trajectory_create(rq_env* env, uint32_t capacity_steps, rq_trajectory** out) {
+    RQ_REQUIRE(env && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(capacity_steps > 0, RQ_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    *out = nullptr;
+    int rc = set_device(env->dev); if (rc) return rc;
+    rq_trajectory* t = new (std::nothrow) rq_trajectory();
+    RQ_REQUIRE(t, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    t->env = env; t->ordinal = env->ordinal; t->capacity = capacity_steps;
+    const size_t per = (size_t)capacity_steps * env->ld;
+    hipError_t e1 = hipMalloc(&t->obs, per * RQ_POLICY_INPUT_DIM * sizeof(float));
+    hipError_t e2 = hipMalloc(&t->act, per * RQ_ACTION_DIM * sizeof(float));
+    hipError_t e3 = hipMalloc(&t->rew, per * sizeof(float));
+    hipError_t e4 = hipMalloc(&t->done, per);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        rq_trajectory_destroy(t);
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_trajectory_create: device allocation failed");
+    }
+    *out = t;
+    return RQ_OK;
+}
+
+RQ_API int rq_trajectory_destroy(rq_trajectory* t) {
+    if (!t) return RQ_OK;
+    (void)hipSetDevice(t->ordinal);
+    if (t->obs) (void)hipFree(t->obs);
+    if (t->act) (void)hipFree(t->act);
+    if (t->rew) (void)hipFree(t->rew);
+    if (t->done) (void)hipFree(t->done);
+    delete t;
+    return RQ_OK;
+}
+
+RQ_API int rq_trajectory_reset(rq_trajectory* t) {
+    RQ_REQUIRE(t, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    t->length = 0;
+    return RQ_OK;
+}
+
+RQ_API int rq_trajectory_length(const rq_trajectory* t, uint32_t* steps, uint32_t* capacity) {
+    RQ_REQUIRE(t, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (steps) *steps = t->length;
+    if (capacity) *capacity = t->capacity;
+    return RQ_OK;
+}
+
+RQ_API int rq_trajectory_device_ptrs(const rq_trajectory* t, float** obs, float** act, float** rew, uint8_t** done,
+                              uint32_t* ld) {
+    RQ_REQUIRE(t, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (obs) *obs = t->obs;
+    if (act) *act = t->act;
+    if (rew) *rew = t->rew;
+    if (done) *done = t->done;
+    if (ld) *ld = t->env->ld;
+    return RQ_OK;
+}
+
+// host copies, learner layout: obs [T, N, 22], act [T, N, 4], rew [T, N], done [T, N]; any pointer may be NULL
+RQ_API int rq_trajectory_get(const rq_trajectory* t, float* obs, float* act, float* rew, uint8_t* done) {
+    RQ_REQUIRE(t, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    rq_env* env = t->env;
+    rq_device* dev = env->dev;
+    const uint32_t n = env->n, ld = env->ld;
+    for (uint32_t s = 0; s < t->length; ++s) {
+        int rc;
+        if (obs) { rc = soa_to_host(dev, t->obs + (size_t)s * RQ_POLICY_INPUT_DIM * ld, n, ld, RQ_POLICY_INPUT_DIM,
+                                    obs + (size_t)s * n * RQ_POLICY_INPUT_DIM); if (rc) return rc; }
+        if (act) { rc = soa_to_host(dev, t->act + (size_t)s * RQ_ACTION_DIM * ld, n, ld, RQ_ACTION_DIM,
+                                    act + (size_t)s * n * RQ_ACTION_DIM); if (rc) return rc; }
+        if (rew) { rc = soa_to_host(dev, t->rew + (size_t)s * ld, n, ld, 1, rew + (size_t)s * n); if (rc) return rc; }
+    }
+    if (done) {
+        int rc = set_device(dev); if (rc) return rc;
+        RQ_HIP(hipMemcpy2DAsync(done, n, t->done, ld, n, t->length, hipMemcpyDeviceToHost, dev->stream));
+        RQ_HIP(hipStreamSynchronize(dev->stream));
+    }
     return RQ_OK;
 }
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
                                                  const float* __restrict__ weights) {
     const uint32_t i = env_index();
     if (i >= b.n) return;
-    if (ROLLOUT && st.frozen[i]) return;
+    if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
     float y[17], f6[6], a[4], ac[4];
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
     const bool ended = stats_update(c.episode_step_limit, r, term, s);
     st.last_reward[i] = r;
     st.last_terminated[i] = term ? 1 : 0;
+    st.last_done[i] = term ? 1 : (ended ? 2 : 0);
     store_stats(st, i, s, ended);
     bool write_dist = (next_state != state);
     if (ROLLOUT && ended) {
@@ -177,14 +178,15 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // Control flow is wave-uniform around the MFMAs (see k_actor_step): lanes past the end of the
 // batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
 // the rare auto-reset branch (no MFMA inside) diverges.
-template <bool NOISE, bool AUTORESET, typename ACTOR>
+template <bool NOISE, bool AUTORESET, bool RECORD, typename ACTOR>
 __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
                                                                uint64_t seed, uint32_t epoch0, uint32_t n_steps,
                                                                const float* __restrict__ params,
                                                                float* __restrict__ state,
                                                                float* __restrict__ hidden,
                                                                const float* __restrict__ w,
-                                                               const float* __restrict__ packed, StatsPtrs st) {
+                                                               const float* __restrict__ packed, StatsPtrs st,
+                                                               TrajPtrs traj) {
     ACTOR actor;
     actor.load(packed);
     const uint32_t i0 = env_index();
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     float last_r = st.last_reward[i];
     bool last_t = st.last_terminated[i] != 0;
+    uint8_t last_d = st.last_done[i];
     const bool was_frozen = st.frozen[i] != 0;
     bool frozen = was_frozen, any_end = false, dist_changed = false;
     uint32_t ep = AUTORESET ? st.episode[i] : 0u;
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
         bool term;
         const float r = step_inplace(c, k, ds, yn, a, ac, term);
         bool ended = false;
+        uint8_t done_code = 4;          // frozen: computed on a scratch copy, not committed
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
 #pragma unroll
             for (int j = 0; j < 17; ++j) y[j] = yn[j];
@@ -247,6 +251,8 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
             for (int j = 0; j < 4; ++j) la[j] = ac[j];
             last_r = r; last_t = term;
             ended = stats_update(c.episode_step_limit, r, term, s);
+            done_code = term ? 1 : (ended ? 2 : 0);
+            last_d = done_code;
             if (ended) {
                 any_end = true;
                 if (AUTORESET) {
@@ -260,6 +266,15 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
                     frozen = true;
                 }
             }
+        }
+        if (RECORD && valid) {   // one coalesced 256-byte store per field per wave
+            const size_t tt = traj.t0 + t;
+#pragma unroll
+            for (int j = 0; j < 22; ++j) traj.obs[(tt * 22 + j) * ld + i] = o[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) traj.act[(tt * 4 + j) * ld + i] = a[j];
+            traj.rew[tt * ld + i] = r;
+            traj.done[tt * ld + i] = done_code;
         }
         if (AUTORESET) {   // policy reset of the envs whose episode ended: h <- initial_hidden_state
             const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
         store_stats(st, i, s, any_end);
         st.last_reward[i] = last_r;
         st.last_terminated[i] = last_t ? 1 : 0;
+        st.last_done[i] = last_d;
         if (AUTORESET) st.episode[i] = ep;
         if (frozen) st.frozen[i] = 1;
     }
@@ -341,21 +357,44 @@ hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, c
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                const float* packed, StatsPtrs st, int precision) {
+                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
-#define RQ_LAUNCH_FUSED(NZ, AR, ACT) \
-    k_rollout_fused<NZ, AR, ACT><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st)
+#define RQ_LAUNCH_FUSED(NZ, AR, RC, ACT) \
+    k_rollout_fused<NZ, AR, RC, ACT><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj)
+#define RQ_LAUNCH_FUSED_RC(NZ, AR, ACT) \
+    do { if (rec) RQ_LAUNCH_FUSED(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED(NZ, AR, false, ACT); } while (0)
 #define RQ_LAUNCH_FUSED_ACT(ACT)                                                          \
     do {                                                                                  \
-        if (noise) { if (ar) RQ_LAUNCH_FUSED(true, true, ACT); else RQ_LAUNCH_FUSED(true, false, ACT); }   \
-        else       { if (ar) RQ_LAUNCH_FUSED(false, true, ACT); else RQ_LAUNCH_FUSED(false, false, ACT); } \
+        if (noise) { if (ar) RQ_LAUNCH_FUSED_RC(true, true, ACT); else RQ_LAUNCH_FUSED_RC(true, false, ACT); }   \
+        else       { if (ar) RQ_LAUNCH_FUSED_RC(false, true, ACT); else RQ_LAUNCH_FUSED_RC(false, false, ACT); } \
     } while (0)
+    const bool rec = traj.obs != nullptr;
     if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_ACT(ActorBF16);
     else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
+#undef RQ_LAUNCH_FUSED_RC
 #undef RQ_LAUNCH_FUSED_ACT
 #undef RQ_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void k_record(Batch b, const float* __restrict__ obs,
+                                                   const float* __restrict__ act, StatsPtrs st, TrajPtrs traj) {
+    const uint32_t i = env_index();
+    if (i >= b.n) return;
+    const size_t ld = b.ld, tt = traj.t0;
+#pragma unroll
+    for (int j = 0; j < 22; ++j) traj.obs[(tt * 22 + j) * ld + i] = obs[(size_t)j * ld + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) traj.act[(tt * 4 + j) * ld + i] = act[(size_t)j * ld + i];
+    traj.rew[tt * ld + i] = st.last_reward[i];
+    traj.done[tt * ld + i] = st.last_done[i];
+}
+
+hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* act, StatsPtrs st, TrajPtrs traj) {
+    if (b.n == 0) return hipSuccess;
+    k_record<<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, obs, act, st, traj);
     return hipGetLastError();
 }
 

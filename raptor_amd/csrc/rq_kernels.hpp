@@ -55,6 +55,14 @@ struct StatsPtrs {
     float* fin_returns; uint32_t* fin_lengths; uint32_t* fin_counts; uint32_t* fin_terminated;
     float* last_reward; uint8_t* last_terminated;
     uint8_t* frozen; uint32_t* episode;
+    uint8_t* last_done;   // per transition: 0 running, 1 terminated, 2 step limit reached, 4 env frozen (not stepped)
+};
+
+// Trajectory buffer of a rollout: step-major, field-major within a step,
+//   obs [T][22][ld], act [T][4][ld] (raw actor output), rew [T][ld], done [T][ld] (codes of last_done).
+struct TrajPtrs {
+    float* obs; float* act; float* rew; uint8_t* done;
+    uint32_t t0;          // index of the first step this launch writes
 };
 
 struct Batch {           // which envs a launch covers
@@ -85,7 +93,9 @@ hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, c
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                const float* packed, StatsPtrs st, int precision);
+                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj);
+// chained mode: copy step t (env obs/action buffers + last reward / done code) into the trajectory
+hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* act, StatsPtrs st, TrajPtrs traj);
 // Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
 // v_mfma_f32_16x16x4_f32 instructions read as A / C operands (layout: rq_device_math.hpp "actor").
 enum { RQ_PACKED_REGS = 70, RQ_PACKED_FLOATS = 70 * 64, RQ_PACKED_BF16_REGS = 60, RQ_PACKED_BF16_FLOATS = 60 * 64 };

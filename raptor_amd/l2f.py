@@ -259,6 +259,37 @@ class VectorModule:
                     c.assign(self)
                 return c
 
+        class Trajectory(_Handle):
+            """Rollout recording buffer: ``vector.rollout(..., trajectory=t)``
+            appends per step and env the 22 policy inputs, the raw action, the reward and a done
+            code (0 running, 1 terminated, 2 step limit, 4 frozen/not stepped)."""
+            _destroy = "rq_trajectory_destroy"
+
+            def __init__(self, env, capacity_steps):
+                super().__init__()
+                h = C.c_void_p()
+                _lib.call("rq_trajectory_create", env._require("environment"), int(capacity_steps), C.byref(h))
+                self._adopt(h)
+                self._env = env
+
+            def __len__(self):
+                n = C.c_uint32()
+                _lib.call("rq_trajectory_length", self._h, C.byref(n), None)
+                return n.value
+
+            def reset(self):
+                _lib.call("rq_trajectory_reset", self._h)
+
+            def numpy(self):
+                """-> dict(obs [T,N,22], act [T,N,4], rew [T,N], done [T,N] uint8)"""
+                T, N = len(self), mod.N_ENVIRONMENTS
+                out = dict(obs=np.empty((T, N, 22), np.float32), act=np.empty((T, N, 4), np.float32),
+                           rew=np.empty((T, N), np.float32), done=np.empty((T, N), np.uint8))
+                _lib.call("rq_trajectory_get", self._h, _lib.fptr(out["obs"]), _lib.fptr(out["act"]),
+                          _lib.fptr(out["rew"]), out["done"].ctypes.data_as(C.POINTER(C.c_uint8)))
+                return out
+
+        self.Trajectory = Trajectory
         self.VectorRng = VectorRng
         self.VectorEnvironment = VectorEnvironment
         self.VectorParameters = VectorParameters
@@ -316,12 +347,18 @@ class VectorModule:
         _lib.call("rq_step", device._h, env._require("environment"), params._require("VectorParameters"),
                   state._require("VectorState"), None, next_state._ensure(env), rng._require("rng"), None)
 
-    def rollout(self, device, env, params, state, policy, rng, n_steps, mode="fused", autoreset=False):
-        """The loop body README.md:95-99, ``n_steps`` times, entirely on the device."""
+    def rollout(self, device, env, params, state, policy, rng, n_steps, mode="fused", autoreset=False,
+                trajectory=None):
+        """The loop body README.md:95-99, ``n_steps`` times, entirely on the device; with
+        ``trajectory`` every transition is also appended to that buffer."""
         m = {"fused": ROLLOUT_FUSED, "chained": ROLLOUT_CHAINED}[mode]
-        _lib.call("rq_rollout", device._h, env._require("environment"), params._require("VectorParameters"),
-                  state._require("VectorState"), policy._handle(device), rng._require("rng"), int(n_steps), m,
-                  ROLLOUT_AUTORESET if autoreset else 0)
+        args = (device._h, env._require("environment"), params._require("VectorParameters"),
+                state._require("VectorState"), policy._handle(device), rng._require("rng"), int(n_steps), m,
+                ROLLOUT_AUTORESET if autoreset else 0)
+        if trajectory is None:
+            _lib.call("rq_rollout", *args)
+        else:
+            _lib.call("rq_rollout_record", *args, trajectory._require("trajectory"))
 
 
 _modules = {}

@@ -471,6 +471,50 @@ def _lib_set_epoch(w, epoch):
     _lib.call("rq_rng_set_epoch", w.rng._h, epoch)
 
 
+# ------------------------------------------------------------------------------ trajectory -
+@pytest.mark.parametrize("autoreset", [False, True])
+def test_trajectory_fused_equals_chained(device, oracle, autoreset):
+    kw = dict(seed=14, episode_step_limit=30, noise_position=0.01)
+    a, b = World(device, oracle, 200, **kw), World(device, oracle, 200, **kw)
+    ta, tb = a.vector.Trajectory(a.env, 80), b.vector.Trajectory(b.env, 80)
+    for chunk in (50, 30):
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", autoreset, trajectory=ta)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", autoreset, trajectory=tb)
+    A, B = ta.numpy(), tb.numpy()
+    assert len(ta) == len(tb) == 80 and A["obs"].shape == (80, 200, 22)
+    assert np.array_equal(A["done"], B["done"])
+    live = A["done"] != 4
+    for k in ("obs", "act", "rew"):
+        assert np.array_equal(A[k][live], B[k][live]), k
+    if autoreset:
+        assert live.all() and (A["done"] == 2).sum() >= 2 * 200 - (A["done"] == 1).sum() * 2 - 200
+    else:
+        assert (A["done"][40:] == 4).all()          # every env ended by step 30 and froze
+        assert ((A["done"] == 1) | (A["done"] == 2)).sum() == 200
+    with pytest.raises(Exception):                   # capacity exhausted
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 1, "fused", autoreset, trajectory=ta)
+
+
+def test_trajectory_vs_oracle(device, oracle, weights):
+    """Recorded transitions against the oracle's, teacher-forced start, 3 steps, auto-reset with a
+    2-step episode limit so that the reset path is inside the window."""
+    w = World(device, oracle, 512, seed=15, episode_step_limit=2)
+    w.sync_oracle_to_gpu_state()
+    tr = w.vector.Trajectory(w.env, 3)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 3, "fused", True, trajectory=tr)
+    ref = oracle.rollout_record(w.cfg, weights, 15, 0, 0, w.P, w.S, w.H, 3, 1, w.st, 4)
+    G = tr.numpy()
+    assert np.array_equal(G["done"], ref["done"]) and (G["done"][1] >= 1).all()
+    assert np.array_equal(G["obs"][0], ref["obs"][0])                 # same state in -> same bits out
+    assert np.abs(G["act"][0] - ref["act"][0]).max() < ACTOR_TOL
+    assert np.abs(G["rew"] - ref["rew"]).max() < 1e-4
+    assert np.abs(G["obs"][1] - ref["obs"][1]).max() < 1e-4
+    # step 2 observes the freshly re-sampled state (episode 2): independent of the actor
+    assert np.abs(G["obs"][2][:, :3] - ref["obs"][2][:, :3]).max() == 0.0
+    assert np.abs(G["obs"][2] - ref["obs"][2]).max() < INIT_TOL * 4
+    assert np.abs(w.state.numpy()[:, :13] - w.S[:, :13]).max() < 1e-4
+
+
 # ------------------------------------------------------------------------------ scale ------
 def test_sharding_invariance_and_determinism_at_full_size(device, oracle):
     """65 536 envs (BASELINE config 2): one batch == two half batches with global offsets,
