@@ -539,6 +539,65 @@ def test_sharding_invariance_and_determinism_at_full_size(device, oracle):
     assert (Sf[:, 13:17] >= P[:, 22:23]).all() and (Sf[:, 13:17] <= P[:, 23:24]).all()
 
 
+def test_config3_262144_envs_domain_randomised(device, oracle):
+    """BASELINE config 3: 262 144 envs with per-env randomised mass / inertia / thrust parameters.
+    Parameters bit-exact vs the oracle at full size; rollout checked through size-independent
+    properties and a strided sample of envs two steps ahead of the oracle."""
+    n = 262144
+    w = World(device, oracle, n, seed=41)
+    P = w.params.numpy()
+    assert np.array_equal(P, w.P)
+    assert len(np.unique(P[:, 0])) > 0.9 * n                      # every env its own quadrotor
+    w.sync_oracle_to_gpu_state()
+    idx = np.arange(0, n, 509)
+    Ps, Ss, Hs = np.ascontiguousarray(w.P[idx]), np.ascontiguousarray(w.S[idx]), np.zeros((len(idx), 16), np.float32)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 2, "fused", True)
+    G = w.state.numpy()
+    # the oracle on the sampled envs (RNG keyed per env: run them one by one with their global ids)
+    st = oracle.Stats(1)
+    worst = 0.0
+    for k in range(0, len(idx), 8):
+        i = int(idx[k])
+        s1, h1 = Ss[k:k + 1].copy(), Hs[k:k + 1].copy()
+        st = oracle.Stats(1); st.episode[:] = 1
+        oracle.rollout(w.cfg, w.policy.weights, 41, 0, i, Ps[k:k + 1], s1, h1, 2, 1, st, 1)
+        worst = max(worst, (np.abs(G[i, :17] - s1[0, :17]) / np.maximum(np.abs(s1[0, :17]), 1.0)).max())
+    assert worst < 1e-4, worst
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 498, "fused", True)
+    G = w.state.numpy()
+    assert np.isfinite(G).all()
+    assert np.abs(np.linalg.norm(G[:, 3:7], axis=1) - 1).max() < 1e-5
+    assert (G[:, 13:17] >= P[:, 22:23]).all() and (G[:, 13:17] <= P[:, 23:24]).all()
+    assert (w.env.finished_counts() >= 1).all() and w.env.finished_terminated().sum() / w.env.finished_counts().sum() < 0.07
+
+
+def test_config4_shard_of_2097152_equals_slice_of_full_batch(device, oracle):
+    """BASELINE config 4: 2 097 152 envs sharded 8 x 262 144.  On one GPU: the shard a rank would
+    own (global ids 3*262144 ...) must equal the same slice of the unsharded 2 097 152-env batch,
+    bit for bit, and the all-gather layout (contiguous by global id) is what raptor_amd.distributed
+    assumes."""
+    from raptor_amd.distributed import shard_range
+    total, world, rank = 2097152, 8, 3
+    start, count = shard_range(total, world, rank)
+    assert (start, count) == (3 * 262144, 262144)
+    full = World.__new__(World)
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+
+    def make(n, offset):
+        v = l2f.VectorModule(n, offset)
+        rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+        v.initialize_rng(device, rng, 77); v.initialize_environment(device, env)
+        v.sample_initial_parameters(device, env, params, rng); v.sample_initial_state(device, env, params, state, rng)
+        pol = Raptor(device)
+        v.rollout(device, env, params, state, pol, rng, 60, "fused", True)
+        return state.numpy(), env.returns(), env.finished_counts()
+    S_full, R_full, C_full = make(total, 0)
+    S_sh, R_sh, C_sh = make(count, start)
+    assert np.array_equal(S_full[start:start + count], S_sh)
+    assert np.array_equal(R_full[start:start + count], R_sh) and np.array_equal(C_full[start:start + count], C_sh)
+
+
 def test_policy_stabilises_gpu_simulation(device, oracle):
     """The functional pin of the conventions, on the HIP path itself."""
     w = World(device, oracle, 4096, seed=5, termination_enabled=1)
