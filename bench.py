@@ -50,6 +50,7 @@ BYTES_STEP = 4 * (21 + 17 + 6 + 4 + 2) + 4 * (17 + 4) + 4 + 1 + 8   # params, st
 # fused kernel, per env per launch (K steps): params 21 + state 27 + hidden 16 + stats in; state 21 + hidden 16 + stats out
 BYTES_FUSED_LAUNCH = 4 * (21 + 27 + 16 + 8) + 4 * (21 + 16 + 8)
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak = f32 MFMA peak (dense)
+PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak
 PEAK_HBM_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -144,6 +145,43 @@ def kernel_probe(device, n, reps):
                      "achieved_GBps": round(gbps, 1), "peak_GBps": PEAK_HBM_GBPS,
                      "frac": round(gbps / PEAK_HBM_GBPS, 4),
                      "traffic": None if tr is None else tr["bytes_per_launch"]}
+    return out
+
+
+def api_loop_probe(device):
+    """BASELINE config 1 shape: the README loop (README.md:94-99) at N = 8, 500 steps, NumPy arrays
+    crossing the boundary every call (host-bound by construction), and the same loop kept on the
+    device.  Reported as microseconds per loop iteration."""
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+    vector = l2f.vector8
+    rng, env = vector.VectorRng(), vector.VectorEnvironment()
+    params, state, next_state = vector.VectorParameters(), vector.VectorState(), vector.VectorState()
+    vector.initialize_rng(device, rng, 0)
+    vector.initialize_environment(device, env)
+    vector.sample_initial_parameters(device, env, params, rng)
+    vector.sample_initial_state(device, env, params, state, rng)
+    policy = Raptor(device)
+    observation = np.zeros((env.N_ENVIRONMENTS, env.OBSERVATION_DIM), dtype=np.float32)
+    out = {}
+    for name in ("numpy_arrays", "device_resident"):
+        policy.reset()
+        t0 = None
+        for it in range(550):
+            if it == 50:
+                device.synchronize()
+                t0 = time.perf_counter()
+            if name == "numpy_arrays":
+                vector.observe(device, env, params, state, observation, rng)
+                action = policy.evaluate_step(observation[:, :22])
+                vector.step(device, env, params, state, action, next_state, rng)
+                state.assign(next_state)
+            else:
+                vector.observe(device, env, params, state, None, rng)
+                policy.evaluate_step_device(env)
+                vector.step_device(device, env, params, state, state, rng)
+        device.synchronize()
+        out[name + "_us_per_iteration"] = round((time.perf_counter() - t0) / 500 * 1e6, 2)
     return out
 
 
@@ -252,11 +290,26 @@ def main():
     if rank == 0:
         launches = len(plan) if args.mode == "fused" else 3 * args.steps
         avg_launch_s = kernel_ms * 1e-3 / len(plan)      # per rollout call
-        if args.mode == "fused":
+        if args.mode == "fused" and args.precision == "bf16":
+            # config 5: the contractions run on the bf16 XDL pipe (24 MFMAs per wave-step, a few % of its
+            # peak); what bounds the kernel is the fp32 VALU work that remains (gates + env)
+            steps_per_launch = args.steps / len(plan)
+            valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
+            mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
+            tr = pmc_traffic("rq::k_rollout_fused<false, true, false, rq::ActorBF16>", n)
+            result["roofline"] = {
+                "kernel": "k_rollout_fused<ActorBF16>", "bound": "mfma", "achieved": round(valu, 3),
+                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
+                "traffic": None if tr is None else tr["bytes_per_launch"],
+                "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
+                        f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the bf16 MFMA pipe at "
+                        f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak",
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches}
+        elif args.mode == "fused":
             steps_per_launch = args.steps / len(plan)
             flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
             achieved = flop_per_launch / avg_launch_s / 1e12
-            tr = pmc_traffic("rq::k_rollout_fused<false, true>", n)
+            tr = pmc_traffic("rq::k_rollout_fused<false, true, false, rq::ActorF32>", n)
             result["roofline"] = {
                 "kernel": "k_rollout_fused", "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
@@ -279,6 +332,7 @@ def main():
         if world == 1 and not args.no_kernel_probe:
             result["kernels"] = {"n65536": kernel_probe(device, ENVS_PER_GPU, 200),
                                  "n2097152": kernel_probe(device, 2097152, 20)}
+            result["readme_loop_n8"] = api_loop_probe(device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if gathered is not None:

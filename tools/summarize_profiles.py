@@ -14,7 +14,17 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    """kernel name without its argument list (template arguments kept)"""
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            name = name[:i]
+            break
+    return name.replace("void ", "").strip()
 
 
 # 1. kernel stats of the bench command
