@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the quadrotor rollout path on MI355X.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 1 --steps 2000 --warmup 500
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -58,7 +58,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--mode", default="fused", choices=["fused", "chained"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
