@@ -47,8 +47,12 @@ struct rq_device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    void* staging = nullptr;       // pinned host buffer for transposing copies
+    void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
     size_t staging_bytes = 0;
+    void* staging_in = nullptr;    // pinned host buffer for host -> device copies (asynchronous)
+    size_t staging_in_bytes = 0;
+    hipEvent_t ev_h2d = nullptr;   // recorded after the last copy out of staging_in
+    bool h2d_pending = false;
 };
 
 struct rq_rng {
@@ -131,22 +135,29 @@ int soa_to_host(rq_device* dev, const float* d_soa, uint32_t n, uint32_t ld, uin
     return RQ_OK;
 }
 
-// host row-major [n][stride] (first dim columns) -> device SoA [dim][ld]; padding lanes zeroed
+// host row-major [n][stride] (first dim columns) -> device SoA [dim][ld]; padding lanes zeroed.
+// Asynchronous on the device stream: the pinned staging buffer is only waited for when it is
+// about to be overwritten, so a host->device hand-over costs no stream synchronisation.
 int host_to_soa(rq_device* dev, const float* host, uint32_t n, uint32_t stride, uint32_t ld, uint32_t dim,
                 float* d_soa) {
     int rc = set_device(dev); if (rc) return rc;
     const size_t bytes = (size_t)dim * ld * sizeof(float);
-    rc = ensure_staging(dev, bytes); if (rc) return rc;
-    // the previous async copy out of the staging buffer must have completed
-    RQ_HIP(hipStreamSynchronize(dev->stream));
-    float* s = static_cast<float*>(dev->staging);
+    if (dev->h2d_pending) { RQ_HIP(hipEventSynchronize(dev->ev_h2d)); dev->h2d_pending = false; }
+    if (dev->staging_in_bytes < bytes) {
+        if (dev->staging_in) { RQ_HIP(hipHostFree(dev->staging_in)); dev->staging_in = nullptr; dev->staging_in_bytes = 0; }
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        RQ_HIP(hipHostMalloc(&dev->staging_in, want, hipHostMallocDefault));
+        dev->staging_in_bytes = want;
+    }
+    float* s = static_cast<float*>(dev->staging_in);
     for (uint32_t f = 0; f < dim; ++f) {
         float* col = s + (size_t)f * ld;
         for (uint32_t i = 0; i < n; ++i) col[i] = host[(size_t)i * stride + f];
         for (uint32_t i = n; i < ld; ++i) col[i] = 0.0f;
     }
-    RQ_HIP(hipMemcpyAsync(d_soa, dev->staging, bytes, hipMemcpyHostToDevice, dev->stream));
-    RQ_HIP(hipStreamSynchronize(dev->stream));
+    RQ_HIP(hipMemcpyAsync(d_soa, dev->staging_in, bytes, hipMemcpyHostToDevice, dev->stream));
+    RQ_HIP(hipEventRecord(dev->ev_h2d, dev->stream));
+    dev->h2d_pending = true;
     return RQ_OK;
 }
 
@@ -339,6 +350,7 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     hipError_t e1 = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&d->ev_start);
     hipError_t e3 = hipEventCreate(&d->ev_stop);
+    if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&d->ev_h2d, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         delete d;
         return fail(RQ_ERR_HIP, "rq_device_create: stream/event creation failed");
@@ -353,7 +365,9 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->stream) { (void)hipStreamSynchronize(dev->stream); (void)hipStreamDestroy(dev->stream); }
     if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
+    if (dev->ev_h2d) (void)hipEventDestroy(dev->ev_h2d);
     if (dev->staging) (void)hipHostFree(dev->staging);
+    if (dev->staging_in) (void)hipHostFree(dev->staging_in);
     delete dev;
     return RQ_OK;
 }

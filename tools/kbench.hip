@@ -18,8 +18,8 @@ namespace rq { void pack_policy(const float* w, float* packed); }
 template <int MODE>
 __global__ __launch_bounds__(64) void k_loop(uint32_t n, uint32_t steps, const float* __restrict__ packed,
                                              float* __restrict__ out, StepCfg c) {
-    float W[QW_REGS];
-    load_packed_weights(packed, W);
+    ActorF32 actor;
+    actor.load(packed);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const float fi = (float)(i & 1023) * 1e-3f;
     EnvConsts k;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void k_loop(uint32_t n, uint32_t steps, const f
         float o[22], a[4], ac[4];
         if (MODE == 0 || MODE == 2) observe_head<false>(y, la, nc, 0, t, i, o);
         else { for (int j = 0; j < 22; ++j) o[j] = y[j % 17] + (float)j; }
-        if (MODE == 0 || MODE == 1) actor_step(W, o, hQ, a);
+        if (MODE == 0 || MODE == 1) actor.step(o, hQ, a);
         else if (MODE == 3) { for (int q = 0; q < 4; ++q) a[q] = o[q];
         } else if (MODE == 4) {
             for (int j = 0; j < 16; ++j) {
