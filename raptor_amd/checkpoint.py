@@ -1,0 +1,97 @@
+"""Reading policies in the reference's C++ export format (`checkpoint.h`, SURVEY.md §5 "checkpoint /
+resume"; the HDF5 twin needs an HDF5 reader and is not supported yet).
+
+rl-tools writes every parameter as
+    namespace <path> { ... alignas(float) const unsigned char memory[] = {b0, b1, ...}; ... }
+(little-endian float32 bytes, row-major; `checkpoint.h:1,39,50,75,...`).  ``load_checkpoint_header``
+parses such a file supplied by the user and returns the flat parameter vector this engine takes
+(order: W0[16,22] b0[16] Wi[48,16] Wh[48,16] bi[48] bh[48] h0[16] W2[4,16] b2[4]) plus, when present,
+the embedded known-answer example (input [T,B,22], output [T,B,4]) for ``Raptor.selftest``.
+Only the Dense(22->16, ReLU) -> GRU(16) -> Dense(16->4) topology of the RAPTOR policy is accepted.
+"""
+import re
+
+import numpy as np
+
+_LAYOUT = [
+    ("actor/layer_0/weights", 16 * 22),
+    ("actor/layer_0/biases", 16),
+    ("actor/layer_1/weights_input", 48 * 16),
+    ("actor/layer_1/weights_hidden", 48 * 16),
+    ("actor/layer_1/biases_input", 48),
+    ("actor/layer_1/biases_hidden", 48),
+    ("actor/layer_1/initial_hidden_state", 16),
+    ("actor/layer_2/weights", 4 * 16),
+    ("actor/layer_2/biases", 4),
+]
+
+
+def parse_blobs(text):
+    """{namespace path: float32 array} for every byte-array blob of a checkpoint header."""
+    blobs, stack = {}, []
+    ns = re.compile(r"^\s*namespace\s+([\w:]+)\s*\{\s*$")
+    for line in text.split("\n"):
+        m = ns.match(line)
+        if m:
+            stack.append(m.group(1).replace("rl_tools::checkpoint::", "").replace("::", "/"))
+        elif line.strip() == "}":
+            if stack:
+                stack.pop()
+        elif "const unsigned char memory[]" in line:
+            body = line[line.index("{") + 1: line.rindex("}")]
+            raw = np.array([int(t) for t in body.split(",")], dtype=np.uint8)
+            if raw.size % 4:
+                raise ValueError("blob size is not a multiple of 4 bytes")
+            blobs["/".join(s for s in stack if s != "parameters_memory")] = raw.view("<f4").astype(np.float32)
+    return blobs
+
+
+def load_checkpoint_header(path):
+    """-> (weights float32 [2084], example or None) with example = (input [T,B,22], output [T,B,4])."""
+    blobs = parse_blobs(open(path).read())
+    parts = []
+    for name, size in _LAYOUT:
+        if name not in blobs:
+            raise ValueError(f"{path}: parameter '{name}' not found (not a RAPTOR-topology actor export?)")
+        if blobs[name].size != size:
+            raise ValueError(f"{path}: '{name}' has {blobs[name].size} values, expected {size}")
+        parts.append(blobs[name])
+    weights = np.concatenate(parts).astype(np.float32)
+    example = None
+    if "example/input" in blobs and "example/output" in blobs:
+        x, y = blobs["example/input"], blobs["example/output"]
+        m = re.search(r"example::input.*?Shape<[^,]+,\s*(\d+),\s*(\d+),\s*(\d+)>", open(path).read(), re.S)
+        if m and int(m.group(3)) == 22:
+            T, B = int(m.group(1)), int(m.group(2))
+            if x.size == T * B * 22 and y.size == T * B * 4:
+                example = (x.reshape(T, B, 22), y.reshape(T, B, 4))
+    return weights, example
+
+
+def write_checkpoint_header(path, weights, example=None):
+    """Inverse of ``load_checkpoint_header`` for this topology: the byte-array blobs in the same
+    namespaces (without the rl-tools type aliases, which need the rl-tools headers to mean anything)."""
+    w = np.ascontiguousarray(weights, "<f4")
+    if w.size != sum(s for _, s in _LAYOUT):
+        raise ValueError("expected 2084 parameters")
+
+    def blob(ns_path, arr):
+        parts = ns_path.split("/")
+        head = "namespace rl_tools::checkpoint::" + parts[0] + " {\n"
+        for p in parts[1:]:
+            head += "namespace " + p + " {\n"
+        body = "alignas(float) const unsigned char memory[] = {" + ", ".join(str(b) for b in arr.tobytes()) + "};\n"
+        return head + "namespace parameters_memory {\n" + body + "}\n" + "}\n" * len(parts)
+
+    out, off = ["// NOTE: little-endian float32 byte arrays, row-major (out, in)\n"], 0
+    for name, size in _LAYOUT:
+        out.append(blob(name, w[off:off + size]))
+        off += size
+    if example is not None:
+        x, y = (np.ascontiguousarray(a, "<f4") for a in example)
+        T, B = x.shape[0], x.shape[1]
+        for nm, arr, d in (("input", x, 22), ("output", y, 4)):
+            out.append(f"namespace rl_tools::checkpoint::example::{nm} {{\n"
+                       "alignas(float) const unsigned char memory[] = {" + ", ".join(str(b) for b in arr.tobytes()) + "};\n"
+                       f"using SHAPE = rl_tools::tensor::Shape<unsigned long, {T}, {B}, {d}>;\n}}\n")
+    open(path, "w").write("".join(out))

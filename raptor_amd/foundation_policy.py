@@ -60,6 +60,17 @@ class Raptor:
         self._device = device
         self._h = None
         self._fin = None
+        self.example = None
+
+    @classmethod
+    def from_checkpoint(cls, path, device=None, precision="fp32"):
+        """Load a policy exported by rl-tools as C++ code (``checkpoint.h`` format, same topology).
+        The embedded known-answer example, if any, is kept as ``policy.example``."""
+        from .checkpoint import load_checkpoint_header
+        weights, example = load_checkpoint_header(path)
+        pol = cls(device=device, weights=weights, precision=precision)
+        pol.example = example
+        return pol
 
     # the C object is created on first use so that ``Raptor()`` itself needs no device argument
     def _handle(self, device=None):

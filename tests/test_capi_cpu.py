@@ -99,3 +99,19 @@ def test_vector_module_surface():
     assert l2f.vector(65536).N_ENVIRONMENTS == 65536
     from raptor_amd.foundation_policy import Raptor
     assert hasattr(Raptor, "reset") and hasattr(Raptor, "evaluate_step")
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/raptor_quad.h compiles as C11 (no C++ in the boundary) and a plain-C program written
+    against it links with libraptor_quad.so."""
+    import subprocess
+    pkg = os.path.join(ROOT, "raptor_amd")
+    exe = str(tmp_path / "readme_loop")
+    r = subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "readme_loop.c"),
+                        "-L" + pkg, "-lraptor_quad", "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if not HAS_GPU:
+        run = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
+        assert run.returncode == 1 and "no HIP device" in run.stderr      # loud, not a crash

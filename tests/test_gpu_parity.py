@@ -609,6 +609,34 @@ def test_policy_stabilises_gpu_simulation(device, oracle):
     assert np.median(np.linalg.norm(S[term == 0, :3], axis=1)) < 0.1
 
 
+def test_c_example_runs_on_the_gpu(tmp_path):
+    """examples/readme_loop.c: the README loop through the C ABI from plain C."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "raptor_amd")
+    exe = str(tmp_path / "readme_loop")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "readme_loop.c"), "-L" + pkg, "-lraptor_quad",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("env ")]
+    assert len(lines) == 8
+    pos = np.array([[float(v) for v in l.split("(")[1].split(")")[0].split()] for l in lines])
+    assert np.median(np.linalg.norm(pos, axis=1)) < 0.2
+
+
+def test_policy_from_checkpoint_header(device, weights, kat, tmp_path):
+    from raptor_amd.checkpoint import write_checkpoint_header
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    path = tmp_path / "checkpoint.h"
+    write_checkpoint_header(path, weights, (x[:20], y[:20]))
+    pol = Raptor.from_checkpoint(path, device)
+    assert pol.selftest(*pol.example, tolerance=ACTOR_TOL) < ACTOR_TOL
+
+
 # ------------------------------------------------------------------------------ errors -----
 def test_error_codes(device, oracle):
     import raptor_amd.l2f as l2f
