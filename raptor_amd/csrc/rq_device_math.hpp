@@ -341,15 +341,6 @@ __device__ __forceinline__ void sample_state(const SampleCfg& c, uint64_t seed, 
 enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF_BH = 1952,
        OFF_H0 = 2000, OFF_W2 = 2016, OFF_B2 = 2080 };
 
-// sigma(x) = 1 / (1 + 2^(-x log2 e)) on v_exp_f32 + v_rcp_f32 (1 ulp each)
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-// tanh(x) = 2 sigma(2x) - 1
-__device__ __forceinline__ float fast_tanh(float x) {
-    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
-}
-
 // The dense contractions of the actor run on the matrix cores as v_mfma_f32_16x16x4_f32 (exact
 // f32: one correctly rounded fma per product, the only f32 MFMA shape that reaches the full
 // 64 FLOP/clk/SIMD rate from a single wave — measured: the multi-block 4x4x1 form issues at

@@ -8,10 +8,12 @@
 //   kernel               replaces (reference call site)                          bound
 //   k_sample_params      vector.sample_initial_parameters   README.md:60         HBM (write 104 B/env)
 //   k_sample_state       vector.sample_initial_state        README.md:61         HBM
-//   k_observe            vector.observe                     README.md:96         HBM (read 84 B, write 104 B /env)
-//   k_actor_step         Raptor.evaluate_step               README.md:97         HBM at large n (232 B/env, 3.9 kFLOP)
-//   k_step               vector.step + state.assign         README.md:98-99      HBM (~320 B/env)
-//   k_rollout_fused      the loop body README.md:95-99 x K                       fp32 VALU (state in registers)
+//   k_observe            vector.observe                     README.md:96         HBM (read 92 B, write 104 B /env)
+//   k_actor_step         Raptor.evaluate_step               README.md:97         fp32 FMA rate (232 B/env, 3.9 kFLOP on MFMA)
+//   k_step               vector.step + state.assign         README.md:98-99      HBM (297 B/env)
+//   k_rollout_fused      the loop body README.md:95-99 x K                       fp32 FMA rate (MFMA + VALU share it;
+//                                                                                state, hidden, weights in registers)
+//   k_record             chained-mode trajectory append                          HBM
 #include "rq_device_math.hpp"
 
 namespace rq {
