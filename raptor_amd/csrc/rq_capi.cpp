@@ -74,6 +74,15 @@ struct rq_env {
     float* act = nullptr;       // [RQ_ACTION_DIM][ld]
     void* stats_block = nullptr;
     rq::StatsPtrs st{};
+    // chained rollouts replay a captured hipGraph of kGraphSteps steps (3 kernel nodes per step + the
+    // epoch-counter bump); one executable graph per distinct argument set
+    struct GraphEntry {
+        const float* params; float* state; float* hidden; const float* packed; const float* weights;
+        uint32_t flags; int precision; rq_env_config cfg; uint64_t seed;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
+    uint32_t* epoch_dev = nullptr;   // device-side noise epoch read by the graph's observe nodes
 };
 
 struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
@@ -476,10 +485,12 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
     hipError_t e1 = hipMalloc(&e->obs, (size_t)RQ_OBSERVATION_DIM * ld * sizeof(float));
     hipError_t e2 = hipMalloc(&e->act, (size_t)RQ_ACTION_DIM * ld * sizeof(float));
     hipError_t e3 = hipMalloc(&e->stats_block, stats_bytes);
+    if (e3 == hipSuccess) e3 = hipMalloc(&e->epoch_dev, sizeof(uint32_t));
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         if (e->obs) (void)hipFree(e->obs);
         if (e->act) (void)hipFree(e->act);
         if (e->stats_block) (void)hipFree(e->stats_block);
+        if (e->epoch_dev) (void)hipFree(e->epoch_dev);
         delete e;
         return fail(RQ_ERR_OUT_OF_MEMORY, "rq_env_create: device allocation failed");
     }
@@ -512,6 +523,8 @@ RQ_API int rq_env_destroy(rq_env* env) {
     if (env->obs) (void)hipFree(env->obs);
     if (env->act) (void)hipFree(env->act);
     if (env->stats_block) (void)hipFree(env->stats_block);
+    if (env->epoch_dev) (void)hipFree(env->epoch_dev);
+    for (auto& g : env->graphs) (void)hipGraphExecDestroy(g.exec);
     delete env;
     return RQ_OK;
 }
@@ -656,7 +669,7 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
     rc = set_device(dev); if (rc) return rc;
     RQ_HIP(rq::launch_observe(dev->stream, batch_of(env), rq::noise_cfg(env->cfg), rq::noise_enabled(env->cfg),
-                              rng->seed, rng->epoch, params->d, state->d, env->obs));
+                              rng->seed, rng->epoch, nullptr, params->d, state->d, env->obs));
     rng->epoch += 1;
     if (observation) return soa_to_host(dev, env->obs, env->n, env->ld, RQ_OBSERVATION_DIM, observation);
     return RQ_OK;
@@ -847,6 +860,8 @@ RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* e
 }
 
 // ---------------------------------------------------------------------------- Rollout ---
+static constexpr uint32_t kGraphSteps = 25;   // steps per captured graph (divides the 500-step episode)
+
 static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
                         rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags, rq_trajectory* traj) {
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
@@ -877,18 +892,52 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
                                         policy->precision, tp));
     } else {
-        for (uint32_t t = 0; t < n_steps; ++t) {
-            RQ_HIP(rq::launch_observe(dev->stream, b, nc, noise, rng->seed, rng->epoch + t, params->d, state->d,
-                                      env->obs));
-            RQ_HIP(rq::launch_actor_step(dev->stream, env->n, packed_of(policy), env->obs, env->ld, policy->hidden,
-                                         policy->ld, env->act, env->ld, env->st.frozen, policy->precision));
-            RQ_HIP(rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
-                                   /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev));
-            if (traj) {
-                rq::TrajPtrs tt = tp; tt.t0 = tp.t0 + t;
-                RQ_HIP(rq::launch_record(dev->stream, b, env->obs, env->act, env->st, tt));
+        // one step = observe -> evaluate_step -> step (-> record) on the stream
+        auto enqueue_step = [&](uint32_t epoch, const uint32_t* epoch_base, uint32_t t_record) -> hipError_t {
+            hipError_t e = rq::launch_observe(dev->stream, b, nc, noise, rng->seed, epoch, epoch_base, params->d,
+                                              state->d, env->obs);
+            if (e == hipSuccess)
+                e = rq::launch_actor_step(dev->stream, env->n, packed_of(policy), env->obs, env->ld, policy->hidden,
+                                          policy->ld, env->act, env->ld, env->st.frozen, policy->precision);
+            if (e == hipSuccess)
+                e = rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
+                                    /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev);
+            if (e == hipSuccess && traj) {
+                rq::TrajPtrs tt = tp; tt.t0 = tp.t0 + t_record;
+                e = rq::launch_record(dev->stream, b, env->obs, env->act, env->st, tt);
             }
+            return e;
+        };
+        uint32_t done_steps = 0;
+        if (!traj && n_steps >= kGraphSteps) {
+            // replay a captured graph of kGraphSteps steps; kernel boundaries stay (~1.5 us each) but the
+            // host no longer pays ~3.5 us per launch, which is what bounds small batches
+            hipGraphExec_t exec = nullptr;
+            for (auto& g : env->graphs)
+                if (g.params == params->d && g.state == state->d && g.hidden == policy->hidden &&
+                    g.packed == packed_of(policy) && g.weights == policy->w_dev && g.flags == flags &&
+                    g.precision == policy->precision && g.seed == rng->seed &&
+                    std::memcmp(&g.cfg, &env->cfg, sizeof(rq_env_config)) == 0) { exec = g.exec; break; }
+            if (!exec) {
+                hipGraph_t graph = nullptr;
+                RQ_HIP(hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal));
+                hipError_t ce = hipSuccess;
+                for (uint32_t t = 0; t < kGraphSteps && ce == hipSuccess; ++t) ce = enqueue_step(t, env->epoch_dev, 0);
+                if (ce == hipSuccess) ce = rq::launch_add_u32(dev->stream, env->epoch_dev, kGraphSteps);
+                hipError_t ee = hipStreamEndCapture(dev->stream, &graph);
+                RQ_HIP(ce);
+                RQ_HIP(ee);
+                hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                RQ_HIP(ie);
+                env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, flags,
+                                       policy->precision, env->cfg, rng->seed, exec});
+            }
+            RQ_HIP(rq::launch_set_u32(dev->stream, env->epoch_dev, rng->epoch));
+            for (; done_steps + kGraphSteps <= n_steps; done_steps += kGraphSteps)
+                RQ_HIP(hipGraphLaunch(exec, dev->stream));
         }
+        for (uint32_t t = done_steps; t < n_steps; ++t) RQ_HIP(enqueue_step(rng->epoch + t, nullptr, t));
     }
     rng->epoch += n_steps;
     if (traj) traj->length += n_steps;

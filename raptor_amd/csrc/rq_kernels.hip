@@ -56,11 +56,15 @@ __global__ __launch_bounds__(kBlock) void k_sample_state(Batch b, SampleCfg c, u
 
 // ------------------------------------------------------------------ observe ------------
 template <bool NOISE>
-__global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64_t seed, uint32_t epoch,
+__global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64_t seed, uint32_t epoch_offset,
+                                                    const uint32_t* __restrict__ epoch_base,
                                                     const float* __restrict__ params,
                                                     const float* __restrict__ state, float* __restrict__ obs) {
     const uint32_t i = env_index();
     if (i >= b.n) return;
+    // inside a replayed hipGraph the noise epoch cannot be a baked-in argument: it is read from a
+    // device counter the graph itself advances (k_advance_u32); eager launches pass nullptr
+    const uint32_t epoch = epoch_offset + (epoch_base != nullptr ? *epoch_base : 0u);
     float y[17], la[4];
 #pragma unroll
     for (int k = 0; k < 17; ++k) y[k] = state[(size_t)k * b.ld + i];
@@ -325,10 +329,22 @@ hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t see
 }
 
 hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint64_t seed, uint32_t epoch,
-                          const float* params, const float* state, float* obs) {
+                          const uint32_t* epoch_base, const float* params, const float* state, float* obs) {
     if (b.n == 0) return hipSuccess;
-    if (noise) k_observe<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, params, state, obs);
-    else       k_observe<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, params, state, obs);
+    if (noise) k_observe<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, epoch_base, params, state, obs);
+    else       k_observe<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, epoch_base, params, state, obs);
+    return hipGetLastError();
+}
+
+__global__ void k_advance_u32(uint32_t* p, uint32_t add, uint32_t set, int do_set) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p = do_set ? set : *p + add;
+}
+hipError_t launch_set_u32(hipStream_t s, uint32_t* p, uint32_t value) {
+    k_advance_u32<<<1, 64, 0, s>>>(p, 0u, value, 1);
+    return hipGetLastError();
+}
+hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add) {
+    k_advance_u32<<<1, 64, 0, s>>>(p, add, 0u, 0);
     return hipGetLastError();
 }
 

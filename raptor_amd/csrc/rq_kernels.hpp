@@ -76,8 +76,12 @@ hipError_t launch_sample_params(hipStream_t s, Batch b, SampleCfg c, uint64_t se
 hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params,
                                float* state, uint32_t* episode, uint8_t* frozen);
 // vector.observe (README.md:96): obs [RQ_OBSERVATION_DIM][ld]
+// epoch used = epoch + (epoch_base ? *epoch_base : 0): epoch_base is a device counter for launches
+// replayed from a hipGraph (see rq_rollout, chained mode)
 hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint64_t seed, uint32_t epoch,
-                          const float* params, const float* state, float* obs);
+                          const uint32_t* epoch_base, const float* params, const float* state, float* obs);
+hipError_t launch_set_u32(hipStream_t s, uint32_t* p, uint32_t value);
+hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.
 // frozen != nullptr: envs with frozen[i] != 0 are skipped (rollout semantics).
 // `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
