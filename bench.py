@@ -148,13 +148,13 @@ def kernel_probe(device, n, reps):
     return out
 
 
-def api_loop_probe(device):
-    """BASELINE config 1 shape: the README loop (README.md:94-99) at N = 8, 500 steps, NumPy arrays
-    crossing the boundary every call (host-bound by construction), and the same loop kept on the
-    device.  Reported as microseconds per loop iteration."""
+def api_loop_probe(device, n=8, iters=500):
+    """BASELINE config 1 shape: the README loop (README.md:94-99), NumPy arrays crossing the boundary
+    every call (PCIe-inclusive, host-bound by construction), and the same loop kept on the device.
+    Reported as microseconds per loop iteration."""
     import raptor_amd.l2f as l2f
     from raptor_amd.foundation_policy import Raptor
-    vector = l2f.vector8
+    vector = l2f.vector(n)
     rng, env = vector.VectorRng(), vector.VectorEnvironment()
     params, state, next_state = vector.VectorParameters(), vector.VectorState(), vector.VectorState()
     vector.initialize_rng(device, rng, 0)
@@ -167,8 +167,9 @@ def api_loop_probe(device):
     for name in ("numpy_arrays", "device_resident"):
         policy.reset()
         t0 = None
-        for it in range(550):
-            if it == 50:
+        warm = max(2, iters // 10)
+        for it in range(iters + warm):
+            if it == warm:
                 device.synchronize()
                 t0 = time.perf_counter()
             if name == "numpy_arrays":
@@ -181,7 +182,8 @@ def api_loop_probe(device):
                 policy.evaluate_step_device(env)
                 vector.step_device(device, env, params, state, state, rng)
         device.synchronize()
-        out[name + "_us_per_iteration"] = round((time.perf_counter() - t0) / 500 * 1e6, 2)
+        out[name + "_us_per_iteration"] = round((time.perf_counter() - t0) / iters * 1e6, 2)
+    out["env_steps_per_s_numpy_arrays"] = round(n / (out["numpy_arrays_us_per_iteration"] * 1e-6), 1)
     return out
 
 
@@ -333,6 +335,7 @@ def main():
             result["kernels"] = {"n65536": kernel_probe(device, ENVS_PER_GPU, 200),
                                  "n2097152": kernel_probe(device, 2097152, 20)}
             result["readme_loop_n8"] = api_loop_probe(device)
+            result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if gathered is not None:

@@ -88,27 +88,33 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 // batch (and frozen envs) compute on a clamped index and only their STORES are predicated —
 // no lane leaves early.
 template <typename ACTOR>
-__global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, const float* __restrict__ packed,
+__global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
+                                                       const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen) {
     ACTOR actor;
-    actor.load(packed);
-    const uint32_t i0 = env_index();
-    const uint32_t wave_base = i0 & ~63u;
-    const uint32_t i = i0 < n ? i0 : n - 1;
-    const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
-    const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
-    float x[22], hQ[4][4], a[4];
+    actor.load(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t g = 0; g < groups_per_wave; ++g) {
+        const uint32_t wave_base = (wave * groups_per_wave + g) * 64;
+        if (wave_base >= n) break;                       // wave-uniform
+        const uint32_t i0 = wave_base + lane;
+        const uint32_t i = i0 < n ? i0 : n - 1;
+        const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
+        const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
+        float x[22], hQ[4][4], a[4];
 #pragma unroll
-    for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
-    load_hidden_q(hidden, ld_h, wave_base, n, hQ);
-    actor.step(x, hQ, a);
-    store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
-    if (commit) {
+        for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
+        load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+        actor.step(x, hQ, a);
+        store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
+        if (commit) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
+            for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
+        }
     }
 }
 
@@ -352,10 +358,15 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
                              int precision) {
     if (n == 0) return hipSuccess;
+    // enough waves to fill the 1024 SIMDs first, then several 64-env groups per wave so that the
+    // per-wave operand-image load (18 KB, more than a group's own 14.8 KB of data) is amortised
+    const uint32_t groups = (n + 63) / 64;
+    const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
+    const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
     if (precision == RQ_POLICY_BF16_MFMA)
-        k_actor_step<ActorBF16><<<grid_for(n, kBlock), kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
     else
-        k_actor_step<ActorF32><<<grid_for(n, kBlock), kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+        k_actor_step<ActorF32><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
     return hipGetLastError();
 }
 
