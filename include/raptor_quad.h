@@ -253,6 +253,14 @@ typedef enum rq_policy_precision {
 RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out);
 RQ_API int rq_policy_destroy(rq_policy* pol);
 RQ_API int rq_policy_set_precision(rq_policy* pol, int precision);
+/* Optional stages named by rl-tools' layer list (README.md:114,116) that the SHIPPED checkpoint does not
+ * contain (checkpoint.h:185 chains layer_0, layer_1, layer_2 only) — identity unless enabled; their
+ * reference semantics are unpinned (no source or test vector in the reference tree):
+ *   Standardize: x <- (x - mean) / std on the 22 inputs (folded into layer_0's weights, zero run-time cost);
+ *                mean = std = NULL disables.
+ *   Squash:      action <- tanh(action) (SampleAndSquash evaluated deterministically). */
+RQ_API int rq_policy_set_standardize(rq_policy* pol, const float* mean, const float* std);
+RQ_API int rq_policy_set_squash(rq_policy* pol, int enable);
 /* hidden state h[B,16] <- initial_hidden_state (checkpoint.h:123); sized on first use */
 RQ_API int rq_policy_reset(rq_policy* pol);
 /* One recurrent step for a batch.  observation: host [batch, obs_stride] (first 22 columns

@@ -20,7 +20,7 @@ LIB = os.path.join(PKG, "libraptor_quad.so")
 
 ARCH = "gfx950"
 # -ffp-contract=off: only explicit fmaf() calls fuse (DESIGN.md "Arithmetic contract")
-DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
+DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"--offload-arch={ARCH}",
                 "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 SOURCES = ["rq_kernels.hip", "rq_capi.cpp"]
 HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", os.path.join(INCLUDE, "raptor_quad.h")]

@@ -104,7 +104,11 @@ struct rq_policy {
     float* w_dev = nullptr;       // raw parameters (checkpoint order)
     float* w_packed = nullptr;    // f32 MFMA operand image, rq::RQ_PACKED_FLOATS floats
     float* w_packed_bf16 = nullptr;   // bf16 MFMA operand image, rq::RQ_PACKED_BF16_FLOATS floats
-    float w_host[RQ_POLICY_NUM_WEIGHTS];
+    float w_host[RQ_POLICY_NUM_WEIGHTS];      // as loaded (checkpoint order)
+    float w_eff[RQ_POLICY_NUM_WEIGHTS];       // with the optional Standardize stage folded into layer_0
+    bool standardize = false;
+    float std_mean[RQ_POLICY_INPUT_DIM], std_inv[RQ_POLICY_INPUT_DIM];
+    int squash = 0;
     int precision = RQ_POLICY_FP32;
     uint32_t batch = 0, ld = 0;   // 0 = not sized yet
     bool needs_reset = true;      // hidden must be (re)filled with initial_hidden_state before use
@@ -192,6 +196,8 @@ int check_env_objects(const rq_device* dev, const rq_env* env, const rq_params* 
 }
 
 void policy_free_buffers(rq_policy* pol);
+
+int mode_of(const rq_policy* pol) { return pol->precision | (pol->squash << 8); }
 
 const float* packed_of(const rq_policy* pol) {
     return pol->precision == RQ_POLICY_BF16_MFMA ? pol->w_packed_bf16 : pol->w_packed;
@@ -734,6 +740,33 @@ RQ_API int rq_env_reset_statistics(rq_env* env) {
 }
 
 // ---------------------------------------------------------------------------- Policy ----
+// (re)build the effective parameters and both MFMA operand images, and upload them
+static int policy_upload(rq_policy* p) {
+    std::memcpy(p->w_eff, p->w_host, sizeof(p->w_eff));
+    if (p->standardize) {
+        // Standardize (x - mean) / std followed by Dense folds into the Dense:
+        //   W0' = W0 diag(1/std),  b0' = b0 - W0' mean      (semantics unpinned)
+        for (int o = 0; o < 16; ++o) {
+            float shift = 0.0f;
+            for (int k = 0; k < RQ_POLICY_INPUT_DIM; ++k) {
+                const float w = p->w_host[o * 22 + k] * p->std_inv[k];
+                p->w_eff[o * 22 + k] = w;
+                shift += w * p->std_mean[k];
+            }
+            p->w_eff[352 + o] = p->w_host[352 + o] - shift;
+        }
+    }
+    std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS);
+    rq::pack_policy(p->w_eff, packed.data());
+    rq::pack_policy_bf16(p->w_eff, packed16.data());
+    int rc = set_device(p->dev); if (rc) return rc;
+    RQ_HIP(hipStreamSynchronize(p->dev->stream));
+    RQ_HIP(hipMemcpy(p->w_dev, p->w_eff, sizeof(p->w_eff), hipMemcpyHostToDevice));
+    RQ_HIP(hipMemcpy(p->w_packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    RQ_HIP(hipMemcpy(p->w_packed_bf16, packed16.data(), packed16.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RQ_OK;
+}
+
 RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out) {
     RQ_REQUIRE(dev && weights && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(n_weights == RQ_POLICY_NUM_WEIGHTS, RQ_ERR_INVALID_ARGUMENT,
@@ -746,19 +779,14 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
     std::memcpy(p->w_host, weights, sizeof(p->w_host));
     hipError_t e = hipMalloc(&p->w_dev, sizeof(p->w_host));
     if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed"); }
-    std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS);
-    rq::pack_policy(p->w_host, packed.data());
-    rq::pack_policy_bf16(p->w_host, packed16.data());
-    e = hipMalloc(&p->w_packed, packed.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&p->w_packed_bf16, packed16.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpyAsync(p->w_packed_bf16, packed16.data(), packed16.size() * sizeof(float), hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(p->w_dev, p->w_host, sizeof(p->w_host), hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(p->w_packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    e = hipMalloc(&p->w_packed, (size_t)rq::RQ_PACKED_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p->w_packed_bf16, (size_t)rq::RQ_PACKED_BF16_FLOATS * sizeof(float));
     if (e != hipSuccess) {
-        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed); if (p->w_packed_bf16) (void)hipFree(p->w_packed_bf16); delete p;
-        return fail(RQ_ERR_HIP, "rq_policy_create: weight upload failed");
+        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed); delete p;
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed");
     }
+    rc = policy_upload(p);
+    if (rc) { rq_policy_destroy(p); return rc; }
     *out = p;
     return RQ_OK;
 }
@@ -779,6 +807,26 @@ RQ_API int rq_policy_set_precision(rq_policy* pol, int precision) {
     RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA, RQ_ERR_INVALID_ARGUMENT,
                "unknown precision");
     pol->precision = precision;
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_set_standardize(rq_policy* pol, const float* mean, const float* std) {
+    RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE((mean == nullptr) == (std == nullptr), RQ_ERR_INVALID_ARGUMENT, "mean and std must be given together");
+    if (mean) {
+        for (int k = 0; k < RQ_POLICY_INPUT_DIM; ++k) {
+            RQ_REQUIRE(std[k] > 0.0f, RQ_ERR_INVALID_ARGUMENT, "std must be positive");
+            pol->std_mean[k] = mean[k];
+            pol->std_inv[k] = 1.0f / std[k];
+        }
+    }
+    pol->standardize = mean != nullptr;
+    return policy_upload(pol);
+}
+
+RQ_API int rq_policy_set_squash(rq_policy* pol, int enable) {
+    RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    pol->squash = enable ? 1 : 0;
     return RQ_OK;
 }
 
@@ -813,7 +861,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     float* d_act = action ? pol->act : env->act;
     const uint32_t ld_act = action ? pol->ld : env->ld;
     RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
-                                 ld_act, nullptr, pol->precision));
+                                 ld_act, nullptr, mode_of(pol)));
     if (action) return soa_to_host(pol->dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
     return RQ_OK;
 }
@@ -839,6 +887,14 @@ RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* e
     rq_policy* tmp = nullptr;
     int rc = rq_policy_create(pol->dev, pol->w_host, RQ_POLICY_NUM_WEIGHTS, &tmp); if (rc) return rc;
     tmp->precision = pol->precision;
+    tmp->squash = pol->squash;
+    if (pol->standardize) {
+        tmp->standardize = true;
+        std::memcpy(tmp->std_mean, pol->std_mean, sizeof(tmp->std_mean));
+        std::memcpy(tmp->std_inv, pol->std_inv, sizeof(tmp->std_inv));
+        rc = policy_upload(tmp);
+        if (rc) { rq_policy_destroy(tmp); return rc; }
+    }
     std::vector<float> act((size_t)batch * RQ_ACTION_DIM);
     float worst = 0.0f;
     for (uint32_t t = 0; t < steps && rc == RQ_OK; ++t) {
@@ -890,7 +946,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
-                                        policy->precision, tp));
+                                        mode_of(policy), tp));
     } else {
         // one step = observe -> evaluate_step -> step (-> record) on the stream
         auto enqueue_step = [&](uint32_t epoch, const uint32_t* epoch_base, uint32_t t_record) -> hipError_t {
@@ -898,7 +954,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                                               state->d, env->obs);
             if (e == hipSuccess)
                 e = rq::launch_actor_step(dev->stream, env->n, packed_of(policy), env->obs, env->ld, policy->hidden,
-                                          policy->ld, env->act, env->ld, env->st.frozen, policy->precision);
+                                          policy->ld, env->act, env->ld, env->st.frozen, mode_of(policy));
             if (e == hipSuccess)
                 e = rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
                                     /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev);
@@ -916,7 +972,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
             for (auto& g : env->graphs)
                 if (g.params == params->d && g.state == state->d && g.hidden == policy->hidden &&
                     g.packed == packed_of(policy) && g.weights == policy->w_dev && g.flags == flags &&
-                    g.precision == policy->precision && g.seed == rng->seed &&
+                    g.precision == mode_of(policy) && g.seed == rng->seed &&
                     std::memcmp(&g.cfg, &env->cfg, sizeof(rq_env_config)) == 0) { exec = g.exec; break; }
             if (!exec) {
                 hipGraph_t graph = nullptr;
@@ -931,7 +987,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                 (void)hipGraphDestroy(graph);
                 RQ_HIP(ie);
                 env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, flags,
-                                       policy->precision, env->cfg, rng->seed, exec});
+                                       mode_of(policy), env->cfg, rng->seed, exec});
             }
             RQ_HIP(rq::launch_set_u32(dev->stream, env->epoch_dev, rng->epoch));
             for (; done_steps + kGraphSteps <= n_steps; done_steps += kGraphSteps)

@@ -603,6 +603,14 @@ struct ActorBF16 {
     }
 };
 
+// Optional output stage (SampleAndSquash in inference mode: tanh of the mean
+// head; NOT part of the shipped checkpoint, semantics unpinned): a <- tanh(a).
+__device__ __forceinline__ void squash_action(float (&a)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        a[r] = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * a[r])), -1.0f);
+}
+
 // Q-layout addressing helpers for a wave whose first env is wave_base: tile t of lane (q,j) is
 // env wave_base + 16 t + j (clamped to the batch), hidden feature 4q + r.
 __device__ __forceinline__ void load_hidden_q(const float* __restrict__ hidden, size_t ld, uint32_t wave_base,

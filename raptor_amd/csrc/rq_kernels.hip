@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
-                                                       const uint8_t* __restrict__ frozen) {
+                                                       const uint8_t* __restrict__ frozen, uint32_t squash) {
     ACTOR actor;
     actor.load(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
     const uint32_t lane = threadIdx.x & 63;
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
         for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
         load_hidden_q(hidden, ld_h, wave_base, n, hQ);
         actor.step(x, hQ, a);
+        if (squash) squash_action(a);        // wave-uniform (kernel argument)
         store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
         if (commit) {
 #pragma unroll
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
                                                                float* __restrict__ hidden,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ packed, StatsPtrs st,
-                                                               TrajPtrs traj) {
+                                                               TrajPtrs traj, uint32_t squash) {
     ACTOR actor;
     actor.load(packed);
     const uint32_t i0 = env_index();
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg 
 #pragma unroll
             for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
         actor.step(o, hn, a);
+        if (squash) squash_action(a);        // wave-uniform (kernel argument)
         if (AUTORESET) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
@@ -360,13 +362,15 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     if (n == 0) return hipSuccess;
     // enough waves to fill the 1024 SIMDs first, then several 64-env groups per wave so that the
     // per-wave operand-image load (18 KB, more than a group's own 14.8 KB of data) is amortised
+    const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
+    precision &= 0xff;
     const uint32_t groups = (n + 63) / 64;
     const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
     if (precision == RQ_POLICY_BF16_MFMA)
-        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash);
     else
-        k_actor_step<ActorF32><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen);
+        k_actor_step<ActorF32><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash);
     return hipGetLastError();
 }
 
@@ -391,7 +395,7 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
 #define RQ_LAUNCH_FUSED(NZ, AR, RC, ACT) \
-    k_rollout_fused<NZ, AR, RC, ACT><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj)
+    k_rollout_fused<NZ, AR, RC, ACT><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, squash)
 #define RQ_LAUNCH_FUSED_RC(NZ, AR, ACT) \
     do { if (rec) RQ_LAUNCH_FUSED(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED(NZ, AR, false, ACT); } while (0)
 #define RQ_LAUNCH_FUSED_ACT(ACT)                                                          \
@@ -400,6 +404,8 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
         else       { if (ar) RQ_LAUNCH_FUSED_RC(false, true, ACT); else RQ_LAUNCH_FUSED_RC(false, false, ACT); } \
     } while (0)
     const bool rec = traj.obs != nullptr;
+    const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
+    precision &= 0xff;
     if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_ACT(ActorBF16);
     else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
 #undef RQ_LAUNCH_FUSED_RC

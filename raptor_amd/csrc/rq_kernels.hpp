@@ -84,6 +84,7 @@ hipError_t launch_set_u32(hipStream_t s, uint32_t* p, uint32_t value);
 hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.
 // frozen != nullptr: envs with frozen[i] != 0 are skipped (rollout semantics).
+// `precision`: rq_policy_precision in bits 0-7, bit 8 = squash the output with tanh.
 // `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,

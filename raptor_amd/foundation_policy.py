@@ -101,6 +101,21 @@ class Raptor:
         if self._h is not None:
             _lib.call("rq_policy_set_precision", self._h, PRECISIONS[precision])
 
+    def set_standardize(self, mean=None, std=None):
+        """Optional Standardize input stage (x - mean) / std (not part of the shipped checkpoint;
+        folded into layer_0 on the host).  ``None`` disables."""
+        if mean is None:
+            _lib.call("rq_policy_set_standardize", self._handle(), None, None)
+        else:
+            m, s_ = np.ascontiguousarray(mean, np.float32), np.ascontiguousarray(std, np.float32)
+            assert m.shape == (POLICY_INPUT_DIM,) and s_.shape == (POLICY_INPUT_DIM,)
+            _lib.call("rq_policy_set_standardize", self._handle(), _lib.fptr(m), _lib.fptr(s_))
+
+    def set_squash(self, enable):
+        """Optional tanh output stage (SampleAndSquash evaluated deterministically; not in the
+        shipped checkpoint)."""
+        _lib.call("rq_policy_set_squash", self._handle(), 1 if enable else 0)
+
     def reset(self):
         """README.md:21,94 — hidden state <- initial_hidden_state (checkpoint.h:123, zeros)."""
         _lib.call("rq_policy_reset", self._handle())

@@ -120,6 +120,30 @@ def test_actor_batch_change_requires_reset(device):
     assert pol.evaluate_step(np.zeros((5, 22), np.float32)).shape == (5, 4)
 
 
+def test_optional_standardize_and_squash_stages(device, oracle, weights):
+    """A6 / A7 of SURVEY.md section 8(a): identity by default, and when enabled equal to the oracle's actor
+    fed standardised inputs / followed by tanh (their l2f / rl-tools parity is unpinned)."""
+    from raptor_amd.foundation_policy import Raptor
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((300, 22)) * 3 + 1).astype(np.float32)
+    mean = rng.standard_normal(22).astype(np.float32)
+    std = rng.uniform(0.5, 2.0, 22).astype(np.float32)
+    pol = Raptor(device)
+    pol.set_standardize(mean, std)
+    pol.set_squash(True)
+    pol.reset()
+    h = np.zeros((300, 16), np.float32)
+    for _ in range(3):
+        a = pol.evaluate_step(x)
+        ref = np.tanh(oracle.actor_batch_step(weights, ((x - mean) / std).astype(np.float32), h))
+        assert np.abs(a - ref).max() < 2e-5 and np.abs(a).max() <= 1.0
+    pol.set_standardize(None, None)
+    pol.set_squash(False)
+    pol.reset()
+    h = np.zeros((300, 16), np.float32)
+    assert np.abs(pol.evaluate_step(x) - oracle.actor_batch_step(weights, x, h)).max() < 5e-5   # |x| up to ~10
+
+
 # ------------------------------------------------------------------------------ bf16 actor --
 BF16_KAT_TOL = 5e-2     # abs on raw actions: bf16 operands (8-bit mantissa), fp32 accumulate (numpy model: 1.9e-2)
 
