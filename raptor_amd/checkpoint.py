@@ -1,5 +1,6 @@
-"""Reading policies in the reference's C++ export format (`checkpoint.h`, SURVEY.md §5 "checkpoint /
-resume"; the HDF5 twin needs an HDF5 reader and is not supported yet).
+"""Reading policies in the two formats rl-tools writes per checkpoint (SURVEY.md §5 "checkpoint /
+resume", §8(f) row 3): the C++ code export `checkpoint.h` and its HDF5 twin `checkpoint.h5` (read with
+the dependency-free minimal reader in `hdf5_min.py`).
 
 rl-tools writes every parameter as
     namespace <path> { ... alignas(float) const unsigned char memory[] = {b0, b1, ...}; ... }
@@ -95,3 +96,54 @@ def write_checkpoint_header(path, weights, example=None):
                        "alignas(float) const unsigned char memory[] = {" + ", ".join(str(b) for b in arr.tobytes()) + "};\n"
                        f"using SHAPE = rl_tools::tensor::Shape<unsigned long, {T}, {B}, {d}>;\n}}\n")
     open(path, "w").write("".join(out))
+
+
+_H5_LAYOUT = [
+    ("actor/layers/0/weights/parameters", (16, 22)), ("actor/layers/0/biases/parameters", (1, 16)),
+    ("actor/layers/1/weights_input/parameters", (48, 16)), ("actor/layers/1/weights_hidden/parameters", (48, 16)),
+    ("actor/layers/1/biases_input/parameters", (48,)), ("actor/layers/1/biases_hidden/parameters", (48,)),
+    ("actor/layers/1/initial_hidden_state/parameters", (16,)),
+    ("actor/layers/2/weights/parameters", (4, 16)), ("actor/layers/2/biases/parameters", (1, 4)),
+]
+
+
+def load_checkpoint_h5(path):
+    """-> (weights float32 [2084], example or None, meta str or None) from an rl-tools `checkpoint.h5`
+    (groups `/actor/layers/{0,1,2}`, string attributes `type` / `activation_function`; `h5:/actor...` in
+    SURVEY.md).  Only Dense(22->16, RELU) -> GRU(16) -> Dense(16->4, IDENTITY) is accepted."""
+    from .hdf5_min import File, Hdf5FormatError
+    root = File(path).root
+    try:
+        actor = root["actor"]
+        kinds = [(actor[f"layers/{i}"].attrs.get("type"), actor[f"layers/{i}"].attrs.get("activation_function"))
+                 for i in range(3)]
+    except KeyError as e:
+        raise ValueError(f"{path}: not an rl-tools actor checkpoint (missing {e})")
+    if actor.attrs.get("type") != "sequential" or kinds != [("dense", "RELU"), ("gru", None), ("dense", "IDENTITY")]:
+        raise ValueError(f"{path}: unsupported topology {actor.attrs.get('type')} {kinds}; expected "
+                         "sequential Dense(RELU) -> GRU -> Dense(IDENTITY)")
+    if "layers/3" in actor:
+        raise ValueError(f"{path}: more than three layers")
+    parts = []
+    for name, shape in _H5_LAYOUT:
+        ds = root[name]
+        if tuple(ds.shape) != shape or ds.dtype != np.dtype("<f4"):
+            raise ValueError(f"{path}: {name} has shape {ds.shape} {ds.dtype}, expected {shape} float32")
+        parts.append(ds.numpy().ravel())
+    weights = np.concatenate(parts).astype(np.float32)
+    example = None
+    if "example/input" in root and "example/output" in root:
+        x, y = root["example/input"].numpy(), root["example/output"].numpy()
+        if x.ndim == 3 and x.shape[2] == 22 and y.shape == x.shape[:2] + (4,):
+            example = (x.astype(np.float32), y.astype(np.float32))
+    return weights, example, actor.attrs.get("meta")
+
+
+def load_checkpoint(path):
+    """Dispatch on the file type: HDF5 signature -> `load_checkpoint_h5`, otherwise the C++ export."""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic == b"\x89HDF\r\n\x1a\n":
+        w, ex, _ = load_checkpoint_h5(path)
+        return w, ex
+    return load_checkpoint_header(path)

@@ -64,10 +64,11 @@ class Raptor:
 
     @classmethod
     def from_checkpoint(cls, path, device=None, precision="fp32"):
-        """Load a policy exported by rl-tools as C++ code (``checkpoint.h`` format, same topology).
-        The embedded known-answer example, if any, is kept as ``policy.example``."""
-        from .checkpoint import load_checkpoint_header
-        weights, example = load_checkpoint_header(path)
+        """Load a policy checkpoint written by rl-tools: the C++ code export (``checkpoint.h``) or its
+        HDF5 twin (``checkpoint.h5``), same topology.  The embedded known-answer example, if any, is
+        kept as ``policy.example``."""
+        from .checkpoint import load_checkpoint
+        weights, example = load_checkpoint(path)
         pol = cls(device=device, weights=weights, precision=precision)
         pol.example = example
         return pol

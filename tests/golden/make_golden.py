@@ -9,6 +9,8 @@ the GPU box).  Its outputs are committed:
   tests/golden/kat_h_output.bin         known-answer output #1  [500,2,4]  f32
   tests/golden/kat_h5_input.bin         known-answer input  #2  [500,2,22] f32
   tests/golden/kat_h5_output.bin        known-answer output #2  [500,2,4]  f32
+  tests/golden/checkpoint.h5            the published HDF5 checkpoint itself (a 142 KB data file:
+                                        weights + known-answer pair #2), fixture of the HDF5 reader
   tests/golden/MANIFEST.json            sha256 + shape of every file above
 
 Sources (members of /root/reference/data/raptor-policy-checkpoint.tar.gz, directory
@@ -131,6 +133,11 @@ def main():
             manifest[os.path.relpath(fn, REPO)] = {
                 "shape": shape, "dtype": "<f4",
                 "sha256": hashlib.sha256(arr.astype("<f4").tobytes()).hexdigest()}
+        import shutil
+        shutil.copy(os.path.join(ck, "checkpoint.h5"), os.path.join(gold, "checkpoint.h5"))
+        manifest["tests/golden/checkpoint.h5"] = {
+            "shape": [os.path.getsize(os.path.join(gold, "checkpoint.h5"))], "dtype": "bytes",
+            "sha256": hashlib.sha256(open(os.path.join(gold, "checkpoint.h5"), "rb").read()).hexdigest()}
         manifest["_source"] = {
             "tarball": "data/raptor-policy-checkpoint.tar.gz", "dir": CK_DIR,
             "checkpoint_name": "logs/2025-04-19_16-16-17",

@@ -62,3 +62,30 @@ def test_checkpoint_header_of_the_reference(tmp_path):
     assert ex[0].shape == (500, 2, 22)
     assert np.array_equal(ex[0].ravel(), np.fromfile(os.path.join(GOLDEN, "kat_h_input.bin"), "<f4"))
     assert np.array_equal(ex[1].ravel(), np.fromfile(os.path.join(GOLDEN, "kat_h_output.bin"), "<f4"))
+
+
+def test_hdf5_checkpoint_reader(oracle):
+    """The published checkpoint.h5 (fixture) through the dependency-free HDF5 reader: same weights
+    as the shipped parameter file, the second known-answer pair, the observation spec string, and
+    the oracle reproduces that pair from these weights."""
+    import os
+    from conftest import GOLDEN
+    from raptor_amd.checkpoint import load_checkpoint, load_checkpoint_h5
+    from raptor_amd.foundation_policy import load_weights
+    path = os.path.join(GOLDEN, "checkpoint.h5")
+    w, ex, meta = load_checkpoint_h5(path)
+    assert np.array_equal(w, load_weights())
+    assert "OrientationRotationMatrix" in meta and "ActionHistory(1)" in meta
+    assert np.array_equal(ex[0].ravel(), np.fromfile(os.path.join(GOLDEN, "kat_h5_input.bin"), "<f4"))
+    assert np.array_equal(ex[1].ravel(), np.fromfile(os.path.join(GOLDEN, "kat_h5_output.bin"), "<f4"))
+    assert np.abs(oracle.actor_sequence(w, ex[0]) - ex[1]).max() < 1e-5
+    w2, ex2 = load_checkpoint(path)
+    assert np.array_equal(w2, w) and ex2[0].shape == (500, 2, 22)
+
+
+def test_hdf5_reader_rejects_garbage(tmp_path):
+    from raptor_amd.hdf5_min import File, Hdf5FormatError
+    p = tmp_path / "x.h5"
+    p.write_bytes(b"not hdf5 at all")
+    with pytest.raises(Hdf5FormatError):
+        File(p)

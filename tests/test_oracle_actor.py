@@ -17,7 +17,7 @@ def test_golden_manifest_intact():
             continue
         data = open(os.path.join(ROOT, rel), "rb").read()
         assert hashlib.sha256(data).hexdigest() == meta["sha256"], rel
-        assert len(data) == 4 * int(np.prod(meta["shape"]))
+        assert len(data) == (1 if meta["dtype"] == "bytes" else 4) * int(np.prod(meta["shape"]))
 
 
 def test_kat_vectors_are_independent():
