@@ -368,23 +368,7 @@ enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF
 // biases are added last.  These are fp32 re-associations of the oracle's k-ascending chains
 // (differences ~1e-7, covered by the actor tolerance).
 //
-// Packed weight image (host: rq::pack_policy, one 64-lane VGPR image each):
-enum {
-    QW_L0 = 0,    //  6: layer_0, K-step s: lane (q,j) = W0[j][4s+q]; input 22 -> b0[j], input 23 -> 0
-    QW_GI = 6,    // 12: W_input,  [m][s]: lane (q,j) = Wi[16m+j][4q+s]
-    QW_GH = 18,   // 12: W_hidden, [m][s]: lane (q,j) = Wh[16m+j][4q+s]
-    QW_L2 = 30,   // 16: layer_2,  [t][s]: lane (q,j) = (j>>2 == t) ? W2[j&3][4q+s] : 0
-    // biases never occupy an MFMA C operand (that costs a 4-register copy per chain): layer_0's
-    // bias rides in the spare K slot 22 (its B operand is the constant 1), the gate biases are
-    // folded, pre-scaled, into the fma that feeds v_exp_f32, layer_2's is added after the MFMAs
-    QW_BR = 46,   //  4: [r]: -log2(e)  * (bi[4q+r] + bh[4q+r])
-    QW_BZ = 50,   //  4: [r]: -log2(e)  * (bi[16+4q+r] + bh[16+4q+r])
-    QW_BNI = 54,  //  4: [r]: -2log2(e) * bi[32+4q+r]
-    QW_BNH = 58,  //  4: [r]: -2log2(e) * bh[32+4q+r]
-    QW_H0 = 62,   //  4: [r]: initial_hidden_state[4q+r]
-    QW_B2 = 66,   //  4: [r]: b2[r] on every lane
-    QW_REGS = 70
-};
+// Packed weight image: enum QW_* in rq_kernels.hpp (shared with the host-side packer rq_pack.cpp).
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -514,11 +498,7 @@ struct ActorF32 {
 //   layer_2 : slots e < 4 carry h[4q+e]; the four tiles accumulate into one D (native layout).
 // 4 + 16 + 4 = 24 MFMAs per wave-step instead of 136.  Operands are rounded to bf16 (RNE) by
 // v_cvt_pk_bf16_f32; products are exact in fp32 and accumulation is fp32.
-enum {
-    BW_L0 = 0, BW_R = 4, BW_Z = 8, BW_NI = 12, BW_NH = 16, BW_L2 = 20,   // bf16x8 A operands, 4 dwords each
-    BW_BR = 36, BW_BZ = 40, BW_BNI = 44, BW_BNH = 48, BW_H0 = 52, BW_B2 = 56,   // fp32, as in the f32 image
-    BW_REGS = 60
-};
+// image indices: enum BW_* in rq_kernels.hpp
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t dwordx4 __attribute__((ext_vector_type(4)));
@@ -533,18 +513,18 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float f0, float f1, float f2, floa
 
 struct ActorBF16 {
     static constexpr int kPackedRegs = BW_REGS;
-    uint32_t A[36];
-    float B[24];
+    uint32_t A[BW_BR];
+    float B[BW_REGS - BW_BR];
 
     __device__ __forceinline__ void load(const float* __restrict__ packed) {
         const int lane = threadIdx.x & 63;
         const uint32_t* pu = reinterpret_cast<const uint32_t*>(packed);
 #pragma unroll
-        for (int v = 0; v < 36; ++v) A[v] = pu[v * 64 + lane];
+        for (int v = 0; v < BW_BR; ++v) A[v] = pu[v * 64 + lane];
 #pragma unroll
-        for (int v = 0; v < 24; ++v) B[v] = packed[(36 + v) * 64 + lane];
+        for (int v = 0; v < BW_REGS - BW_BR; ++v) B[v] = packed[(BW_BR + v) * 64 + lane];
     }
-    __device__ __forceinline__ float h0(int r) const { return B[BW_H0 - 36 + r]; }
+    __device__ __forceinline__ float h0(int r) const { return B[BW_H0 - BW_BR + r]; }
     __device__ __forceinline__ bf16x8 a_op(int base) const {
         const dwordx4 u = {A[base], A[base + 1], A[base + 2], A[base + 3]};
         return __builtin_bit_cast(bf16x8, u);
@@ -584,10 +564,10 @@ struct ActorBF16 {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, B[BW_BR - 36 + r])));
-                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, B[BW_BZ - 36 + r])));
+                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, B[BW_BR - BW_BR + r])));
+                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, B[BW_BZ - BW_BR + r])));
                 const float u = fmaf(rr, gnh[t][r], gni[t][r]);
-                const float v = fmaf(rr, B[BW_BNH - 36 + r], B[BW_BNI - 36 + r]);
+                const float v = fmaf(rr, B[BW_BNH - BW_BR + r], B[BW_BNI - BW_BR + r]);
                 const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
                 hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
             }
@@ -599,7 +579,7 @@ struct ActorBF16 {
             else       d0 = mfma(a_op(BW_L2 + 4 * t), hb, d0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + B[BW_B2 - 36 + r];
+        for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + B[BW_B2 - BW_BR + r];
     }
 };
 

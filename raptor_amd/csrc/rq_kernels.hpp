@@ -101,9 +101,36 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 const float* packed, StatsPtrs st, int precision, TrajPtrs traj);
 // chained mode: copy step t (env obs/action buffers + last reward / done code) into the trajectory
 hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* act, StatsPtrs st, TrajPtrs traj);
+// ---- MFMA operand images of the policy (layout rationale: rq_device_math.hpp "actor") ----------
+// lane l = (q = l >> 4, j = l & 15); one image = 64 dwords, one per lane.
+// f32 actor (v_mfma_f32_16x16x4_f32): one float image per A operand / bias vector
+enum {
+    QW_L0 = 0,    //  6: layer_0, K-step s: lane (q,j) = W0[j][4s+q]; input 22 -> b0[j], input 23 -> 0
+    QW_GI = 6,    // 12: W_input,  [m][s]: lane (q,j) = Wi[16m+j][4q+s]
+    QW_GH = 18,   // 12: W_hidden, [m][s]: lane (q,j) = Wh[16m+j][4q+s]
+    QW_L2 = 30,   // 16: layer_2,  [t][s]: lane (q,j) = (j>>2 == t) ? W2[j&3][4q+s] : 0
+    // biases never occupy an MFMA C operand (that costs a 4-register copy per chain): layer_0's
+    // bias rides in the spare K slot 22 (its B operand is the constant 1), the gate biases are
+    // folded, pre-scaled, into the fma that feeds v_exp_f32, layer_2's is added after the MFMAs
+    QW_BR = 46,   //  4: [r]: -log2(e)  * (bi[4q+r] + bh[4q+r])
+    QW_BZ = 50,   //  4: [r]: -log2(e)  * (bi[16+4q+r] + bh[16+4q+r])
+    QW_BNI = 54,  //  4: [r]: -2log2(e) * bi[32+4q+r]
+    QW_BNH = 58,  //  4: [r]: -2log2(e) * bh[32+4q+r]
+    QW_H0 = 62,   //  4: [r]: initial_hidden_state[4q+r]
+    QW_B2 = 66,   //  4: [r]: b2[r] on every lane
+    QW_REGS = 70
+};
+// bf16 actor (v_mfma_f32_16x16x32_bf16): A operands are bf16x8 = 4 dword images each, element e of
+// lane (q, i) in the low/high half of dword e/2; biases as in the f32 image
+enum {
+    BW_L0 = 0, BW_R = 4, BW_Z = 8, BW_NI = 12, BW_NH = 16, BW_L2 = 20,   // bf16x8 A operands, 4 dwords each
+    BW_BR = 36, BW_BZ = 40, BW_BNI = 44, BW_BNH = 48, BW_H0 = 52, BW_B2 = 56,   // fp32, as in the f32 image
+    BW_REGS = 60
+};
+
 // Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
 // v_mfma_f32_16x16x4_f32 instructions read as A / C operands (layout: rq_device_math.hpp "actor").
-enum { RQ_PACKED_REGS = 70, RQ_PACKED_FLOATS = 70 * 64, RQ_PACKED_BF16_REGS = 60, RQ_PACKED_BF16_FLOATS = 60 * 64 };
+enum { RQ_PACKED_FLOATS = QW_REGS * 64, RQ_PACKED_BF16_FLOATS = BW_REGS * 64 };
 void pack_policy(const float* weights, float* packed);
 // the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
 void pack_policy_bf16(const float* weights, float* packed);
