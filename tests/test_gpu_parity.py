@@ -330,6 +330,40 @@ def test_step_in_place_equals_out_of_place(device, oracle):
     assert np.array_equal(w.state.numpy(), out)
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_randomised_configs_step_observe_bit_exact(device, oracle, case):
+    """Fuzz over the MDP configuration (dt, gravity, limits, reward weights, thresholds, disturbances,
+    batch size incl. ragged tails): params / observe / 30 chained transitions stay bit-identical."""
+    r = np.random.default_rng(1000 + case)
+    n = int(r.choice([1, 7, 64, 65, 129, 640, 1000, 4097]))
+    over = dict(dt=float(r.choice([0.002, 0.005, 0.01, 0.02])), gravity=float(r.uniform(1.0, 12.0)),
+                episode_step_limit=int(r.integers(3, 40)), domain_randomization=int(r.integers(0, 2)),
+                dr_scale_min=float(r.uniform(0.4, 1.0)), dr_scale_max=float(r.uniform(1.5, 9.0)),
+                init_guidance=float(r.uniform(0, 1)), init_max_position=float(r.uniform(0.1, 2.0)),
+                disturbance_force_std=float(r.choice([0.0, 0.05])), disturbance_torque_std=float(r.choice([0.0, 0.02])),
+                reward_scale=float(r.uniform(0.1, 2)), reward_constant=float(r.uniform(0, 2)),
+                reward_termination_penalty=float(r.uniform(-5, 0)), reward_action=float(r.uniform(0, 1)),
+                termination_enabled=int(r.integers(0, 2)), termination_position=float(r.uniform(0.3, 3.0)),
+                termination_linear_velocity=float(r.uniform(1.0, 100.0)),
+                termination_angular_velocity=float(r.uniform(5.0, 100.0)))
+    w = World(device, oracle, n, seed=int(r.integers(0, 2 ** 40)), offset=int(r.integers(0, 2 ** 34)), **over)
+    assert np.array_equal(w.params.numpy(), w.P)
+    w.sync_oracle_to_gpu_state()
+    obs = np.zeros((n, 26), np.float32)
+    for t in range(30):
+        w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+        assert np.array_equal(obs, oracle.observe(w.cfg, w.seed, t, w.offset, w.P, w.S))
+        act = r.uniform(-1.3, 1.3, (n, 4)).astype(np.float32)
+        w.vector.step(device, w.env, w.params, w.state, act, w.state, w.rng)
+        w.S, rew, term = oracle.step(w.cfg, w.P, w.S, act)
+        oracle.stats_update(w.cfg, rew, term, w.st)
+        assert np.array_equal(w.state.numpy(), w.S, equal_nan=True)
+        assert np.array_equal(w.env.rewards(), rew, equal_nan=True) and np.array_equal(w.env.terminated(), term)
+    assert np.array_equal(w.env.finished_counts(), w.st.fin_counts)
+    assert np.array_equal(w.env.finished_lengths(), w.st.fin_lengths)
+    assert np.array_equal(w.env.finished_returns(), w.st.fin_returns, equal_nan=True)
+
+
 # ------------------------------------------------------------------------------ loops ------
 def test_readme_loop_runs_as_written(device):
     """README.md:41-101 with the module names swapped; N = 8 (vector8), 500 steps."""
