@@ -164,6 +164,8 @@ def api_loop_probe(device, n=8, iters=500):
     policy = Raptor(device)
     observation = np.zeros((env.N_ENVIRONMENTS, env.OBSERVATION_DIM), dtype=np.float32)
     out = {}
+    import gc
+    gc.collect()      # free the previous probes' device buffers now, not inside the timed loop
     for name in ("numpy_arrays", "device_resident"):
         policy.reset()
         t0 = None
