@@ -393,7 +393,8 @@ __device__ __forceinline__ void transpose4(float& n0, float& n1, float& n2, floa
 
 // One recurrent step for the 64 envs of this wave.  o: native observation; hQ[t][r]: hidden state
 // in the Q layout, updated in place; a: native action.  Wave-uniform control flow required.
-struct ActorF32 {
+template <bool LEAN>
+struct ActorF32T {
     static constexpr int kPackedRegs = QW_REGS;
     float W[QW_REGS];
 
@@ -431,44 +432,52 @@ struct ActorF32 {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y0[t][r] = fmaxf(y0[t][r], 0.0f);
 
-        f32x4 gr[4], gz[4], gni[4], gnh[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            gr[t] = mfma16(W[QW_GI + 0], y0[t][0], zero);
-            gz[t] = mfma16(W[QW_GI + 4], y0[t][0], zero);
-            gni[t] = mfma16(W[QW_GI + 8], y0[t][0], zero);
-            gnh[t] = mfma16(W[QW_GH + 8], hQ[t][0], zero);
-        }
-#pragma unroll
-        for (int s = 1; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                gr[t] = mfma16(W[QW_GI + 0 + s], y0[t][s], gr[t]);
-                gz[t] = mfma16(W[QW_GI + 4 + s], y0[t][s], gz[t]);
-                gni[t] = mfma16(W[QW_GI + 8 + s], y0[t][s], gni[t]);
-                gnh[t] = mfma16(W[QW_GH + 8 + s], hQ[t][s], gnh[t]);
-            }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                gr[t] = mfma16(W[QW_GH + 0 + s], hQ[t][s], gr[t]);
-                gz[t] = mfma16(W[QW_GH + 4 + s], hQ[t][s], gz[t]);
-            }
-        // gates: sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2log2e)) - 1,
-        // with the pre-scaled biases b' of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each)
+        // GRU, two tiles at a time (TILES_PER_PASS): 4 accumulators per tile are live per pass, so the
+        // LEAN variant (2 waves/SIMD, 256 registers) halves the accumulator footprint; the arithmetic and
+        // its order per tile are identical in both variants
         constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+        constexpr int TP = LEAN ? 2 : 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t0 = 0; t0 < 4; t0 += TP) {
+            f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, W[QW_BR + r])));
-                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, W[QW_BZ + r])));
-                const float u = fmaf(rr, gnh[t][r], gni[t][r]);
-                const float v = fmaf(rr, W[QW_BNH + r], W[QW_BNI + r]);
-                const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
-                hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
+            for (int u = 0; u < TP; ++u) {
+                gr[u] = mfma16(W[QW_GI + 0], y0[t0 + u][0], zero);
+                gz[u] = mfma16(W[QW_GI + 4], y0[t0 + u][0], zero);
+                gni[u] = mfma16(W[QW_GI + 8], y0[t0 + u][0], zero);
+                gnh[u] = mfma16(W[QW_GH + 8], hQ[t0 + u][0], zero);
             }
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    gr[u] = mfma16(W[QW_GI + 0 + s], y0[t0 + u][s], gr[u]);
+                    gz[u] = mfma16(W[QW_GI + 4 + s], y0[t0 + u][s], gz[u]);
+                    gni[u] = mfma16(W[QW_GI + 8 + s], y0[t0 + u][s], gni[u]);
+                    gnh[u] = mfma16(W[QW_GH + 8 + s], hQ[t0 + u][s], gnh[u]);
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
+                    gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
+                }
+            // gates: sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2log2e)) - 1,
+            // with the pre-scaled biases b' of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each)
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[u][r], kS, W[QW_BR + r])));
+                    const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[u][r], kS, W[QW_BZ + r])));
+                    const float uu = fmaf(rr, gnh[u][r], gni[u][r]);
+                    const float vv = fmaf(rr, W[QW_BNH + r], W[QW_BNI + r]);
+                    const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(uu, kT, vv))), -1.0f);
+                    hQ[t0 + u][r] = fmaf(zz, hQ[t0 + u][r] - nn, nn);
+                }
+            if (LEAN) __builtin_amdgcn_sched_barrier(0);   // keep the two passes apart (register footprint)
+        }
         // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
         f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], zero);
         f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
@@ -486,6 +495,9 @@ struct ActorF32 {
     }
 };
 
+
+typedef ActorF32T<false> ActorF32;       // 1 wave/SIMD: all 512 registers, all four tiles in flight
+typedef ActorF32T<true> ActorF32Lean;    // 2 waves/SIMD (batches >= 131 072 envs): 256 registers
 
 // ---- bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 gates (BASELINE config 5) -----
 // Same Q layout and the same register-stationary scheme; K = 32 per instruction and lane-group q

@@ -191,8 +191,11 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // Control flow is wave-uniform around the MFMAs (see k_actor_step): lanes past the end of the
 // batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
 // the rare auto-reset branch (no MFMA inside) diverges.
+template <typename A> struct WavesPerSimd { static constexpr int value = 1; };
+template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; };
+
 template <bool NOISE, bool AUTORESET, bool RECORD, typename ACTOR>
-__global__ __launch_bounds__(kFusedBlock) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
+__global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
                                                                uint64_t seed, uint32_t epoch0, uint32_t n_steps,
                                                                const float* __restrict__ params,
                                                                float* __restrict__ state,
@@ -406,7 +409,10 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     const bool rec = traj.obs != nullptr;
     const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
     precision &= 0xff;
+    // one wave per SIMD up to 65 536 envs (1024 SIMDs x 64 lanes); beyond that the register-lean variant
+    // lets two waves share a SIMD and hide each other's VALU latency
     if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_ACT(ActorBF16);
+    else if (b.n >= 131072)               RQ_LAUNCH_FUSED_ACT(ActorF32Lean);
     else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
 #undef RQ_LAUNCH_FUSED_RC
 #undef RQ_LAUNCH_FUSED_ACT
