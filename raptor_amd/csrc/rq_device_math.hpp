@@ -595,6 +595,8 @@ struct ActorBF16 {
     }
 };
 
+struct ActorBF16Lean : ActorBF16 {};     // same arithmetic, compiled for 2 waves/SIMD (batches >= 131 072 envs)
+
 // Optional output stage (SampleAndSquash in inference mode: tanh of the mean
 // head; NOT part of the shipped checkpoint, semantics unpinned): a <- tanh(a).
 __device__ __forceinline__ void squash_action(float (&a)[4]) {

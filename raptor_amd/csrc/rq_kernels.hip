@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // the rare auto-reset branch (no MFMA inside) diverges.
 template <typename A> struct WavesPerSimd { static constexpr int value = 1; };
 template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; };
+template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; };
 
 template <bool NOISE, bool AUTORESET, bool RECORD, typename ACTOR>
 __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
@@ -411,7 +412,9 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     precision &= 0xff;
     // one wave per SIMD up to 65 536 envs (1024 SIMDs x 64 lanes); beyond that the register-lean variant
     // lets two waves share a SIMD and hide each other's VALU latency
-    if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_ACT(ActorBF16);
+    if (precision == RQ_POLICY_BF16_MFMA) {
+        if (b.n >= 131072) RQ_LAUNCH_FUSED_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_ACT(ActorBF16);
+    }
     else if (b.n >= 131072)               RQ_LAUNCH_FUSED_ACT(ActorF32Lean);
     else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
 #undef RQ_LAUNCH_FUSED_RC
