@@ -336,6 +336,22 @@ __device__ __forceinline__ void sample_state(const SampleCfg& c, uint64_t seed, 
     }
 }
 
+// Out-of-line variant for the fused kernel: an episode end is rare (about once per 500 steps per
+// env), so the re-sampling code (6 Philox blocks, sin/cos, Box-Muller) is kept out of the hot
+// loop's register allocation; out = [y(17), last_action(4), disturbance(6)].
+__device__ __attribute__((noinline)) void sample_state_outlined(const SampleCfg c, uint64_t seed, uint32_t episode,
+                                                                 uint64_t genv, float mass, float hover_rpm,
+                                                                 float pos0x, float pos0y, float* __restrict__ out) {
+    float s[17], la[4], f[6];
+    sample_state(c, seed, episode, genv, mass, hover_rpm, pos0x, pos0y, s, la, f);
+#pragma unroll
+    for (int i = 0; i < 17; ++i) out[i] = s[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[17 + i] = la[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out[21 + i] = f[i];
+}
+
 // ------------------------------------------------------------------ actor --------------
 // flat weight vector offsets (order of checkpoint.h:39,50,75,87,99,111,123,149,160)
 enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF_BH = 1952,

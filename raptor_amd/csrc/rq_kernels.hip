@@ -274,9 +274,17 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             if (ended) {
                 any_end = true;
                 if (AUTORESET) {
-                    sample_state(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
-                                 params[(size_t)RQ_P_HOVER_RPM * ld + i], params[(size_t)RQ_P_ROTOR_POS * ld + i],
-                                 params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], y, la, f6);
+                    float fresh[27];
+                    sample_state_outlined(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
+                                          params[(size_t)RQ_P_HOVER_RPM * ld + i],
+                                          params[(size_t)RQ_P_ROTOR_POS * ld + i],
+                                          params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], fresh);
+#pragma unroll
+                    for (int j = 0; j < 17; ++j) y[j] = fresh[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) la[j] = fresh[17 + j];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) f6[j] = fresh[21 + j];
                     ep += 1;
                     ds = make_disturbance(k, c.gravity, f6);
                     dist_changed = true;
