@@ -208,8 +208,8 @@ def cpu_baseline(seconds):
         return n * steps / (time.perf_counter() - t0)
 
     rate = run(max(64 * threads, 1024), 100)                 # calibration
-    n = int(min(ENVS_PER_GPU, max(1024, 64 * threads)))
-    steps = int(max(100, min(2000, rate * seconds / n)))
+    n = ENVS_PER_GPU                                          # the bench's own batch
+    steps = int(max(20, min(2000, rate * seconds / n)))       # ~`seconds` of wall time on all host cores
     value = run(n, steps)
     return {"value": round(value, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} envs x {steps} steps of the same workload (domain-randomised, auto-reset), "
