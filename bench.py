@@ -210,8 +210,11 @@ def cpu_baseline(seconds):
     rate = run(max(64 * threads, 1024), 100)                 # calibration
     n = ENVS_PER_GPU                                          # the bench's own batch
     steps = int(max(20, min(2000, rate * seconds / n)))       # ~`seconds` of wall time on all host cores
+    c0, t0 = time.process_time(), time.perf_counter()
     value = run(n, steps)
+    busy = (time.process_time() - c0) / (time.perf_counter() - t0)   # CPU-seconds per wall-second
     return {"value": round(value, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "effective_cores": round(busy, 1),      # < cores when the container's CPU quota is below its thread count
             "sample": f"{n} envs x {steps} steps of the same workload (domain-randomised, auto-reset), "
                       f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads} threads"}
 
