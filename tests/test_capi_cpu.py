@@ -115,3 +115,18 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     if not HAS_GPU:
         run = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
         assert run.returncode == 1 and "no HIP device" in run.stderr      # loud, not a crash
+
+
+def test_cpp_wrapper_example_links(tmp_path):
+    """include/raptor_quad.hpp (header-only C++17 layer with the reference's free-function shape)."""
+    import subprocess
+    pkg = os.path.join(ROOT, "raptor_amd")
+    exe = str(tmp_path / "readme_loop_cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "readme_loop.cpp"),
+                        "-L" + pkg, "-lraptor_quad", "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if not HAS_GPU:
+        run = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
+        assert run.returncode == 1 and "no HIP device" in run.stderr

@@ -685,6 +685,20 @@ def test_c_example_runs_on_the_gpu(tmp_path):
     assert np.median(np.linalg.norm(pos, axis=1)) < 0.2
 
 
+def test_cpp_wrapper_example_runs_on_the_gpu(tmp_path):
+    import os
+    import subprocess
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "raptor_amd")
+    exe = str(tmp_path / "readme_loop_cpp")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "readme_loop.cpp"), "-L" + pkg, "-lraptor_quad",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert float(r.stdout.split("=")[1].split()[0]) < 1.0
+
+
 def test_policy_from_checkpoint_header(device, weights, kat, tmp_path):
     from raptor_amd.checkpoint import write_checkpoint_header
     from raptor_amd.foundation_policy import Raptor
