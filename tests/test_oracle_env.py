@@ -252,6 +252,75 @@ def test_step_matches_independent_float64_integration(oracle, dr):
         assert err_fine.max() < 1e-3, (i, err_fine)
 
 
+def _yaw(psi):
+    c, s_ = np.cos(psi), np.sin(psi)
+    return np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]), np.array([np.cos(psi / 2), 0, 0, np.sin(psi / 2)])
+
+
+def _qmul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def test_dynamics_are_equivariant_under_world_yaw(oracle):
+    """Physics does not care about the world heading: rotating the initial state about the world z axis
+    (p, v rotate, q gets the yaw quaternion on the left, body-frame w unchanged) and stepping must give
+    the rotated result.  Pins the frame conventions (world-frame p, v; body-frame w; body->world q)."""
+    cfg, P, S, _ = _setup(oracle, dr=1, n=64, init_guidance=0.0, seed=21)
+    cfg.termination_enabled = 0
+    a = np.random.default_rng(0).uniform(-1, 1, (64, 4)).astype(np.float32)
+    psi = 0.7
+    Rz, qz = _yaw(psi)
+    S2 = S.copy()
+    S2[:, 0:3] = S[:, 0:3] @ Rz.T
+    S2[:, 7:10] = S[:, 7:10] @ Rz.T
+    S2[:, 3:7] = np.array([_qmul(qz, q) for q in S[:, 3:7]])
+    s1, s2 = S.copy(), S2.astype(np.float32)
+    for _ in range(20):
+        s1, r1, _ = oracle.step(cfg, P, s1, a)
+        s2, r2, _ = oracle.step(cfg, P, s2, a)
+    assert np.allclose(s1[:, 0:3] @ Rz.T, s2[:, 0:3], atol=2e-4)
+    assert np.allclose(s1[:, 7:10] @ Rz.T, s2[:, 7:10], atol=2e-3)
+    assert np.allclose(s1[:, 10:17], s2[:, 10:17], rtol=1e-3, atol=1e-3)          # body rates and rotors identical
+    q_rot = np.array([_qmul(qz, q) for q in s1[:, 3:7]])
+    assert np.allclose(np.abs((q_rot * s2[:, 3:7]).sum(axis=1)), 1.0, atol=1e-4)   # same attitude (up to sign)
+    # (the reward is NOT yaw-invariant: its orientation term 1 - q_w^2 penalises heading as well)
+    # the observation rotates consistently: R_obs2 = Rz R_obs1
+    o1 = oracle.observe(cfg, 0, 0, 0, P, s1)[:, 3:12].reshape(-1, 3, 3)
+    o2 = oracle.observe(cfg, 0, 0, 0, P, s2)[:, 3:12].reshape(-1, 3, 3)
+    assert np.allclose(Rz @ o1, o2, atol=1e-3)
+
+
+def test_free_rotation_conserves_angular_momentum_and_energy(oracle):
+    """No thrust, no gravity: torque-free rigid body.  World-frame angular momentum R(q) J w and the
+    rotational energy w.J w / 2 stay constant (RK4 error only) — pins the gyroscopic term and q-dot."""
+    cfg, P, S, _ = _setup(oracle, dr=0, n=8, init_guidance=0.0, seed=5)
+    cfg.termination_enabled = 0
+    cfg.gravity = 0.0
+    P = P.copy()
+    P[:, 16:19] = 0.0                               # thrust polynomial = 0
+    P[:, 1:4] = [2.0e-5, 3.5e-5, 5.0e-5]            # an asymmetric body (tumbling)
+    S = S.copy()
+    S[:, 10:13] *= 8.0
+    J = P[0, 1:4].astype(np.float64)
+
+    def invariants(s):
+        o = oracle.observe(cfg, 0, 0, 0, P, s)[:, 3:12].reshape(-1, 3, 3).astype(np.float64)
+        w = s[:, 10:13].astype(np.float64)
+        L = np.einsum("nij,nj->ni", o, J * w)
+        return L, 0.5 * (J * w * w).sum(axis=1)
+    L0, E0 = invariants(S)
+    s = S.copy()
+    a = np.zeros((8, 4), np.float32)
+    for _ in range(200):
+        s, _, _ = oracle.step(cfg, P, s, a)
+    L1, E1 = invariants(s)
+    assert np.allclose(L1, L0, rtol=2e-3, atol=1e-9) and np.allclose(E1, E0, rtol=2e-3)
+    assert np.abs(s[:, 10:13] - S[:, 10:13]).max() > 0.5       # it did tumble
+
+
 def test_stats_and_freeze_semantics(oracle, weights):
     cfg, P, S, ep = _setup(oracle, n=64)
     cfg.episode_step_limit = 50
