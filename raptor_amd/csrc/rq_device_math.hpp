@@ -462,7 +462,7 @@ struct ActorF32T {
         // LEAN variant (2 waves/SIMD, 256 registers) halves the accumulator footprint; the arithmetic and
         // its order per tile are identical in both variants
         constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
-        constexpr int TP = LEAN ? 2 : 4;
+        constexpr int TP = LEAN ? 2 : 4;   // (measured: 1, 2 or 4 tiles per pass are within 2 % at 1 wave/SIMD)
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TP) {
             f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];
