@@ -210,11 +210,29 @@ def cpu_baseline(seconds):
     rate = run(max(64 * threads, 1024), 100)                 # calibration
     n = ENVS_PER_GPU                                          # the bench's own batch
     steps = int(max(20, min(2000, rate * seconds / n)))       # ~`seconds` of wall time on all host cores
+    # BASELINE.md section 2 side lines (all with the same C restatement): B2 = N 8, one thread, native loop;
+    # B4 = one thread on a larger batch; B1 = the README loop at N 8 driven call by call from Python
+    extras = {}
+    threads_all, threads = threads, 1
+    extras["B2_n8_1thread_env_steps_per_s"] = round(max(run(8, 500) for _ in range(3)), 1)
+    extras["B4_n1024_1thread_env_steps_per_s"] = round(run(1024, 300), 1)
+    threads = threads_all
+    P8 = O.sample_initial_parameters(cfg, 0, 0, 0, 8)
+    st8 = O.Stats(8)
+    S8 = O.sample_initial_state(cfg, 0, st8.episode, 0, P8)
+    H8 = np.zeros((8, 16), np.float32)
+    t1 = time.perf_counter()
+    for k in range(500):
+        obs = O.observe(cfg, 0, k, 0, P8, S8)
+        act = O.actor_batch_step(w, obs, H8)
+        S8, _, _ = O.step(cfg, P8, S8, act)
+    extras["B1_n8_python_loop_us_per_iteration"] = round((time.perf_counter() - t1) / 500 * 1e6, 2)
     c0, t0 = time.process_time(), time.perf_counter()
     value = run(n, steps)
     busy = (time.process_time() - c0) / (time.perf_counter() - t0)   # CPU-seconds per wall-second
     return {"value": round(value, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
             "effective_cores": round(busy, 1),      # < cores when the container's CPU quota is below its thread count
+            "extras": extras,
             "sample": f"{n} envs x {steps} steps of the same workload (domain-randomised, auto-reset), "
                       f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads} threads"}
 
