@@ -23,6 +23,10 @@ static constexpr int kFusedBlock = 64;  // 1 wave per workgroup: spreads 65 536 
 
 __device__ __forceinline__ uint32_t env_index() { return blockIdx.x * blockDim.x + threadIdx.x; }
 
+// Field f of a field-major SoA buffer: env i of the batch is element i of this row.
+template <typename T>
+__device__ __forceinline__ T* field(T* base, uint32_t f, uint32_t ld) { return base + (size_t)f * ld; }
+
 // ------------------------------------------------------------------ sampling -----------
 __global__ __launch_bounds__(kBlock) void k_sample_params(Batch b, SampleCfg c, uint64_t seed, uint32_t epoch,
                                                           float* __restrict__ params) {
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_params(Batch b, SampleCfg c, 
     float p[RQ_PARAM_DIM];
     sample_params(c, seed, epoch, b.env_offset + i, p);
 #pragma unroll
-    for (int f = 0; f < RQ_PARAM_DIM; ++f) params[(size_t)f * b.ld + i] = p[f];
+    for (int f = 0; f < RQ_PARAM_DIM; ++f) field(params, f, b.ld)[i] = p[f];
 }
 
 __global__ __launch_bounds__(kBlock) void k_sample_state(Batch b, SampleCfg c, uint64_t seed,
@@ -41,15 +45,15 @@ __global__ __launch_bounds__(kBlock) void k_sample_state(Batch b, SampleCfg c, u
     if (i >= b.n) return;
     const uint32_t ep = episode[i];
     float s[17], la[4], f[6];
-    sample_state(c, seed, ep, b.env_offset + i, params[(size_t)RQ_P_MASS * b.ld + i],
-                 params[(size_t)RQ_P_HOVER_RPM * b.ld + i], params[(size_t)RQ_P_ROTOR_POS * b.ld + i],
-                 params[(size_t)(RQ_P_ROTOR_POS + 1) * b.ld + i], s, la, f);
+    sample_state(c, seed, ep, b.env_offset + i, field(params, RQ_P_MASS, b.ld)[i],
+                 field(params, RQ_P_HOVER_RPM, b.ld)[i], field(params, RQ_P_ROTOR_POS, b.ld)[i],
+                 field(params, (RQ_P_ROTOR_POS + 1), b.ld)[i], s, la, f);
 #pragma unroll
-    for (int k = 0; k < 17; ++k) state[(size_t)k * b.ld + i] = s[k];
+    for (int k = 0; k < 17; ++k) field(state, k, b.ld)[i] = s[k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) state[(size_t)(RQ_S_LAST_ACTION + k) * b.ld + i] = la[k];
+    for (int k = 0; k < 4; ++k) field(state, (RQ_S_LAST_ACTION + k), b.ld)[i] = la[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) state[(size_t)(RQ_S_FORCE + k) * b.ld + i] = f[k];
+    for (int k = 0; k < 6; ++k) field(state, (RQ_S_FORCE + k), b.ld)[i] = f[k];
     episode[i] = ep + 1;
     frozen[i] = 0;
 }
@@ -67,19 +71,19 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
     const uint32_t epoch = epoch_offset + (epoch_base != nullptr ? *epoch_base : 0u);
     float y[17], la[4];
 #pragma unroll
-    for (int k = 0; k < 17; ++k) y[k] = state[(size_t)k * b.ld + i];
+    for (int k = 0; k < 17; ++k) y[k] = field(state, k, b.ld)[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) la[k] = state[(size_t)(RQ_S_LAST_ACTION + k) * b.ld + i];
-    const float rmin = params[(size_t)RQ_P_RPM_MIN * b.ld + i];
-    const float rmax = params[(size_t)RQ_P_RPM_MAX * b.ld + i];
+    for (int k = 0; k < 4; ++k) la[k] = field(state, (RQ_S_LAST_ACTION + k), b.ld)[i];
+    const float rmin = field(params, RQ_P_RPM_MIN, b.ld)[i];
+    const float rmax = field(params, RQ_P_RPM_MAX, b.ld)[i];
     float o[22];
     observe_head<NOISE>(y, la, nc, seed, epoch, b.env_offset + i, o);
 #pragma unroll
-    for (int k = 0; k < 22; ++k) obs[(size_t)k * b.ld + i] = o[k];
+    for (int k = 0; k < 22; ++k) field(obs, k, b.ld)[i] = o[k];
     // privileged tail: normalised rotor speeds
     const float inv = 2.0f / (rmax - rmin);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) obs[(size_t)(22 + k) * b.ld + i] = fmaf(y[13 + k] - rmin, inv, -1.0f);
+    for (int k = 0; k < 4; ++k) field(obs, (22 + k), b.ld)[i] = fmaf(y[13 + k] - rmin, inv, -1.0f);
 }
 
 // ------------------------------------------------------------------ actor --------------
@@ -107,14 +111,14 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
         const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
         float x[22], hQ[4][4], a[4];
 #pragma unroll
-        for (int k = 0; k < 22; ++k) x[k] = obs[(size_t)k * ld_obs + i];
+        for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
         load_hidden_q(hidden, ld_h, wave_base, n, hQ);
         actor.step(x, hQ, a);
         if (squash) squash_action(a);        // wave-uniform (kernel argument)
         store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
         if (commit) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) act[(size_t)k * ld_act + i] = a[k];
+            for (int k = 0; k < 4; ++k) field(act, k, ld_act)[i] = a[k];
         }
     }
 }
@@ -142,14 +146,14 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
     if (i >= b.n) return;
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
-    const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
+    const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
     float y[17], f6[6], a[4], ac[4];
 #pragma unroll
-    for (int j = 0; j < 17; ++j) y[j] = state[(size_t)j * ld + i];
+    for (int j = 0; j < 17; ++j) y[j] = field(state, j, ld)[i];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) f6[j] = state[(size_t)(RQ_S_FORCE + j) * ld + i];
+    for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = action[(size_t)j * ld + i];
+    for (int j = 0; j < 4; ++j) a[j] = field(action, j, ld)[i];
     Stats s = load_stats(st, i);
     const Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool term;
@@ -163,24 +167,24 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
     if (ROLLOUT && ended) {
         if (flags & RQ_ROLLOUT_AUTORESET) {
             const uint32_t ep = st.episode[i];
-            sample_state(sc, seed, ep, b.env_offset + i, params[(size_t)RQ_P_MASS * ld + i],
-                         params[(size_t)RQ_P_HOVER_RPM * ld + i], params[(size_t)RQ_P_ROTOR_POS * ld + i],
-                         params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], y, ac, f6);
+            sample_state(sc, seed, ep, b.env_offset + i, field(params, RQ_P_MASS, ld)[i],
+                         field(params, RQ_P_HOVER_RPM, ld)[i], field(params, RQ_P_ROTOR_POS, ld)[i],
+                         field(params, (RQ_P_ROTOR_POS + 1), ld)[i], y, ac, f6);
             st.episode[i] = ep + 1;
             write_dist = true;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) hidden[(size_t)j * ld + i] = weights[OFF_H0 + j];
+            for (int j = 0; j < 16; ++j) field(hidden, j, ld)[i] = weights[OFF_H0 + j];
         } else {
             st.frozen[i] = 1;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 17; ++j) next_state[(size_t)j * ld + i] = y[j];
+    for (int j = 0; j < 17; ++j) field(next_state, j, ld)[i] = y[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) next_state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i] = ac[j];
+    for (int j = 0; j < 4; ++j) field(next_state, (RQ_S_LAST_ACTION + j), ld)[i] = ac[j];
     if (write_dist) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) next_state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
+        for (int j = 0; j < 6; ++j) field(next_state, (RQ_S_FORCE + j), ld)[i] = f6[j];
     }
 }
 
@@ -212,14 +216,14 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     const bool valid = i0 < b.n;
     const size_t ld = b.ld;
     const uint64_t genv = b.env_offset + i;
-    const EnvConsts k = make_consts([&](int f) { return params[(size_t)f * ld + i]; });
+    const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
     float y[17], la[4], f6[6], hQ[4][4];
 #pragma unroll
-    for (int j = 0; j < 17; ++j) y[j] = state[(size_t)j * ld + i];
+    for (int j = 0; j < 17; ++j) y[j] = field(state, j, ld)[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) la[j] = state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i];
+    for (int j = 0; j < 4; ++j) la[j] = field(state, (RQ_S_LAST_ACTION + j), ld)[i];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) f6[j] = state[(size_t)(RQ_S_FORCE + j) * ld + i];
+    for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
     load_hidden_q(hidden, ld, wave_base, b.n, hQ);
     float h0Q[4][4];
 #pragma unroll
@@ -275,10 +279,10 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
                 any_end = true;
                 if (AUTORESET) {
                     float fresh[27];
-                    sample_state_outlined(sc, seed, ep, genv, params[(size_t)RQ_P_MASS * ld + i],
-                                          params[(size_t)RQ_P_HOVER_RPM * ld + i],
-                                          params[(size_t)RQ_P_ROTOR_POS * ld + i],
-                                          params[(size_t)(RQ_P_ROTOR_POS + 1) * ld + i], fresh);
+                    sample_state_outlined(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i],
+                                          field(params, RQ_P_HOVER_RPM, ld)[i],
+                                          field(params, RQ_P_ROTOR_POS, ld)[i],
+                                          field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh);
 #pragma unroll
                     for (int j = 0; j < 17; ++j) y[j] = fresh[j];
 #pragma unroll
@@ -310,12 +314,12 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
 
     if (valid && !was_frozen) {
 #pragma unroll
-        for (int j = 0; j < 17; ++j) state[(size_t)j * ld + i] = y[j];
+        for (int j = 0; j < 17; ++j) field(state, j, ld)[i] = y[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) state[(size_t)(RQ_S_LAST_ACTION + j) * ld + i] = la[j];
+        for (int j = 0; j < 4; ++j) field(state, (RQ_S_LAST_ACTION + j), ld)[i] = la[j];
         if (dist_changed) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) state[(size_t)(RQ_S_FORCE + j) * ld + i] = f6[j];
+            for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), ld)[i] = f6[j];
         }
         store_stats(st, i, s, any_end);
         st.last_reward[i] = last_r;
@@ -437,9 +441,9 @@ __global__ __launch_bounds__(kBlock) void k_record(Batch b, const float* __restr
     if (i >= b.n) return;
     const size_t ld = b.ld, tt = traj.t0;
 #pragma unroll
-    for (int j = 0; j < 22; ++j) traj.obs[(tt * 22 + j) * ld + i] = obs[(size_t)j * ld + i];
+    for (int j = 0; j < 22; ++j) traj.obs[(tt * 22 + j) * ld + i] = field(obs, j, ld)[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) traj.act[(tt * 4 + j) * ld + i] = act[(size_t)j * ld + i];
+    for (int j = 0; j < 4; ++j) traj.act[(tt * 4 + j) * ld + i] = field(act, j, ld)[i];
     traj.rew[tt * ld + i] = st.last_reward[i];
     traj.done[tt * ld + i] = st.last_done[i];
 }
