@@ -397,6 +397,49 @@ enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF
 // Packed weight image: enum QW_* in rq_kernels.hpp (shared with the host-side packer rq_pack.cpp).
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// max(x, 0) in ONE instruction (v_max_i32 on the bit pattern: non-negative floats order like ints, every
+// negative float and -0 is a negative int).  fmaxf() on an MFMA result costs two: the compiler first
+// canonicalises a value of unknown provenance with v_max_f32 x, x, x.  Differs from fmaxf only for a
+// NaN input (kept, not turned into 0).  Not inline asm: the compiler inserts the MFMA -> VALU wait
+// states only for instructions it can see.
+__device__ __forceinline__ float relu(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// two-wide fp32 helpers (v_pk_fma_f32 and friends; the transcendentals have no packed form)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_exp2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
+__device__ __forceinline__ f32x2 pk_rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
+
+// GRU state update of one tile in the Q layout (4 rows per lane): h <- (1 - z) n + z h with
+//   r = sigma(gr + b_r), z = sigma(gz + b_z), n = tanh(gni + b_ni + r (gnh + b_nh)),
+// sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2 log2e)) - 1, b' = the pre-scaled
+// biases of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each).  Rows go in pairs through
+// v_pk_fma_f32 / v_pk_add_f32: a lone wave issues one VALU instruction per ~4.7 cycles whatever its width
+// (tools/overlap.hip), so a packed op is a free second lane of arithmetic; per element the operations and
+// their order are the scalar ones.  br/bz/bni/bnh point at 4 consecutive bias registers each.
+__device__ __forceinline__ void gru_gates_q(const f32x4& gr, const f32x4& gz, const f32x4& gni, const f32x4& gnh,
+                                            const float* br, const float* bz, const float* bni, const float* bnh,
+                                            float (&h)[4]) {
+    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+    const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f}, kS2 = {kS, kS}, kT2 = {kT, kT};
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const f32x2 xr = pk_fma(f32x2{gr[r], gr[r + 1]}, kS2, f32x2{br[r], br[r + 1]});
+        const f32x2 xz = pk_fma(f32x2{gz[r], gz[r + 1]}, kS2, f32x2{bz[r], bz[r + 1]});
+        const f32x2 rr = pk_rcp(one + pk_exp2(xr));
+        const f32x2 zz = pk_rcp(one + pk_exp2(xz));
+        const f32x2 uu = pk_fma(rr, f32x2{gnh[r], gnh[r + 1]}, f32x2{gni[r], gni[r + 1]});
+        const f32x2 vv = pk_fma(rr, f32x2{bnh[r], bnh[r + 1]}, f32x2{bni[r], bni[r + 1]});
+        const f32x2 nn = pk_fma(two, pk_rcp(one + pk_exp2(pk_fma(uu, kT2, vv))), -one);
+        const f32x2 hn = pk_fma(zz, f32x2{h[r], h[r + 1]} - nn, nn);
+        h[r] = hn[0];
+        h[r + 1] = hn[1];
+    }
+}
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -456,12 +499,11 @@ struct ActorF32T {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y0[t][r] = fmaxf(y0[t][r], 0.0f);
+            for (int r = 0; r < 4; ++r) y0[t][r] = relu(y0[t][r]);
 
         // GRU, two tiles at a time (TILES_PER_PASS): 4 accumulators per tile are live per pass, so the
         // LEAN variant (2 waves/SIMD, 256 registers) halves the accumulator footprint; the arithmetic and
         // its order per tile are identical in both variants
-        constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
         constexpr int TP = LEAN ? 2 : 4;   // (measured: 1, 2 or 4 tiles per pass are within 2 % at 1 wave/SIMD)
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TP) {
@@ -489,19 +531,9 @@ struct ActorF32T {
                     gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
                     gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
                 }
-            // gates: sigma(x + b) = 1 / (1 + 2^(x * -log2e + b')), tanh(u) = 2 / (1 + 2^(u * -2log2e)) - 1,
-            // with the pre-scaled biases b' of the packed image (v_exp_f32 / v_rcp_f32, 1 ulp each)
 #pragma unroll
             for (int u = 0; u < TP; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[u][r], kS, W[QW_BR + r])));
-                    const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[u][r], kS, W[QW_BZ + r])));
-                    const float uu = fmaf(rr, gnh[u][r], gni[u][r]);
-                    const float vv = fmaf(rr, W[QW_BNH + r], W[QW_BNI + r]);
-                    const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(uu, kT, vv))), -1.0f);
-                    hQ[t0 + u][r] = fmaf(zz, hQ[t0 + u][r] - nn, nn);
-                }
+                gru_gates_q(gr[u], gz[u], gni[u], gnh[u], &W[QW_BR], &W[QW_BZ], &W[QW_BNI], &W[QW_BNH], hQ[t0 + u]);
             if (LEAN) __builtin_amdgcn_sched_barrier(0);   // keep the two passes apart (register footprint)
         }
         // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
@@ -590,25 +622,17 @@ struct ActorBF16 {
             y0[t] = mfma(wl0, pack_bf16x8(X[0][t], X[1][t], X[2][t], X[3][t], X[4][t], X[5][t], 0.f, 0.f), zero);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8 xh = pack_bf16x8(fmaxf(y0[t][0], 0.f), fmaxf(y0[t][1], 0.f), fmaxf(y0[t][2], 0.f),
-                                          fmaxf(y0[t][3], 0.f), hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3]);
+            const bf16x8 xh = pack_bf16x8(relu(y0[t][0]), relu(y0[t][1]), relu(y0[t][2]),
+                                          relu(y0[t][3]), hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3]);
             gr[t] = mfma(wr, xh, zero);
             gz[t] = mfma(wz, xh, zero);
             gni[t] = mfma(wni, xh, zero);
             gnh[t] = mfma(wnh, xh, zero);
         }
-        constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gr[t][r], kS, B[BW_BR - BW_BR + r])));
-                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(gz[t][r], kS, B[BW_BZ - BW_BR + r])));
-                const float u = fmaf(rr, gnh[t][r], gni[t][r]);
-                const float v = fmaf(rr, B[BW_BNH - BW_BR + r], B[BW_BNI - BW_BR + r]);
-                const float nn = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(u, kT, v))), -1.0f);
-                hQ[t][r] = fmaf(zz, hQ[t][r] - nn, nn);
-            }
+            gru_gates_q(gr[t], gz[t], gni[t], gnh[t], &B[BW_BR - BW_BR], &B[BW_BZ - BW_BR], &B[BW_BNI - BW_BR],
+                        &B[BW_BNH - BW_BR], hQ[t]);
         f32x4 d0 = zero, d1 = zero;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
