@@ -321,6 +321,39 @@ def test_step_termination_masks_and_nan(device, oracle):
     assert np.array_equal(w.env.finished_terminated(), term.astype(np.uint32))
 
 
+def test_step_termination_flag_every_component_nonfinite_or_over_threshold(device, oracle):
+    """The HIP step derives `terminated` from NaN-propagating group maxima (v_maximum3_f32); the oracle
+    tests every component on its own.  One env per (component, poison) pair: NaN, +inf, -inf, a huge finite
+    value and values just under / over each threshold, alone and next to a NaN neighbour."""
+    poisons = [np.nan, np.inf, -np.inf, 3.0e38, -3.0e38]
+    cases = [(f, v) for f in range(17) for v in poisons]
+    thr = {0: 3.0, 1: 3.0, 2: 3.0, 7: 1000.0, 8: 1000.0, 9: 1000.0, 10: 1000.0, 11: 1000.0, 12: 1000.0}
+    n = 64 * ((len(cases) + 4 * len(thr) + 63) // 64)
+    w = World(device, oracle, n, domain_randomization=0, init_guidance=1.0)
+    cfg = w.cfg
+    thr = {f: (cfg.termination_position if f < 3 else cfg.termination_linear_velocity if f < 10
+               else cfg.termination_angular_velocity) for f in thr}
+    S = w.state.numpy()
+    S[:, 0:3] = 0.0; S[:, 7:13] = 0.0          # hover at the origin: one step moves nothing past a threshold
+    e = 0
+    for f, v in cases:
+        S[e, f] = v; e += 1
+    for f, t in thr.items():                   # threshold edges: x(t+dt) = x(t) + O(dt) for these fields
+        for scale, nan_neighbour in ((0.9, False), (1.1, False), (1.1, True), (-1.1, False)):
+            S[e, f] = t * scale
+            if nan_neighbour:
+                S[e, f + 1 if f % 3 != 2 and f != 12 else f - 1] = np.nan
+            e += 1
+    w.state.set(S)
+    act = np.tile(w.P[:, 25:26], (1, 4)).astype(np.float32)
+    w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+    ns, r, term = oracle.step(w.cfg, w.P, S, act)
+    assert 0 < term[:e].sum() and term[e:].sum() == 0
+    assert np.array_equal(w.env.terminated(), term)
+    assert np.array_equal(w.env.rewards(), r, equal_nan=True)
+    assert np.array_equal(w.next_state.numpy(), ns, equal_nan=True)
+
+
 def test_step_in_place_equals_out_of_place(device, oracle):
     w = World(device, oracle, 300, seed=2)
     act = np.random.default_rng(1).uniform(-1, 1, (300, 4)).astype(np.float32)
