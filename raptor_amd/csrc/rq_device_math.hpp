@@ -567,8 +567,8 @@ struct ActorF32T {
 };
 
 
-typedef ActorF32T<false> ActorF32;       // 1 wave/SIMD: all 512 registers, all four tiles in flight
-typedef ActorF32T<true> ActorF32Lean;    // 2 waves/SIMD (batches >= 131 072 envs): 256 registers
+typedef ActorF32T<false> ActorF32;       // 512-register budget (1 wave/SIMD), all four tiles in flight
+typedef ActorF32T<true> ActorF32Lean;    // 256-register budget (2 waves/SIMD); which one runs: launch_rollout_fused
 
 // ---- bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 gates (BASELINE config 5) -----
 // Same Q layout and the same register-stationary scheme; K = 32 per instruction and lane-group q
@@ -658,7 +658,7 @@ struct ActorBF16 {
     }
 };
 
-struct ActorBF16Lean : ActorBF16 {};     // same arithmetic, compiled for 2 waves/SIMD (batches >= 131 072 envs)
+struct ActorBF16Lean : ActorBF16 {};     // same arithmetic, compiled for 2 waves/SIMD (batches > 65 536 envs)
 
 // Optional output stage (SampleAndSquash in inference mode: tanh of the mean
 // head; NOT part of the shipped checkpoint, semantics unpinned): a <- tanh(a).

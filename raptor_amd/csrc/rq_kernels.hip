@@ -422,12 +422,17 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     const bool rec = traj.obs != nullptr;
     const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
     precision &= 0xff;
-    // one wave per SIMD up to 65 536 envs (1024 SIMDs x 64 lanes); beyond that the register-lean variant
-    // lets two waves share a SIMD and hide each other's VALU latency
+    // Two builds of the same loop: a 512-register one (one wave per SIMD) and a 256-register "lean" one
+    // (two waves per SIMD, GRU two tiles at a time).  Beyond 65 536 envs (1024 SIMDs x 64 lanes) the lean
+    // build wins because two waves share a SIMD.  For the fp32 actor it also wins at one wave per SIMD
+    // (measured 3.67 vs 3.80 us/step at 65 536 envs: under the tighter budget the allocator stops parking
+    // MFMA operands in AGPRs and copying them back, ~85 fewer vector instructions per step) but costs
+    // ~6 us more per launch, so short launches keep the 512-register build.  bf16: the reverse at <= 65 536.
+    const bool lean = b.n > 65536u || (precision != RQ_POLICY_BF16_MFMA && n_steps >= 48u);
     if (precision == RQ_POLICY_BF16_MFMA) {
-        if (b.n >= 131072) RQ_LAUNCH_FUSED_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_ACT(ActorBF16);
+        if (lean) RQ_LAUNCH_FUSED_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_ACT(ActorBF16);
     }
-    else if (b.n >= 131072)               RQ_LAUNCH_FUSED_ACT(ActorF32Lean);
+    else if (lean)                        RQ_LAUNCH_FUSED_ACT(ActorF32Lean);
     else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
 #undef RQ_LAUNCH_FUSED_RC
 #undef RQ_LAUNCH_FUSED_ACT
