@@ -92,18 +92,22 @@ class Shard:
                             autoreset=True)
 
 
-def pmc_traffic(kernel, grid):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE
-    doubled per the gfx950 correction of MI355X_MICROARCH.md).  None when no profile covers it."""
+def pmc_traffic(kernel, grid, also=""):
+    """HBM bytes per launch of the kernel whose profiled name starts with `kernel` (and contains `also`)
+    from the committed rocprofv3 PMC summary (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).
+    None when no profile covers it."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
-            d = json.load(open(path)).get(f"{kernel}@{grid}")
+            table = json.load(open(path))
         except Exception:
-            d = None
-        if d and d.get("hbm_bytes_per_launch_corrected"):
-            return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path)}
+            continue
+        for key, d in sorted(table.items()):
+            name, _, g = key.rpartition("@")
+            if g == str(grid) and name.startswith(kernel) and also in name and d.get("hbm_bytes_per_launch_corrected"):
+                return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path),
+                        "kernel": name}
     return None
 
 
@@ -327,7 +331,7 @@ def main():
             steps_per_launch = args.steps / len(plan)
             valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
             mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
-            tr = pmc_traffic("rq::k_rollout_fused<false, true, false, rq::ActorBF16>", n)
+            tr = pmc_traffic("rq::k_rollout_fused<false, true, false", n, "BF16")
             result["roofline"] = {
                 "kernel": "k_rollout_fused<ActorBF16>", "bound": "mfma", "achieved": round(valu, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
@@ -340,7 +344,7 @@ def main():
             steps_per_launch = args.steps / len(plan)
             flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
             achieved = flop_per_launch / avg_launch_s / 1e12
-            tr = pmc_traffic("rq::k_rollout_fused<false, true, false, rq::ActorF32>", n)
+            tr = pmc_traffic("rq::k_rollout_fused<false, true, false", n, "F32")
             result["roofline"] = {
                 "kernel": "k_rollout_fused", "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),

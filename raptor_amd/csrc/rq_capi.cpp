@@ -48,6 +48,8 @@ struct rq_device {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
+    float* rows = nullptr;         // device scratch, row-major side of the GPU layout changes (large batches)
+    size_t rows_bytes = 0;
     size_t staging_bytes = 0;
     void* staging_in = nullptr;    // pinned host buffer for host -> device copies (asynchronous)
     size_t staging_in_bytes = 0;
@@ -133,9 +135,31 @@ int ensure_staging(rq_device* dev, size_t bytes) {
     return RQ_OK;
 }
 
+// From kGpuLayoutMinEnvs envs up the row-major <-> field-major change runs on the GPU (k_soa_to_rows /
+// k_rows_to_soa) and the PCIe copy goes straight between the caller's array and a device row buffer; below
+// it the few KB are transposed by the host through a pinned staging buffer (one launch less).
+constexpr uint32_t kGpuLayoutMinEnvs = 1024;
+
+int ensure_rows(rq_device* dev, size_t bytes) {
+    if (dev->rows_bytes >= bytes) return RQ_OK;
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    if (dev->rows) { RQ_HIP(hipFree(dev->rows)); dev->rows = nullptr; dev->rows_bytes = 0; }
+    RQ_HIP(hipMalloc(&dev->rows, bytes));
+    dev->rows_bytes = bytes;
+    return RQ_OK;
+}
+
 // device SoA [dim][ld] -> host row-major [n][dim]
 int soa_to_host(rq_device* dev, const float* d_soa, uint32_t n, uint32_t ld, uint32_t dim, float* host) {
     int rc = set_device(dev); if (rc) return rc;
+    if (n >= kGpuLayoutMinEnvs) {
+        const size_t row_bytes = (size_t)n * dim * sizeof(float);
+        rc = ensure_rows(dev, row_bytes); if (rc) return rc;
+        RQ_HIP(rq::launch_soa_to_rows(dev->stream, d_soa, ld, dim, n, dev->rows));
+        RQ_HIP(hipMemcpyAsync(host, dev->rows, row_bytes, hipMemcpyDeviceToHost, dev->stream));
+        RQ_HIP(hipStreamSynchronize(dev->stream));
+        return RQ_OK;
+    }
     const size_t bytes = (size_t)dim * ld * sizeof(float);
     rc = ensure_staging(dev, bytes); if (rc) return rc;
     RQ_HIP(hipMemcpyAsync(dev->staging, d_soa, bytes, hipMemcpyDeviceToHost, dev->stream));
@@ -149,11 +173,20 @@ int soa_to_host(rq_device* dev, const float* d_soa, uint32_t n, uint32_t ld, uin
 }
 
 // host row-major [n][stride] (first dim columns) -> device SoA [dim][ld]; padding lanes zeroed.
-// Asynchronous on the device stream: the pinned staging buffer is only waited for when it is
-// about to be overwritten, so a host->device hand-over costs no stream synchronisation.
+// Small batches: asynchronous on the device stream (the pinned staging buffer is only waited for when it
+// is about to be overwritten, so the hand-over costs no stream synchronisation).  Large batches: the
+// caller's block is copied as it is and re-laid out on the GPU; the call returns when the copy has read it.
 int host_to_soa(rq_device* dev, const float* host, uint32_t n, uint32_t stride, uint32_t ld, uint32_t dim,
                 float* d_soa) {
     int rc = set_device(dev); if (rc) return rc;
+    if (n >= kGpuLayoutMinEnvs && stride <= 2 * dim) {
+        const size_t row_bytes = ((size_t)(n - 1) * stride + dim) * sizeof(float);   // last row: only its first dim columns
+        rc = ensure_rows(dev, (size_t)n * stride * sizeof(float)); if (rc) return rc;
+        RQ_HIP(hipMemcpyAsync(dev->rows, host, row_bytes, hipMemcpyHostToDevice, dev->stream));
+        RQ_HIP(rq::launch_rows_to_soa(dev->stream, dev->rows, stride, dim, n, ld, d_soa));
+        RQ_HIP(hipStreamSynchronize(dev->stream));
+        return RQ_OK;
+    }
     const size_t bytes = (size_t)dim * ld * sizeof(float);
     if (dev->h2d_pending) { RQ_HIP(hipEventSynchronize(dev->ev_h2d)); dev->h2d_pending = false; }
     if (dev->staging_in_bytes < bytes) {
@@ -300,6 +333,7 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
     if (dev->ev_h2d) (void)hipEventDestroy(dev->ev_h2d);
     if (dev->staging) (void)hipHostFree(dev->staging);
+    if (dev->rows) (void)hipFree(dev->rows);
     if (dev->staging_in) (void)hipHostFree(dev->staging_in);
     delete dev;
     return RQ_OK;

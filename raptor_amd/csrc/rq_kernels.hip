@@ -459,6 +459,55 @@ hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ layout changes -----
+// The boundary speaks row-major [n][dim] (NumPy), the engine field-major [dim][ld].  One wave moves a
+// 64-env tile through LDS so that BOTH sides are touched in whole 256-byte lines: SoA side one field
+// row per instruction, row-major side the tile's 64*dim contiguous floats.  kMaxDim bounds the LDS tile.
+static constexpr int kMaxDim = 32;
+
+__global__ __launch_bounds__(64) void k_soa_to_rows(const float* __restrict__ soa, uint32_t ld, uint32_t dim,
+                                                      uint32_t n, float* __restrict__ rows) {
+    __shared__ float tile[64 * (kMaxDim + 1)];
+    const uint32_t lane = threadIdx.x, base = blockIdx.x * 64u;
+    const uint32_t pitch = dim + 1;                       // odd pitch for dim = 4, 16, 26: no bank conflicts
+    for (uint32_t f = 0; f < dim; ++f) tile[lane * pitch + f] = soa[(size_t)f * ld + base + lane];   // ld >= base + 64
+    __syncthreads();
+    const uint32_t count = (n - base < 64u ? n - base : 64u) * dim;
+    float* out = rows + (size_t)base * dim;
+    for (uint32_t k = lane; k < count; k += 64u) out[k] = tile[(k / dim) * pitch + (k % dim)];
+}
+
+// rows [n][stride] (first dim columns) -> SoA [dim][ld]; lanes n..ld-1 are zeroed
+__global__ __launch_bounds__(64) void k_rows_to_soa(const float* __restrict__ rows, uint32_t stride, uint32_t dim,
+                                                      uint32_t n, uint32_t ld, float* __restrict__ soa) {
+    __shared__ float tile[64 * (kMaxDim + 1)];
+    const uint32_t lane = threadIdx.x, base = blockIdx.x * 64u;
+    const uint32_t pitch = dim + 1;
+    const uint32_t envs = base < n ? (n - base < 64u ? n - base : 64u) : 0u;
+    const float* in = rows + (size_t)base * stride;
+    for (uint32_t k = lane; k < envs * stride; k += 64u) {
+        const uint32_t e = k / stride, c = k % stride;
+        if (c < dim) tile[e * pitch + c] = in[k];
+    }
+    __syncthreads();
+    for (uint32_t f = 0; f < dim; ++f) soa[(size_t)f * ld + base + lane] = lane < envs ? tile[lane * pitch + f] : 0.0f;
+}
+
+hipError_t launch_soa_to_rows(hipStream_t s, const float* soa, uint32_t ld, uint32_t dim, uint32_t n, float* rows) {
+    if (n == 0 || dim == 0) return hipSuccess;
+    if (dim > (uint32_t)kMaxDim) return hipErrorInvalidValue;
+    k_soa_to_rows<<<(n + 63u) / 64u, 64, 0, s>>>(soa, ld, dim, n, rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_soa(hipStream_t s, const float* rows, uint32_t stride, uint32_t dim, uint32_t n, uint32_t ld,
+                              float* soa) {
+    if (ld == 0 || dim == 0) return hipSuccess;
+    if (dim > (uint32_t)kMaxDim || stride < dim) return hipErrorInvalidValue;
+    k_rows_to_soa<<<ld / 64u, 64, 0, s>>>(rows, stride, dim, n, ld, soa);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, uint32_t count) {
     if (count == 0) return hipSuccess;
     k_fill_f32<<<grid_for(count, kBlock), kBlock, 0, s>>>(p, v, count);

@@ -135,6 +135,12 @@ void pack_policy(const float* weights, float* packed);
 // the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
 void pack_policy_bf16(const float* weights, float* packed);
 
+// layout changes at the boundary (device pointers): field-major [dim][ld] <-> row-major [n][dim|stride],
+// dim <= 32; rows_to_soa zeroes the padding lanes n..ld-1
+hipError_t launch_soa_to_rows(hipStream_t s, const float* soa, uint32_t ld, uint32_t dim, uint32_t n, float* rows);
+hipError_t launch_rows_to_soa(hipStream_t s, const float* rows, uint32_t stride, uint32_t dim, uint32_t n, uint32_t ld,
+                              float* soa);
+
 // out[i] = value for i < count (uint32 / float / uint8 fills on the stream)
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, uint32_t count);
 

@@ -354,6 +354,46 @@ def test_step_termination_flag_every_component_nonfinite_or_over_threshold(devic
     assert np.array_equal(w.next_state.numpy(), ns, equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [1023, 1024, 1500, 4103])
+def test_host_transfers_small_and_large_batch_paths(device, oracle, weights, n):
+    """From 1024 envs up, host arrays cross the boundary through the GPU layout kernels (row-major <->
+    field-major in LDS tiles); below, through a host-side transpose.  Both must be exact copies: round trips
+    of every container, strided policy input, and the README loop against the oracle."""
+    w = World(device, oracle, n, seed=5)
+    rng = np.random.default_rng(n)
+    S = rng.standard_normal((n, 27)).astype(np.float32)
+    w.state.set(S)
+    assert np.array_equal(w.state.numpy(), S)
+    P = w.params.numpy()
+    assert np.array_equal(P, w.P)                      # sampled on the GPU, fetched through the path under test
+    w.params.set(P[::-1].copy())
+    assert np.array_equal(w.params.numpy(), P[::-1])
+    w.params.set(P)
+    A = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    w.env.set_action(A)
+    assert np.array_equal(w.env.action(), A)
+    H = rng.standard_normal((n, 16)).astype(np.float32)
+    w.policy.reset()
+    wide = np.full((n, 26), np.nan, np.float32)        # columns 22.. must never be read
+    wide[:, :22] = rng.standard_normal((n, 22)).astype(np.float32)
+    a0 = w.policy.evaluate_step(wide[:, :22])
+    w.policy.set_hidden_state(H)
+    assert np.array_equal(w.policy.hidden_state(n), H)
+    a_ref = oracle.actor_batch_step(weights, wide[:, :22].copy(), np.zeros((n, 16), np.float32) + weights[2000:2016])
+    assert np.max(np.abs(a0 - a_ref)) < ACTOR_TOL
+    # README loop, host arrays every call, bit-exact transitions with the actions the GPU produced
+    w.state.set(w.S)
+    obs = np.zeros((n, 26), np.float32)
+    for _ in range(3):
+        w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+        assert np.array_equal(obs, oracle.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+        act = w.policy.evaluate_step(obs[:, :22])
+        w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+        w.state.assign(w.next_state)
+        w.S, _, _ = oracle.step(w.cfg, w.P, w.S, act)
+        assert np.array_equal(w.state.numpy(), w.S)
+
+
 def test_step_in_place_equals_out_of_place(device, oracle):
     w = World(device, oracle, 300, seed=2)
     act = np.random.default_rng(1).uniform(-1, 1, (300, 4)).astype(np.float32)
