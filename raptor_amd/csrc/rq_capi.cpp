@@ -55,6 +55,13 @@ struct rq_device {
     size_t staging_in_bytes = 0;
     hipEvent_t ev_h2d = nullptr;   // recorded after the last copy out of staging_in
     bool h2d_pending = false;
+    // small-batch mailbox (rq::Mailbox): pinned, device-visible rows + completion flag
+    uint32_t* mb_flag = nullptr;   // pinned host: sequence number of the last finished mailbox launch
+    uint32_t* mb_counter = nullptr;  // device: workgroup counter of the launch in flight
+    float* mb_in = nullptr;        // pinned host rows read by kernels (observations / actions)
+    float* mb_out = nullptr;       // pinned host rows written by kernels
+    uint32_t mb_seq = 0;           // last sequence number handed to a launch
+    uint32_t mb_in_busy = 0;       // sequence number of the last launch that reads mb_in
 };
 
 struct rq_rng {
@@ -207,6 +214,66 @@ int host_to_soa(rq_device* dev, const float* host, uint32_t n, uint32_t stride, 
     return RQ_OK;
 }
 
+// ---- small-batch mailbox (below kGpuLayoutMinEnvs envs): rows cross the boundary in pinned host memory
+// the kernels read and write themselves, and the host waits on a flag instead of the stream ---------------
+constexpr size_t kMailboxRowFloats = (size_t)(kGpuLayoutMinEnvs - 1) * 32;
+
+int ensure_mailbox(rq_device* dev) {
+    if (dev->mb_flag) return RQ_OK;
+    void *flag = nullptr, *in = nullptr, *out = nullptr;
+    RQ_HIP(hipHostMalloc(&flag, 64, hipHostMallocDefault));
+    *static_cast<volatile uint32_t*>(flag) = 0;
+    hipError_t e1 = hipHostMalloc(&in, kMailboxRowFloats * sizeof(float), hipHostMallocDefault);
+    hipError_t e2 = hipHostMalloc(&out, kMailboxRowFloats * sizeof(float), hipHostMallocDefault);
+    hipError_t e3 = hipMalloc(&dev->mb_counter, sizeof(uint32_t));
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(dev->mb_counter, 0, sizeof(uint32_t), dev->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        (void)hipHostFree(flag); if (in) (void)hipHostFree(in); if (out) (void)hipHostFree(out);
+        if (dev->mb_counter) { (void)hipFree(dev->mb_counter); dev->mb_counter = nullptr; }
+        return fail(RQ_ERR_OUT_OF_MEMORY, "ensure_mailbox: pinned host allocation failed");
+    }
+    dev->mb_flag = static_cast<uint32_t*>(flag);
+    dev->mb_in = static_cast<float*>(in);
+    dev->mb_out = static_cast<float*>(out);
+    return RQ_OK;
+}
+
+// spin until the launch with sequence number seq (or a later one: launches finish in stream order) signalled
+int mailbox_wait(rq_device* dev, uint32_t seq) {
+    for (uint64_t spins = 1;; ++spins) {
+        const uint32_t f = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
+        if ((int32_t)(f - seq) >= 0) return RQ_OK;
+        if ((spins & 0xFFFFu) == 0) {           // every ~100 us: is the stream still alive?
+            const hipError_t q = hipStreamQuery(dev->stream);
+            if (q == hipSuccess) {
+                const uint32_t g = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
+                if ((int32_t)(g - seq) >= 0) return RQ_OK;
+                return fail(RQ_ERR_HIP, "mailbox_wait: the stream drained without the kernel signalling");
+            }
+            if (q != hipErrorNotReady) RQ_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// before the host overwrites mb_in: the last launch reading it must have finished
+int mailbox_in_free(rq_device* dev) {
+    if (dev->mb_in_busy == 0) return RQ_OK;
+    const int rc = mailbox_wait(dev, dev->mb_in_busy);
+    if (rc == RQ_OK) dev->mb_in_busy = 0;
+    return rc;
+}
+
+rq::Mailbox mailbox_for(rq_device* dev, const float* rows_in, uint32_t in_stride, float* rows_out) {
+    rq::Mailbox mb{};
+    mb.rows_in = rows_in; mb.in_stride = in_stride; mb.rows_out = rows_out;
+    mb.counter = dev->mb_counter; mb.flag = dev->mb_flag;
+    if (++dev->mb_seq == 0) ++dev->mb_seq;      // 0 means "nothing pending"
+    mb.seq = dev->mb_seq;
+    if (rows_in) dev->mb_in_busy = mb.seq;
+    return mb;
+}
+
 template <typename T>
 int copy_out(const rq_env* env, const T* src, T* dst, int dst_is_device) {
     RQ_REQUIRE(env && dst, RQ_ERR_INVALID_ARGUMENT, "null argument");
@@ -334,6 +401,10 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->ev_h2d) (void)hipEventDestroy(dev->ev_h2d);
     if (dev->staging) (void)hipHostFree(dev->staging);
     if (dev->rows) (void)hipFree(dev->rows);
+    if (dev->mb_flag) (void)hipHostFree(dev->mb_flag);
+    if (dev->mb_in) (void)hipHostFree(dev->mb_in);
+    if (dev->mb_out) (void)hipHostFree(dev->mb_out);
+    if (dev->mb_counter) (void)hipFree(dev->mb_counter);
     if (dev->staging_in) (void)hipHostFree(dev->staging_in);
     delete dev;
     return RQ_OK;
@@ -626,9 +697,17 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
     RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
     rc = set_device(dev); if (rc) return rc;
+    const bool mailbox = observation && env->n < kGpuLayoutMinEnvs;
+    rq::Mailbox mb{};
+    if (mailbox) { rc = ensure_mailbox(dev); if (rc) return rc; mb = mailbox_for(dev, nullptr, 0, dev->mb_out); }
     RQ_HIP(rq::launch_observe(dev->stream, batch_of(env), rq::noise_cfg(env->cfg), rq::noise_enabled(env->cfg),
-                              rng->seed, rng->epoch, nullptr, params->d, state->d, env->obs));
+                              rng->seed, rng->epoch, nullptr, params->d, state->d, env->obs, mb));
     rng->epoch += 1;
+    if (mailbox) {
+        rc = mailbox_wait(dev, mb.seq); if (rc) return rc;
+        std::memcpy(observation, dev->mb_out, (size_t)env->n * RQ_OBSERVATION_DIM * sizeof(float));
+        return RQ_OK;
+    }
     if (observation) return soa_to_host(dev, env->obs, env->n, env->ld, RQ_OBSERVATION_DIM, observation);
     return RQ_OK;
 }
@@ -639,13 +718,20 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     RQ_REQUIRE(params && state && next_state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(next_state->env == env, RQ_ERR_SHAPE_MISMATCH, "next_state belongs to another env");
     rc = set_device(dev); if (rc) return rc;
-    if (action) {
+    rq::Mailbox mb{};
+    if (action && env->n < kGpuLayoutMinEnvs) {
+        // the kernel reads the actions from the mailbox (and files them in env->act); nothing to wait for
+        rc = ensure_mailbox(dev); if (rc) return rc;
+        rc = mailbox_in_free(dev); if (rc) return rc;
+        std::memcpy(dev->mb_in, action, (size_t)env->n * RQ_ACTION_DIM * sizeof(float));
+        mb = mailbox_for(dev, dev->mb_in, RQ_ACTION_DIM, nullptr);
+    } else if (action) {
         rc = host_to_soa(dev, action, env->n, RQ_ACTION_DIM, env->ld, RQ_ACTION_DIM, env->act);
         if (rc) return rc;
     }
     RQ_HIP(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
                            next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
-                           nullptr, nullptr));
+                           nullptr, nullptr, mb));
     if (dts) for (uint32_t i = 0; i < env->n; ++i) dts[i] = env->cfg.dt;
     return RQ_OK;
 }
@@ -802,9 +888,24 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     if (observation) RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
     int rc = set_device(pol->dev); if (rc) return rc;
     rc = policy_size(pol, batch); if (rc) return rc;
+    rq_device* dev = pol->dev;
+    const bool mailbox = batch < kGpuLayoutMinEnvs && (observation || action);
     const float* d_obs; uint32_t ld_obs;
-    if (observation) {
-        rc = host_to_soa(pol->dev, observation, batch, obs_stride, pol->ld, RQ_POLICY_INPUT_DIM, pol->obs);
+    const float* rows_in = nullptr;
+    if (observation && mailbox) {
+        rc = ensure_mailbox(dev); if (rc) return rc;
+        rc = mailbox_in_free(dev); if (rc) return rc;
+        if (obs_stride == RQ_POLICY_INPUT_DIM) {
+            std::memcpy(dev->mb_in, observation, (size_t)batch * RQ_POLICY_INPUT_DIM * sizeof(float));
+        } else {
+            for (uint32_t i = 0; i < batch; ++i)
+                std::memcpy(dev->mb_in + (size_t)i * RQ_POLICY_INPUT_DIM, observation + (size_t)i * obs_stride,
+                            RQ_POLICY_INPUT_DIM * sizeof(float));
+        }
+        rows_in = dev->mb_in;
+        d_obs = pol->obs; ld_obs = pol->ld;     // unused by the kernel when rows_in is set
+    } else if (observation) {
+        rc = host_to_soa(dev, observation, batch, obs_stride, pol->ld, RQ_POLICY_INPUT_DIM, pol->obs);
         if (rc) return rc;
         d_obs = pol->obs; ld_obs = pol->ld;
     } else {
@@ -812,9 +913,19 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     }
     float* d_act = action ? pol->act : env->act;
     const uint32_t ld_act = action ? pol->ld : env->ld;
-    RQ_HIP(rq::launch_actor_step(pol->dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
-                                 ld_act, nullptr, mode_of(pol)));
-    if (action) return soa_to_host(pol->dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
+    rq::Mailbox mb{};
+    if (mailbox) {
+        rc = ensure_mailbox(dev); if (rc) return rc;
+        mb = mailbox_for(dev, rows_in, RQ_POLICY_INPUT_DIM, action ? dev->mb_out : nullptr);
+    }
+    RQ_HIP(rq::launch_actor_step(dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
+                                 ld_act, nullptr, mode_of(pol), mb));
+    if (action && mailbox) {
+        rc = mailbox_wait(dev, mb.seq); if (rc) return rc;
+        std::memcpy(action, dev->mb_out, (size_t)batch * RQ_ACTION_DIM * sizeof(float));
+        return RQ_OK;
+    }
+    if (action) return soa_to_host(dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
     return RQ_OK;
 }
 

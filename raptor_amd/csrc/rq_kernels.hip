@@ -27,6 +27,21 @@ __device__ __forceinline__ uint32_t env_index() { return blockIdx.x * blockDim.x
 template <typename T>
 __device__ __forceinline__ T* field(T* base, uint32_t f, uint32_t ld) { return base + (size_t)f * ld; }
 
+// Publish completion of this launch in the host mailbox: every workgroup makes its stores visible at system
+// scope and counts itself; the last one resets the counter and writes seq to the pinned flag.
+__device__ __forceinline__ void mailbox_signal(const Mailbox& mb) {
+    if (mb.flag == nullptr) return;          // wave-uniform (kernel argument)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(mb.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(mb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mb.flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ sampling -----------
 __global__ __launch_bounds__(kBlock) void k_sample_params(Batch b, SampleCfg c, uint64_t seed, uint32_t epoch,
                                                           float* __restrict__ params) {
@@ -63,27 +78,36 @@ template <bool NOISE>
 __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64_t seed, uint32_t epoch_offset,
                                                     const uint32_t* __restrict__ epoch_base,
                                                     const float* __restrict__ params,
-                                                    const float* __restrict__ state, float* __restrict__ obs) {
+                                                    const float* __restrict__ state, float* __restrict__ obs,
+                                                    Mailbox mb) {
     const uint32_t i = env_index();
-    if (i >= b.n) return;
-    // inside a replayed hipGraph the noise epoch cannot be a baked-in argument: it is read from a
-    // device counter the graph itself advances (k_advance_u32); eager launches pass nullptr
-    const uint32_t epoch = epoch_offset + (epoch_base != nullptr ? *epoch_base : 0u);
-    float y[17], la[4];
+    if (i < b.n) {
+        // inside a replayed hipGraph the noise epoch cannot be a baked-in argument: it is read from a
+        // device counter the graph itself advances (k_advance_u32); eager launches pass nullptr
+        const uint32_t epoch = epoch_offset + (epoch_base != nullptr ? *epoch_base : 0u);
+        float y[17], la[4];
 #pragma unroll
-    for (int k = 0; k < 17; ++k) y[k] = field(state, k, b.ld)[i];
+        for (int k = 0; k < 17; ++k) y[k] = field(state, k, b.ld)[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) la[k] = field(state, (RQ_S_LAST_ACTION + k), b.ld)[i];
-    const float rmin = field(params, RQ_P_RPM_MIN, b.ld)[i];
-    const float rmax = field(params, RQ_P_RPM_MAX, b.ld)[i];
-    float o[22];
-    observe_head<NOISE>(y, la, nc, seed, epoch, b.env_offset + i, o);
+        for (int k = 0; k < 4; ++k) la[k] = field(state, (RQ_S_LAST_ACTION + k), b.ld)[i];
+        const float rmin = field(params, RQ_P_RPM_MIN, b.ld)[i];
+        const float rmax = field(params, RQ_P_RPM_MAX, b.ld)[i];
+        float head[22], o[RQ_OBSERVATION_DIM];
+        observe_head<NOISE>(y, la, nc, seed, epoch, b.env_offset + i, head);
 #pragma unroll
-    for (int k = 0; k < 22; ++k) field(obs, k, b.ld)[i] = o[k];
-    // privileged tail: normalised rotor speeds
-    const float inv = 2.0f / (rmax - rmin);
+        for (int k = 0; k < 22; ++k) o[k] = head[k];
+        // privileged tail: normalised rotor speeds
+        const float inv = 2.0f / (rmax - rmin);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) field(obs, (22 + k), b.ld)[i] = fmaf(y[13 + k] - rmin, inv, -1.0f);
+        for (int k = 0; k < 4; ++k) o[22 + k] = fmaf(y[13 + k] - rmin, inv, -1.0f);
+#pragma unroll
+        for (int k = 0; k < RQ_OBSERVATION_DIM; ++k) field(obs, k, b.ld)[i] = o[k];
+        if (mb.rows_out != nullptr) {            // wave-uniform (kernel argument)
+#pragma unroll
+            for (int k = 0; k < RQ_OBSERVATION_DIM; ++k) mb.rows_out[(size_t)i * RQ_OBSERVATION_DIM + k] = o[k];
+        }
+    }
+    mailbox_signal(mb);
 }
 
 // ------------------------------------------------------------------ actor --------------
@@ -97,7 +121,8 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
-                                                       const uint8_t* __restrict__ frozen, uint32_t squash) {
+                                                       const uint8_t* __restrict__ frozen, uint32_t squash,
+                                                       Mailbox mb) {
     ACTOR actor;
     actor.load(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
     const uint32_t lane = threadIdx.x & 63;
@@ -110,8 +135,13 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
         const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
         const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
         float x[22], hQ[4][4], a[4];
+        if (mb.rows_in != nullptr) {         // wave-uniform (kernel argument)
 #pragma unroll
-        for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
+            for (int k = 0; k < 22; ++k) x[k] = mb.rows_in[(size_t)i * mb.in_stride + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
+        }
         load_hidden_q(hidden, ld_h, wave_base, n, hQ);
         actor.step(x, hQ, a);
         if (squash) squash_action(a);        // wave-uniform (kernel argument)
@@ -119,8 +149,13 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
         if (commit) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) field(act, k, ld_act)[i] = a[k];
+            if (mb.rows_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mb.rows_out[(size_t)i * 4 + k] = a[k];
+            }
         }
     }
+    mailbox_signal(mb);
 }
 
 // ------------------------------------------------------------------ step ---------------
@@ -137,13 +172,11 @@ __device__ __forceinline__ void store_stats(const StatsPtrs& st, uint32_t i, con
 }
 
 template <bool ROLLOUT>
-__global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float* __restrict__ params,
-                                                 const float* state, const float* __restrict__ action,
-                                                 float* next_state, StatsPtrs st, uint32_t flags, SampleCfg sc,
-                                                 uint64_t seed, float* __restrict__ hidden,
-                                                 const float* __restrict__ weights) {
-    const uint32_t i = env_index();
-    if (i >= b.n) return;
+__device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepCfg& c, const float* __restrict__ params,
+                                         const float* state, float* __restrict__ action, float* next_state,
+                                         const StatsPtrs& st, uint32_t flags, const SampleCfg& sc, uint64_t seed,
+                                         float* __restrict__ hidden, const float* __restrict__ weights,
+                                         const Mailbox& mb) {
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
@@ -152,8 +185,13 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
     for (int j = 0; j < 17; ++j) y[j] = field(state, j, ld)[i];
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
+    if (mb.rows_in != nullptr) {             // actions handed over in the host mailbox (kernel argument)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = field(action, j, ld)[i];
+        for (int j = 0; j < 4; ++j) { a[j] = mb.rows_in[(size_t)i * mb.in_stride + j]; field(action, j, ld)[i] = a[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = field(action, j, ld)[i];
+    }
     Stats s = load_stats(st, i);
     const Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool term;
@@ -188,6 +226,17 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
     }
 }
 
+
+template <bool ROLLOUT>
+__global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float* __restrict__ params,
+                                                 const float* state, float* __restrict__ action,
+                                                 float* next_state, StatsPtrs st, uint32_t flags, SampleCfg sc,
+                                                 uint64_t seed, float* __restrict__ hidden,
+                                                 const float* __restrict__ weights, Mailbox mb) {
+    const uint32_t i = env_index();
+    if (i < b.n) step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb);
+    mailbox_signal(mb);
+}
 // ------------------------------------------------------------------ fused rollout ------
 // K iterations of observe -> evaluate_step -> step -> assign with the env state, the GRU
 // hidden state, the per-env constants, the policy weights and the episode statistics resident
@@ -353,10 +402,11 @@ hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t see
 }
 
 hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint64_t seed, uint32_t epoch,
-                          const uint32_t* epoch_base, const float* params, const float* state, float* obs) {
+                          const uint32_t* epoch_base, const float* params, const float* state, float* obs,
+                          Mailbox mb) {
     if (b.n == 0) return hipSuccess;
-    if (noise) k_observe<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, epoch_base, params, state, obs);
-    else       k_observe<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, epoch_base, params, state, obs);
+    if (noise) k_observe<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, epoch_base, params, state, obs, mb);
+    else       k_observe<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, nc, seed, epoch, epoch_base, params, state, obs, mb);
     return hipGetLastError();
 }
 
@@ -374,7 +424,7 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add) {
 
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
-                             int precision) {
+                             int precision, Mailbox mb) {
     if (n == 0) return hipSuccess;
     // enough waves to fill the 1024 SIMDs first, then several 64-env groups per wave so that the
     // per-wave operand-image load (18 KB, more than a group's own 14.8 KB of data) is amortised
@@ -384,22 +434,22 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
     if (precision == RQ_POLICY_BF16_MFMA)
-        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash);
+        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash, mb);
     else
-        k_actor_step<ActorF32><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash);
+        k_actor_step<ActorF32><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash, mb);
     return hipGetLastError();
 }
 
 hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
-                       const float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
-                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights) {
+                       float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
+                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb) {
     if (b.n == 0) return hipSuccess;
     if (rollout)
         k_step<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                              sc, seed, hidden, weights);
+                                                              sc, seed, hidden, weights, mb);
     else
         k_step<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                               sc, seed, hidden, weights);
+                                                               sc, seed, hidden, weights, mb);
     return hipGetLastError();
 }
 
