@@ -1078,6 +1078,9 @@ RQ_API int rq_rollout_record(rq_device* dev, rq_env* env, const rq_params* param
 RQ_API int rq_trajectory_create(rq_env* env, uint32_t capacity_steps, rq_trajectory** out) {
     RQ_REQUIRE(env && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(capacity_steps > 0, RQ_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    // one step of the observation block is addressed with 32-bit buffer offsets (k_rollout_fused)
+    RQ_REQUIRE((uint64_t)env->ld * RQ_POLICY_INPUT_DIM * sizeof(float) < (1ull << 32), RQ_ERR_INVALID_ARGUMENT,
+               "trajectory recording supports up to 48 million envs per device");
     *out = nullptr;
     int rc = set_device(env->dev); if (rc) return rc;
     rq_trajectory* t = new (std::nothrow) rq_trajectory();

@@ -346,14 +346,26 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
                 }
             }
         }
-        if (RECORD && valid) {   // one coalesced 256-byte store per field per wave
+        if (RECORD) {   // one coalesced 256-byte store per field per wave
+            // buffer stores: resource = this step's block of the trajectory (base moved on the SALU), scalar
+            // offset = field row, vector offset = the lane's env; no per-lane 64-bit address arithmetic and
+            // no per-lane pointers kept alive across the loop.  Lanes past the batch are sent out of range
+            // (the hardware drops out-of-range buffer stores).
             const size_t tt = traj.t0 + t;
+            const uint32_t row = (uint32_t)ld * 4u;                 // bytes per field row (ld < 2^30)
+            const uint32_t lane_off = valid ? i * 4u : 0xFFFFFFFFu;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(traj.obs + tt * 22 * ld, 0, 22u * row, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(traj.act + tt * 4 * ld, 0, 4u * row, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(traj.rew + tt * ld, 0, row, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(traj.done + tt * ld, 0, (uint32_t)ld, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 22; ++j) traj.obs[(tt * 22 + j) * ld + i] = o[j];
+            for (int j = 0; j < 22; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) traj.act[(tt * 4 + j) * ld + i] = a[j];
-            traj.rew[tt * ld + i] = r;
-            traj.done[tt * ld + i] = done_code;
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a[j]), ra, lane_off, (uint32_t)j * row, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rr, lane_off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8(done_code, rd, valid ? i : 0xFFFFFFFFu, 0, 0);
         }
         if (AUTORESET) {   // policy reset of the envs whose episode ended: h <- initial_hidden_state
             const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
