@@ -281,14 +281,16 @@ def main():
             dist.barrier()
 
     # ---- warm-up (untimed) ----
-    # The GPU needs ~20 ms of load to reach its steady clocks (measured: 1.58e10 env-steps/s after a
-    # 500-step warm-up, 1.74e10 after 5 000 or more, same kernel); a short --warmup is therefore
-    # topped up to MIN_UNTIMED_STEPS of the same rollout before the timed region starts.
+    # The GPU needs ~20 ms of load to reach its steady clocks and loses them again after ~5 ms of idling
+    # (measured: 500-step launches take 1.87 ms back to back, 2.08 ms after a 20 ms pause, ramping back over
+    # ~15 ms).  So (1) a short --warmup is topped up to MIN_UNTIMED_STEPS of the same rollout, and (2) the
+    # one-off costs of the exchange (RCCL communicator creation, first barrier) are paid BEFORE the warm-up
+    # rollouts, so that only a warm, sub-millisecond barrier separates them from the timed region.
+    episode_exchange()
+    sync_all()
     untimed = max(args.warmup, MIN_UNTIMED_STEPS)
     for c in chunks(untimed, EPISODE):
         shard.rollout(c, args.mode)
-    episode_exchange()
-    sync_all()
 
     # ---- timed region: exactly --steps steps ----
     plan = chunks(args.steps, EPISODE)
