@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 // batch (and frozen envs) compute on a clamped index and only their STORES are predicated —
 // no lane leaves early.
 template <typename ACTOR>
-__global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
+__global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
                                                        const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
@@ -127,14 +127,11 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
     actor.load(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    for (uint32_t g = 0; g < groups_per_wave; ++g) {
-        const uint32_t wave_base = (wave * groups_per_wave + g) * 64;
-        if (wave_base >= n) break;                       // wave-uniform
+    const uint32_t first = wave * groups_per_wave * 64;
+    // inputs of a 64-env group: 22 observation features of the lane's env + the Q-layout hidden state
+    auto load_group = [&](uint32_t wave_base, float (&x)[22], float (&hQ)[4][4]) {
         const uint32_t i0 = wave_base + lane;
         const uint32_t i = i0 < n ? i0 : n - 1;
-        const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
-        const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
-        float x[22], hQ[4][4], a[4];
         if (mb.rows_in != nullptr) {         // wave-uniform (kernel argument)
 #pragma unroll
             for (int k = 0; k < 22; ++k) x[k] = mb.rows_in[(size_t)i * mb.in_stride + k];
@@ -143,6 +140,23 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
             for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
         }
         load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+    };
+    float x[22], hQ[4][4];
+    if (first < n) load_group(first, x, hQ);                 // wave-uniform
+#pragma unroll 1
+    for (uint32_t g = 0; g < groups_per_wave; ++g) {
+        const uint32_t wave_base = first + g * 64;
+        if (wave_base >= n) break;                       // wave-uniform
+        // software pipeline: the next group's loads are in flight while this group's MFMAs run (the waves
+        // of a launch move in lock-step, so without it the memory and the matrix phases alternate)
+        float xn[22], hn[4][4];
+        const bool more = g + 1 < groups_per_wave && wave_base + 64 < n;
+        if (more) load_group(wave_base + 64, xn, hn);
+        const uint32_t i0 = wave_base + lane;
+        const uint32_t i = i0 < n ? i0 : n - 1;
+        const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
+        const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
+        float a[4];
         actor.step(x, hQ, a);
         if (squash) squash_action(a);        // wave-uniform (kernel argument)
         store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
@@ -153,6 +167,14 @@ __global__ __launch_bounds__(kBlock) void k_actor_step(uint32_t n, uint32_t grou
 #pragma unroll
                 for (int k = 0; k < 4; ++k) mb.rows_out[(size_t)i * 4 + k] = a[k];
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < 22; ++k) x[k] = xn[k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hQ[t][r] = hn[t][r];
         }
     }
     mailbox_signal(mb);
