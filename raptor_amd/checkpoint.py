@@ -1,4 +1,4 @@
-"""Reading policies in the two formats rl-tools writes per checkpoint (SURVEY.md §5 "checkpoint /
+"""Reading and writing policies in the two formats rl-tools writes per checkpoint (SURVEY.md §5 "checkpoint /
 resume", §8(f) row 3): the C++ code export `checkpoint.h` and its HDF5 twin `checkpoint.h5` (read with
 the dependency-free minimal reader in `hdf5_min.py`).
 
@@ -137,6 +137,67 @@ def load_checkpoint_h5(path):
         if x.ndim == 3 and x.shape[2] == 22 and y.shape == x.shape[:2] + (4,):
             example = (x.astype(np.float32), y.astype(np.float32))
     return weights, example, actor.attrs.get("meta")
+
+
+_H5_ATTRS = {     # string attributes rl-tools attaches (tests/golden/checkpoint.h5)
+    "actor": {"type": "sequential"},
+    "actor/layers/0": {"activation_function": "RELU", "type": "dense"},
+    "actor/layers/1": {"type": "gru"},
+    "actor/layers/2": {"activation_function": "IDENTITY", "type": "dense"},
+}
+_DEFAULT_META = ('{"environment": {"name": "l2f","observation": "Position.OrientationRotationMatrix.LinearVelocity.'
+                 'AngularVelocityDelayed(0).ActionHistory(1)"}}')
+
+
+def _shape_attrs(shape, matrix):
+    if matrix:
+        return {"type": "matrix", "rows": str(shape[0]), "cols": str(shape[1])}
+    a = {"type": "tensor", "num_dims": str(len(shape))}
+    a.update({f"dim_{i}": str(d) for i, d in enumerate(shape)})
+    return a
+
+
+def write_checkpoint_h5(path, weights, example=None, meta=_DEFAULT_META, checkpoint_name=None):
+    """Inverse of ``load_checkpoint_h5``: the flat 2 084-parameter vector (and optionally a known-answer
+    example) in the group / dataset / attribute layout rl-tools writes, so a policy handled by this engine
+    round-trips with the reference tooling.  Written with the dependency-free
+    writer of `hdf5_min.py`; libhdf5's h5dump / h5diff accept the result (tests/test_host_logic.py)."""
+    from .hdf5_min import DatasetSpec, GroupSpec, write_file
+    w = np.ascontiguousarray(weights, np.float32).ravel()
+    if w.size != sum(int(np.prod(sh)) for _, sh in _H5_LAYOUT):
+        raise ValueError("expected 2084 parameters")
+    tree, off = {}, 0
+
+    def put(path_, node):
+        parts = path_.split("/")
+        d = tree
+        for p_ in parts[:-1]:
+            d = d.setdefault(p_, {})
+        d[parts[-1]] = node
+
+    for name, shape in _H5_LAYOUT:
+        size = int(np.prod(shape))
+        matrix = "/layers/0/" in name or "/layers/2/" in name          # dense layers store matrices, the GRU tensors
+        put(name, DatasetSpec(w[off:off + size].reshape(shape), _shape_attrs(shape, matrix)))
+        off += size
+    if example is not None:
+        x, y = (np.ascontiguousarray(a, np.float32) for a in example)
+        if x.ndim != 3 or x.shape[2] != 22 or y.shape != x.shape[:2] + (4,):
+            raise ValueError("example must be (input [T,B,22], output [T,B,4])")
+        put("example/input", DatasetSpec(x, _shape_attrs(x.shape, False)))
+        put("example/output", DatasetSpec(y, _shape_attrs(y.shape, False)))
+
+    def build(d, prefix):
+        attrs = dict(_H5_ATTRS.get(prefix, {}))
+        if prefix == "actor":
+            if checkpoint_name is not None:
+                attrs["checkpoint_name"] = checkpoint_name
+            if meta is not None:
+                attrs["meta"] = meta
+        return GroupSpec({k: (build(v, f"{prefix}/{k}" if prefix else k) if isinstance(v, dict) else v)
+                          for k, v in d.items()}, attrs)
+
+    write_file(path, build(tree, ""))
 
 
 def load_checkpoint(path):

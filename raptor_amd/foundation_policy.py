@@ -73,6 +73,17 @@ class Raptor:
         pol.example = example
         return pol
 
+    def save_checkpoint(self, path, example=None):
+        """Write the policy back in an rl-tools format chosen by the extension: ``.h5`` (HDF5 layout of
+        ``checkpoint.h5``) or anything else (C++ byte-array export like ``checkpoint.h``).  ``example``
+        defaults to the known-answer pair the policy was loaded with."""
+        from .checkpoint import write_checkpoint_h5, write_checkpoint_header
+        example = self.example if example is None else example
+        if str(path).endswith((".h5", ".hdf5")):
+            write_checkpoint_h5(path, self._weights, example)
+        else:
+            write_checkpoint_header(path, self._weights, example)
+
     # the C object is created on first use so that ``Raptor()`` itself needs no device argument
     def _handle(self, device=None):
         if self._h is None:

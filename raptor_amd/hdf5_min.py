@@ -231,3 +231,151 @@ class File:
                 break
             pos += 16 + ((osize + 7) & ~7)
         raise Hdf5FormatError("global heap object not found")
+
+
+# ====================================================================== writer =========
+# The same subset, written: superblock version 0, old-style groups (one symbol-table node per group, so
+# at most 8 children each), version-1 object headers without continuation blocks, contiguous
+# little-endian float32 datasets, variable-length UTF-8 string attributes in one global heap collection.
+# Byte layouts follow the file rl-tools/HighFive produced for the reference checkpoint
+# (tests/golden/checkpoint.h5, dumped with this module's reader); `h5dump` / `h5diff` 1.10 accept the output
+# (tests/test_host_logic.py).
+
+class GroupSpec:
+    def __init__(self, children=None, attrs=None):
+        self.children, self.attrs = dict(children or {}), dict(attrs or {})
+
+
+class DatasetSpec:
+    def __init__(self, array, attrs=None):
+        self.array = np.ascontiguousarray(array, "<f4")
+        self.attrs = dict(attrs or {})
+
+
+_LEAF_K, _INTERNAL_K = 4, 16
+_F32_DATATYPE = bytes.fromhex("11201f000400000000002000170800177f000000") + b"\x00" * 4
+_VLEN_STR_DATATYPE = bytes.fromhex("1901010010000000" "100000000100000000000800") + b"\x00" * 4   # 20 B + pad
+_SCALAR_DATASPACE = bytes.fromhex("0100000000000000")
+
+
+def _pad8(b):
+    return b + b"\x00" * (-len(b) % 8)
+
+
+def _message(mtype, data, flags=0):
+    assert len(data) % 8 == 0
+    return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+
+class _Writer:
+    def __init__(self, root):
+        self.strings = []          # global heap objects, index = position + 1
+        self._collect(root)
+        need = 16 + sum(16 + len(_pad8(s)) for s in self.strings) + 16
+        self.gheap_addr, self.gheap_size = 96, max(4096, (need + 4095) // 4096 * 4096)
+        self.buf = bytearray(96 + self.gheap_size)
+        self.string_index = {}
+        self._write_gheap()
+        root_header, btree, heap = self._group(root)
+        eof = len(self.buf)
+        sb = b"\x89HDF\r\n\x1a\n" + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", _LEAF_K, _INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+        sb += struct.pack("<QQII", 0, root_header, 1, 0) + struct.pack("<QQ", btree, heap)
+        assert len(sb) == 96
+        self.buf[:96] = sb
+
+    # -------------------------------------------------------------- global heap (attribute strings)
+    def _collect(self, node):
+        for v in node.attrs.values():
+            self.strings.append(str(v).encode("utf-8"))
+        if isinstance(node, GroupSpec):
+            for name in sorted(node.children):
+                self._collect(node.children[name])
+
+    def _write_gheap(self):
+        out = bytearray(b"GCOL" + bytes([1, 0, 0, 0]) + struct.pack("<Q", self.gheap_size))
+        for i, s in enumerate(self.strings, 1):
+            out += struct.pack("<HHIQ", i, 0, 0, len(s)) + _pad8(s)
+        free = self.gheap_size - len(out)
+        if free >= 16:
+            out += struct.pack("<HHIQ", 0, 0, 0, free)
+        self.buf[self.gheap_addr:self.gheap_addr + len(out)] = out
+        self._next_string = 0
+
+    def _attribute(self, name, value):
+        s = str(value).encode("utf-8")
+        idx = self._next_string + 1              # same traversal order as _collect
+        assert self.strings[self._next_string] == s
+        self._next_string += 1
+        nm = name.encode("utf-8") + b"\x00"
+        data = struct.pack("<BBHHH", 1, 0, len(nm), 20, 8) + _pad8(nm) + _VLEN_STR_DATATYPE + _SCALAR_DATASPACE
+        data += struct.pack("<IQI", len(s), self.gheap_addr, idx)
+        return _message(0x000C, _pad8(data))
+
+    # -------------------------------------------------------------- allocation
+    def _append(self, blob):
+        self.buf += b"\x00" * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += blob
+        return addr
+
+    def _header(self, messages):
+        body = b"".join(messages)
+        return self._append(struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body)
+
+    # -------------------------------------------------------------- objects
+    def _dataset(self, ds):
+        attrs = [self._attribute(k, v) for k, v in ds.attrs.items()]
+        shape = ds.array.shape
+        space = struct.pack("<BBB5x", 1, len(shape), 1) + b"".join(struct.pack("<Q", d) for d in shape) * 2
+        raw = ds.array.tobytes()
+        data_addr = self._append(raw) if raw else UNDEF
+        layout = _pad8(struct.pack("<BBQQ", 3, 1, data_addr, len(raw)))
+        msgs = [_message(0x0001, _pad8(space)), _message(0x0003, _F32_DATATYPE, 1),
+                _message(0x0005, bytes.fromhex("0202020100000000"), 1), _message(0x0008, layout)] + attrs
+        return self._header(msgs)
+
+    def _group(self, g):
+        if not g.children:
+            raise Hdf5FormatError("empty groups are not supported by this writer")
+        if len(g.children) > 2 * _LEAF_K:
+            raise Hdf5FormatError(f"more than {2 * _LEAF_K} children in one group are not supported by this writer")
+        attrs = [self._attribute(k, v) for k, v in g.attrs.items()]      # before the children: _collect order
+        names = sorted(g.children, key=lambda s: s.encode("utf-8"))
+        entries = []
+        for name in names:
+            child = g.children[name]
+            if isinstance(child, GroupSpec):
+                entries.append((name,) + self._group(child))
+            else:
+                entries.append((name, self._dataset(child), None, None))
+        # local heap: "" at offset 0, the names, one free block
+        seg, offsets = bytearray(8), {}
+        for name in names:
+            offsets[name] = len(seg)
+            seg += _pad8(name.encode("utf-8") + b"\x00")
+        free_off = len(seg)
+        seg += struct.pack("<QQ", 1, 32) + b"\x00" * 16
+        seg_addr = self._append(bytes(seg))
+        heap_addr = self._append(b"HEAP" + bytes(4) + struct.pack("<QQQ", len(seg), free_off, seg_addr))
+        snod = bytearray(b"SNOD" + struct.pack("<BBH", 1, 0, len(names)))
+        for name, header, bt, hp in entries:
+            if bt is None:
+                snod += struct.pack("<QQII16x", offsets[name], header, 0, 0)
+            else:
+                snod += struct.pack("<QQIIQQ", offsets[name], header, 1, 0, bt, hp)
+        snod += b"\x00" * (8 + 40 * 2 * _LEAF_K - len(snod))
+        snod_addr = self._append(bytes(snod))
+        tree = bytearray(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF))
+        tree += struct.pack("<QQQ", 0, snod_addr, offsets[names[-1]])
+        tree += b"\x00" * (24 + (2 * _INTERNAL_K + 1) * 8 + 2 * _INTERNAL_K * 8 - len(tree))
+        btree_addr = self._append(bytes(tree))
+        header = self._header([_message(0x0011, struct.pack("<QQ", btree_addr, heap_addr))] + attrs)
+        return header, btree_addr, heap_addr
+
+
+def write_file(path, root):
+    """Write the tree ``root`` (GroupSpec / DatasetSpec, string attributes) as an HDF5 file."""
+    w = _Writer(root)
+    with open(path, "wb") as f:
+        f.write(bytes(w.buf))
