@@ -44,7 +44,8 @@
  *   - One rq_device = one HIP device + one HIP stream.  Calls on objects of one rq_device are
  *     not re-entrant; objects of different rq_devices are independent.  Calls that return
  *     host data are synchronous w.r.t. that data; everything else is asynchronous on the
- *     device stream (rq_device_synchronize waits).
+ *     device stream (rq_device_synchronize waits).  Host input arrays are pageable memory and are
+ *     fully read before the call returns (the caller may reuse them at once).
  *   - Batch size is a runtime value (the reference bakes it into the module name "vector8").
  *   - Device data is struct-of-arrays, field-major: field f of env i lives at base[f*ld + i]
  *     (ld = n_envs rounded up to 64), so a wavefront's 64 lanes read 256 contiguous bytes.

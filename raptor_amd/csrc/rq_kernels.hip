@@ -14,6 +14,9 @@
 //   k_rollout_fused      the loop body README.md:95-99 x K                       fp32 FMA rate (MFMA + VALU share it;
 //                                                                                state, hidden, weights in registers)
 //   k_record             chained-mode trajectory append                          HBM
+//   k_soa_to_rows /      the NumPy-array side of a call at >= 1024 envs          HBM (+ PCIe copy)
+//   k_rows_to_soa        (row-major [n][dim] <-> field-major [dim][ld], LDS tile)
+// Below 1024 envs k_observe / k_actor_step / k_step exchange host rows through a pinned mailbox (Mailbox).
 #include "rq_device_math.hpp"
 
 namespace rq {
