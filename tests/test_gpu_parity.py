@@ -394,6 +394,85 @@ def test_host_transfers_small_and_large_batch_paths(device, oracle, weights, n):
         assert np.array_equal(w.state.numpy(), w.S)
 
 
+@pytest.mark.parametrize("n", [8, 1000, 1100])
+def test_random_api_sequences_against_a_shadow_model(device, oracle, weights, n):
+    """Model-based fuzz of the API-granular calls: 150 random operations mixing host arrays and the
+    device-resident buffers (both sides of the 1 024-env switch between the pinned mailbox and the GPU layout
+    kernels), back-to-back asynchronous steps, in-place steps and getters in between.  A shadow model driven
+    by the oracle holds what every buffer must contain; env data is compared bit for bit, actions to ACTOR_TOL."""
+    w = World(device, oracle, n, seed=11 + n)
+    w.sync_oracle_to_gpu_state()
+    rng = np.random.default_rng(n)
+    S, NS = w.S.copy(), w.S.copy()                    # shadow of state / next_state
+    w.next_state._ensure(w.env)
+    assert np.all(w.next_state.numpy() == 0)          # a fresh VectorState is all zeros
+    w.next_state.set(NS)                              # (a zero quaternion would only breed NaNs)
+    H = np.tile(weights[2000:2016], (n, 1)).astype(np.float32)
+    obs_dev = np.zeros((n, 26), np.float32)           # shadow of the env's device observation buffer
+    act_dev = np.zeros((n, 4), np.float32)            # shadow of the env's device action buffer
+    epoch = 0
+    w.policy.reset()
+    obs_host = np.zeros((n, 26), np.float32)
+    for it in range(150):
+        op = rng.choice(["observe_host", "observe_dev", "eval_host_host", "eval_dev_dev", "step_host", "step_dev",
+                         "step_inplace", "assign", "get_obs", "get_act", "set_act", "get_state", "stats"])
+        if op == "observe_host":
+            w.vector.observe(device, w.env, w.params, w.state, obs_host, w.rng)
+            obs_dev = oracle.observe(w.cfg, w.seed, epoch, w.offset, w.P, S); epoch += 1
+            assert np.array_equal(obs_host, obs_dev), (it, op)
+        elif op == "observe_dev":
+            w.vector.observe(device, w.env, w.params, w.state, None, w.rng)
+            obs_dev = oracle.observe(w.cfg, w.seed, epoch, w.offset, w.P, S); epoch += 1
+        elif op == "eval_host_host":
+            x = rng.standard_normal((n, 22)).astype(np.float32)
+            wide = np.concatenate([x, np.full((n, 4), np.nan, np.float32)], axis=1)
+            a = w.policy.evaluate_step(wide[:, :22] if it % 2 else x)
+            ref = oracle.actor_batch_step(weights, x, H)
+            assert np.max(np.abs(a - ref)) < 10 * ACTOR_TOL, (it, op)
+        elif op == "eval_dev_dev":
+            w.policy.evaluate_step_device(w.env)
+            act_dev = oracle.actor_batch_step(weights, np.ascontiguousarray(obs_dev[:, :22]), H)
+        elif op in ("step_host", "step_dev", "step_inplace"):
+            if op == "step_host":
+                a = rng.uniform(-1.2, 1.2, (n, 4)).astype(np.float32)
+                for _ in range(int(rng.integers(1, 4))):      # back-to-back: the mailbox must not be overwritten early
+                    w.vector.step(device, w.env, w.params, w.state, a, w.next_state, w.rng)
+                    NS, r, term = oracle.step(w.cfg, w.P, S, a)
+                    oracle.stats_update(w.cfg, r, term, w.st)
+                    a = a * np.float32(0.5)
+                act_dev = a * np.float32(2.0)
+            else:
+                # device-resident action: hold it exactly equal on both sides (fetch what the GPU has)
+                act_dev = w.env.action()
+                dst = w.state if op == "step_inplace" else w.next_state
+                w.vector.step_device(device, w.env, w.params, w.state, dst, w.rng)
+                out, r, term = oracle.step(w.cfg, w.P, S, act_dev)
+                oracle.stats_update(w.cfg, r, term, w.st)
+                if op == "step_inplace":
+                    S = out
+                else:
+                    NS = out
+            assert np.array_equal(w.env.rewards(), r) and np.array_equal(w.env.terminated(), term), (it, op)
+        elif op == "assign":
+            w.state.assign(w.next_state)
+            S = NS.copy()
+        elif op == "get_obs":
+            assert np.array_equal(w.env.observation(), obs_dev), (it, op)
+        elif op == "get_act":
+            got = w.env.action()
+            assert np.max(np.abs(got - act_dev)) < 10 * ACTOR_TOL, (it, op)
+        elif op == "set_act":
+            act_dev = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+            w.env.set_action(act_dev)
+        elif op == "get_state":
+            assert np.array_equal(w.state.numpy(), S), (it, op)
+            assert np.array_equal(w.next_state.numpy(), NS), (it, op)
+        elif op == "stats":
+            assert np.array_equal(w.env.returns(), w.st.returns) and np.array_equal(w.env.episode_steps(), w.st.steps)
+            assert np.array_equal(w.env.finished_counts(), w.st.fin_counts)
+    assert np.array_equal(w.state.numpy(), S) and np.array_equal(w.next_state.numpy(), NS)
+
+
 def test_step_in_place_equals_out_of_place(device, oracle):
     w = World(device, oracle, 300, seed=2)
     act = np.random.default_rng(1).uniform(-1, 1, (300, 4)).astype(np.float32)
