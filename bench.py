@@ -11,7 +11,8 @@ step -> assign for every environment (README.md:96-99).  Workload = BASELINE.jso
 randomised parameters, synthetic (seeded Philox) initial states, the shipped RAPTOR checkpoint
 as the policy.  Auto-reset keeps every env stepping, so every counted env-step is a real one.
 Multi-GPU is weak scaling: each rank owns 65 536 envs (global ids rank*65536 ...), no data-path
-collective, one all-gather of episode returns per 500-step episode (RCCL over xGMI).
+collective, one all-gather of episode returns per 500-step episode (RCCL over xGMI), enqueued behind
+the rollout that produced them and overlapped with the next one.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      dominant kernel of the timed region (the fused rollout kernel)
@@ -252,7 +253,7 @@ def main():
 
     import torch
     import raptor_amd.l2f as l2f
-    from raptor_amd.distributed import all_gather_returns
+    from raptor_amd.distributed import ReturnsExchange
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -267,12 +268,15 @@ def main():
     n_total = n * world
     device = l2f.Device(local_rank)
     shard = Shard(device, n, rank * n, precision=args.precision)
-    returns_buf = torch.empty(n, dtype=torch.float32, device=f"cuda:{local_rank}")
+    # the one exchange step of the path: after every episode-length chunk the last
+    # finished return of every env is all-gathered - copy enqueued on the engine's stream, collective on
+    # a side stream, both overlapped with the next chunk's rollout (raptor_amd.distributed.ReturnsExchange)
+    exchange = ReturnsExchange(n, n_total, f"cuda:{local_rank}", engine_stream=device.stream)
 
-    def episode_exchange():
-        """The one exchange step of the path: gather the last finished episode return of every env."""
-        shard.env.finished_returns(out=returns_buf)
-        return all_gather_returns(returns_buf, n_total)
+    def run(plan):
+        for c in plan:
+            shard.rollout(c, args.mode)
+            exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))
 
     def sync_all():
         device.synchronize()
@@ -286,21 +290,21 @@ def main():
     # ~15 ms).  So (1) a short --warmup is topped up to MIN_UNTIMED_STEPS of the same rollout, and (2) the
     # one-off costs of the exchange (RCCL communicator creation, first barrier) are paid BEFORE the warm-up
     # rollouts, so that only a warm, sub-millisecond barrier separates them from the timed region.
-    episode_exchange()
+    run([1])
+    exchange.finish()
     sync_all()
     untimed = max(args.warmup, MIN_UNTIMED_STEPS)
-    for c in chunks(untimed, EPISODE):
-        shard.rollout(c, args.mode)
+    run(chunks(untimed, EPISODE))
+    exchange.finish()
 
-    # ---- timed region: exactly --steps steps ----
+    # ---- timed region: exactly --steps steps (and one exchange per chunk of <= 500 of them) ----
     plan = chunks(args.steps, EPISODE)
     sync_all()
     t0 = time.perf_counter()
     device.timer_start()
-    for c in plan:
-        shard.rollout(c, args.mode)
+    run(plan)
     kernel_ms = device.timer_stop()          # HIP events on the kernels' stream (also drains it)
-    gathered = episode_exchange() if dist is not None else None
+    gathered = exchange.finish()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -375,8 +379,8 @@ def main():
             result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        if gathered is not None:
-            result["config"]["gathered_returns"] = int(gathered.numel())
+        result["config"]["exchanges_in_timed_region"] = len(plan)
+        result["config"]["gathered_returns"] = int(gathered.numel())
         print(json.dumps(result), flush=True)
 
     if dist is not None:

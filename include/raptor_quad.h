@@ -231,8 +231,13 @@ RQ_API int rq_env_get_action(const rq_env* env, float* host_out);      /* [n_env
 RQ_API int rq_env_set_action(rq_env* env, const float* host_in);
 
 /* ---- episode statistics (reward / termination of transitions taken by rq_step/rq_rollout) */
-/* dst_is_device != 0: dst is a device pointer on the same HIP device (e.g. a torch tensor's
- * data_ptr()), copied on the env's stream and synchronised before return. */
+/* dst_is_device: 0 = host pointer; 1 = device pointer on the same HIP device (e.g. a torch tensor's
+ * data_ptr()), copied on the env's stream and synchronised before return; 2 = device pointer, copy only
+ * ENQUEUED on the env's stream (RQ_DST_DEVICE_ASYNC): order consumers behind rq_device_stream(), e.g. with an
+ * event - this is how a collective overlaps the next rollout (bench.py). */
+#define RQ_DST_HOST 0
+#define RQ_DST_DEVICE 1
+#define RQ_DST_DEVICE_ASYNC 2
 RQ_API int rq_env_get_rewards(const rq_env* env, float* dst, int dst_is_device);          /* last transition */
 RQ_API int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dst_is_device);     /* last transition */
 RQ_API int rq_env_get_returns(const rq_env* env, float* dst, int dst_is_device);          /* running episode */

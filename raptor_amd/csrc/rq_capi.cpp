@@ -278,9 +278,11 @@ template <typename T>
 int copy_out(const rq_env* env, const T* src, T* dst, int dst_is_device) {
     RQ_REQUIRE(env && dst, RQ_ERR_INVALID_ARGUMENT, "null argument");
     int rc = set_device(env->dev); if (rc) return rc;
+    RQ_REQUIRE(dst_is_device >= RQ_DST_HOST && dst_is_device <= RQ_DST_DEVICE_ASYNC, RQ_ERR_INVALID_ARGUMENT,
+               "dst_is_device must be 0, 1 or 2");
     RQ_HIP(hipMemcpyAsync(dst, src, (size_t)env->n * sizeof(T),
                           dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, env->dev->stream));
-    RQ_HIP(hipStreamSynchronize(env->dev->stream));
+    if (dst_is_device != RQ_DST_DEVICE_ASYNC) RQ_HIP(hipStreamSynchronize(env->dev->stream));
     return RQ_OK;
 }
 

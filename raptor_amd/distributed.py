@@ -51,3 +51,73 @@ def all_gather_returns(local_returns, n_total, group=None):
     dist.all_gather_into_tensor(out, padded, group=group)
     out = out.view(world, width)
     return torch.cat([out[r, : sizes[r]] for r in range(world)])
+
+
+class ReturnsExchange:
+    """The path's one exchange, overlapped: a double-buffered all-gather of per-env episode returns that runs
+    beside the NEXT rollout instead of between two rollouts.
+
+    ``post(fill)`` hands ``fill`` a local buffer to fill (on a GPU: an asynchronous device-to-device copy
+    enqueued on the engine's own HIP stream, e.g. ``env.finished_returns(out=buf, wait=False)``) and starts
+    the collective behind it on a side stream; the host does not block.  The engine stream is only held
+    back when it is about to overwrite a buffer whose collective (two posts ago) has not finished.
+    ``finish()`` blocks until the last collective is done and returns its [n_total] result.
+    Equal shards only (``n_total == world * n_local``); ``all_gather_returns`` covers uneven ones.
+    """
+
+    def __init__(self, n_local, n_total, device, engine_stream=None, dtype=torch.float32, group=None):
+        self.group = group
+        self.dist = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size(group) if self.dist else 1
+        if n_total != world * n_local:
+            raise ValueError("ReturnsExchange needs equal shards")
+        device = torch.device(device)
+        self.cuda = device.type == "cuda"
+        self.bufs = [torch.zeros(n_local, dtype=dtype, device=device) for _ in range(2)]
+        self.outs = [torch.zeros(n_total, dtype=dtype, device=device) for _ in range(2)] if self.dist else self.bufs
+        self.work = [None, None]
+        self.posts = 0
+        if self.cuda:
+            if engine_stream is None:
+                raise ValueError("on a GPU the engine's HIP stream is needed to order the copies")
+            self.engine = torch.cuda.ExternalStream(engine_stream, device=device)
+            self.side = torch.cuda.Stream(device=device)
+
+    def post(self, fill):
+        j = self.posts % 2
+        if self.work[j] is not None:           # the collective that last read bufs[j] / wrote outs[j]
+            if self.cuda:
+                with torch.cuda.stream(self.engine):
+                    self.work[j].wait()        # holds the ENGINE stream back, not the host
+            else:
+                self.work[j].wait()
+            self.work[j] = None
+        fill(self.bufs[j])
+        if self.dist:
+            if self.cuda:
+                ready = torch.cuda.Event()
+                ready.record(self.engine)
+                self.side.wait_event(ready)
+                with torch.cuda.stream(self.side):
+                    self.work[j] = dist.all_gather_into_tensor(self.outs[j], self.bufs[j], group=self.group,
+                                                               async_op=True)
+            else:
+                self.work[j] = dist.all_gather_into_tensor(self.outs[j], self.bufs[j], group=self.group,
+                                                           async_op=True)
+        self.posts += 1
+
+    def finish(self):
+        if self.posts == 0:
+            return None
+        for j in range(2):
+            if self.work[j] is not None:
+                if self.cuda:
+                    with torch.cuda.stream(self.side):
+                        self.work[j].wait()
+                else:
+                    self.work[j].wait()
+                self.work[j] = None
+        if self.cuda:
+            self.engine.synchronize()
+            self.side.synchronize()
+        return self.outs[(self.posts - 1) % 2]

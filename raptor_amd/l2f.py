@@ -188,10 +188,10 @@ class VectorModule:
                 _lib.call("rq_env_set_action", self._require("environment"), _lib.fptr(a))
 
             # --- episode statistics ---
-            def _stat(self, fn, dtype, out=None):
+            def _stat(self, fn, dtype, out=None, wait=True):
                 h = self._require("environment")
-                if out is not None:   # a torch tensor on the same HIP device
-                    _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1)
+                if out is not None:   # a torch tensor on the same HIP device; wait=False: only enqueued on
+                    _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1 if wait else 2)   # the engine's stream
                     return out
                 a = np.empty(mod.N_ENVIRONMENTS, dtype)
                 _lib.call(fn, h, a.ctypes.data_as(C.c_void_p), 0)
@@ -201,7 +201,8 @@ class VectorModule:
             def terminated(self, out=None): return self._stat("rq_env_get_terminated", np.uint8, out)
             def returns(self, out=None): return self._stat("rq_env_get_returns", np.float32, out)
             def episode_steps(self, out=None): return self._stat("rq_env_get_episode_steps", np.uint32, out)
-            def finished_returns(self, out=None): return self._stat("rq_env_get_finished_returns", np.float32, out)
+            def finished_returns(self, out=None, wait=True):
+                return self._stat("rq_env_get_finished_returns", np.float32, out, wait)
             def finished_lengths(self, out=None): return self._stat("rq_env_get_finished_lengths", np.uint32, out)
             def finished_counts(self, out=None): return self._stat("rq_env_get_finished_counts", np.uint32, out)
             def finished_terminated(self, out=None): return self._stat("rq_env_get_finished_terminated", np.uint32, out)
