@@ -143,6 +143,32 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process, one HIP runtime.  A PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64;
+    if libraptor_quad.so pulls in the system copies first, a later ``import torch`` maps the bundled ones
+    beside them and finds no GPU (measured on the MI355X box).  Mapping torch's copies first - by path,
+    without importing torch - makes this library bind to them by soname, whichever is imported first.
+    Without an installed torch nothing happens and the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libraptor_quad.so (built in-tree by ``python -m raptor_amd.build``)."""
     global _lib
@@ -150,6 +176,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RaptorQuadError(-2, f"{LIB_PATH} is missing: run `python -m raptor_amd.build` "
                                       "(there is no fallback implementation)")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(lib, name)

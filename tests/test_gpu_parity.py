@@ -886,3 +886,33 @@ def test_error_codes(device, oracle):
     with pytest.raises(l2f.RaptorQuadError) as e:
         env.config = cfg
     assert e.value.status == -1
+
+
+def test_overlapped_returns_exchange_on_the_gpu(device, oracle):
+    """ReturnsExchange on the real streams: finished returns are copied on the engine's HIP stream without a
+    host wait, the (1-rank RCCL) all-gather runs on a side stream behind an event; after finish() the gathered
+    tensor equals the synchronous getter - also after the double buffers were recycled."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from raptor_amd.distributed import ReturnsExchange
+    n = 4096
+    w = World(device, oracle, n, seed=21, episode_step_limit=7)
+    torch.cuda.set_device(0)
+    for with_group in (False, True):
+        if with_group:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", 0))
+        try:
+            ex = ReturnsExchange(n, n, "cuda:0", engine_stream=device.stream)
+            for k in range(5):
+                w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 7, "fused", autoreset=True)
+                ex.post(lambda buf: w.env.finished_returns(out=buf, wait=False))
+            got = ex.finish().cpu().numpy()
+            assert np.array_equal(got, w.env.finished_returns()) and np.any(got != 0)
+        finally:
+            if with_group:
+                dist.destroy_process_group()
