@@ -278,6 +278,16 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
                             uint32_t batch, uint32_t obs_stride, float* action);
 RQ_API int rq_policy_get_hidden(const rq_policy* pol, float* host_out, uint32_t batch); /* [batch,16] */
 RQ_API int rq_policy_set_hidden(rq_policy* pol, const float* host_in, uint32_t batch);
+/* Raptor over a SEQUENCE tensor, the layout rl-tools evaluates and the checkpoint's known-answer example
+ * uses (checkpoint.h:197-215, [seq, batch, feature]): observation [steps, batch, obs_stride] (first 22
+ * columns) -> action [steps, batch, 4].  Equivalent to `steps` calls of rq_policy_evaluate_step - the hidden
+ * state is carried from the policy's current one and left after the last step - in ONE kernel launch
+ * (operand image and GRU state stay in registers).  memory: RQ_DST_HOST = host arrays (copied, synchronous),
+ * RQ_DST_DEVICE = device pointers (synchronised before return), RQ_DST_DEVICE_ASYNC = device pointers, only
+ * enqueued on rq_device_stream(). */
+RQ_API int rq_policy_evaluate_sequence(rq_policy* policy, const float* observation, uint32_t steps, uint32_t batch,
+                                uint32_t obs_stride, float* action, int memory);
+
 /* Known-answer self-test (README.md:136-139): runs `steps` x `batch` of a [steps,batch,22]
  * input through reset()+evaluate_step and reports max |out - expected|. */
 RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* expected,

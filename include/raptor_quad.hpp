@@ -88,6 +88,11 @@ struct Raptor : detail::Handle<rq_policy, rq_policy_destroy> {
     void evaluate_step(Environment& env) {   // device-resident: env observation buffer -> env action buffer
         check(rq_policy_evaluate_step(h, env.h, nullptr, env.N_ENVIRONMENTS, 0, nullptr));
     }
+    // observation [steps, batch, obs_stride] -> action [steps, batch, 4] (host arrays), one launch
+    void evaluate_sequence(const float* observation, std::uint32_t steps, std::uint32_t batch, std::uint32_t obs_stride,
+                           float* action) {
+        check(rq_policy_evaluate_sequence(h, observation, steps, batch, obs_stride, action, RQ_DST_HOST));
+    }
     void set_precision(rq_policy_precision p) { check(rq_policy_set_precision(h, p)); }
 };
 

@@ -127,6 +127,7 @@ _SIGNATURES = {
     "rq_policy_get_hidden": [_vp, _fp, C.c_uint32],
     "rq_policy_set_hidden": [_vp, _fp, C.c_uint32],
     "rq_policy_selftest": [_vp, _fp, _fp, C.c_uint32, C.c_uint32, C.c_float, _fp],
+    "rq_policy_evaluate_sequence": [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_int],
     "rq_rollout": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32],
     "rq_trajectory_create": [_vp, C.c_uint32, C.POINTER(_vp)],
     "rq_trajectory_destroy": [_vp],

@@ -50,6 +50,8 @@ struct rq_device {
     void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
     float* rows = nullptr;         // device scratch, row-major side of the GPU layout changes (large batches)
     size_t rows_bytes = 0;
+    float* rows2 = nullptr;        // second device scratch (sequence evaluation: actions)
+    size_t rows2_bytes = 0;
     size_t staging_bytes = 0;
     void* staging_in = nullptr;    // pinned host buffer for host -> device copies (asynchronous)
     size_t staging_in_bytes = 0;
@@ -403,6 +405,7 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->ev_h2d) (void)hipEventDestroy(dev->ev_h2d);
     if (dev->staging) (void)hipHostFree(dev->staging);
     if (dev->rows) (void)hipFree(dev->rows);
+    if (dev->rows2) (void)hipFree(dev->rows2);
     if (dev->mb_flag) (void)hipHostFree(dev->mb_flag);
     if (dev->mb_in) (void)hipHostFree(dev->mb_in);
     if (dev->mb_out) (void)hipHostFree(dev->mb_out);
@@ -928,6 +931,38 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
         return RQ_OK;
     }
     if (action) return soa_to_host(dev, pol->act, batch, pol->ld, RQ_ACTION_DIM, action);
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_evaluate_sequence(rq_policy* pol, const float* observation, uint32_t steps, uint32_t batch,
+                                uint32_t obs_stride, float* action, int memory) {
+    RQ_REQUIRE(pol && observation && action, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(steps > 0 && batch > 0, RQ_ERR_INVALID_ARGUMENT, "empty sequence");
+    RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
+    RQ_REQUIRE(memory >= RQ_DST_HOST && memory <= RQ_DST_DEVICE_ASYNC, RQ_ERR_INVALID_ARGUMENT, "memory must be 0, 1 or 2");
+    rq_device* dev = pol->dev;
+    int rc = set_device(dev); if (rc) return rc;
+    rc = policy_size(pol, batch); if (rc) return rc;
+    const size_t rows = (size_t)steps * batch;
+    const float* d_obs = observation;
+    float* d_act = action;
+    if (memory == RQ_DST_HOST) {
+        const size_t obs_bytes = ((rows - 1) * obs_stride + RQ_POLICY_INPUT_DIM) * sizeof(float);
+        rc = ensure_rows(dev, rows * obs_stride * sizeof(float)); if (rc) return rc;
+        if (dev->rows2_bytes < rows * RQ_ACTION_DIM * sizeof(float)) {
+            RQ_HIP(hipStreamSynchronize(dev->stream));
+            if (dev->rows2) { RQ_HIP(hipFree(dev->rows2)); dev->rows2 = nullptr; dev->rows2_bytes = 0; }
+            RQ_HIP(hipMalloc(&dev->rows2, rows * RQ_ACTION_DIM * sizeof(float)));
+            dev->rows2_bytes = rows * RQ_ACTION_DIM * sizeof(float);
+        }
+        RQ_HIP(hipMemcpyAsync(dev->rows, observation, obs_bytes, hipMemcpyHostToDevice, dev->stream));
+        d_obs = dev->rows; d_act = dev->rows2;
+    }
+    RQ_HIP(rq::launch_actor_sequence(dev->stream, batch, steps, packed_of(pol), d_obs, obs_stride, pol->hidden, pol->ld,
+                                     d_act, mode_of(pol)));
+    if (memory == RQ_DST_HOST)
+        RQ_HIP(hipMemcpyAsync(action, dev->rows2, rows * RQ_ACTION_DIM * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
+    if (memory != RQ_DST_DEVICE_ASYNC) RQ_HIP(hipStreamSynchronize(dev->stream));
     return RQ_OK;
 }
 

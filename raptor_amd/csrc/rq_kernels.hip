@@ -183,6 +183,60 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
     mailbox_signal(mb);
 }
 
+// register budget of a kernel built around an actor type: waves per SIMD it is compiled for
+template <typename A> struct WavesPerSimd { static constexpr int value = 1; };
+template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; };
+template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; };
+
+// Raptor evaluated over a whole observation SEQUENCE in one launch (rl-tools evaluates [seq, batch, feature]
+// tensors: the known-answer example of the checkpoint is one, checkpoint.h:197-215): obs [T][n][stride]
+// row-major -> act [T][n][4] row-major, the tensors' own layout, no field-major detour.  A wave owns 64 batch
+// elements for all T steps: operand image and GRU state stay in registers, each lane streams its own row
+// (11 x 8-byte loads when the stride is even) and writes its action as one 16-byte store; the next step's
+// row is in flight while the current one is on the matrix cores.  Bound: f32 MFMA rate (3.9 kFLOP per 104 B).
+template <typename ACTOR>
+__global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_actor_sequence(
+        uint32_t n, uint32_t steps, const float* __restrict__ packed, const float* __restrict__ obs, uint32_t stride,
+        float* __restrict__ hidden, uint32_t ld_h, float* __restrict__ act, uint32_t squash) {
+    ACTOR actor;
+    actor.load(packed);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_base = blockIdx.x * kFusedBlock;
+    const uint32_t i0 = wave_base + lane;
+    const uint32_t i = i0 < n ? i0 : n - 1;
+    const bool valid = i0 < n;
+    float hQ[4][4];
+    load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+    const bool wide = (stride & 1u) == 0;                 // wave-uniform: rows are 8-byte aligned
+    auto load_row = [&](uint32_t t, float (&x)[22]) {
+        const float* row = obs + ((size_t)t * n + i) * stride;
+        if (wide) {
+            const float2* r2 = reinterpret_cast<const float2*>(row);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { const float2 v = r2[k]; x[2 * k] = v.x; x[2 * k + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 22; ++k) x[k] = row[k];
+        }
+    };
+    float x[22];
+    load_row(0, x);
+    for (uint32_t t = 0; t < steps; ++t) {
+        float xn[22];
+        const bool more = t + 1 < steps;                  // wave-uniform
+        if (more) load_row(t + 1, xn);
+        float a[4];
+        actor.step(x, hQ, a);
+        if (squash) squash_action(a);
+        if (valid) *reinterpret_cast<float4*>(act + ((size_t)t * n + i0) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < 22; ++k) x[k] = xn[k];
+        }
+    }
+    store_hidden_q(hidden, ld_h, wave_base, __builtin_amdgcn_ballot_w64(valid), hQ);
+}
+
 // ------------------------------------------------------------------ step ---------------
 __device__ __forceinline__ Stats load_stats(const StatsPtrs& st, uint32_t i) {
     return {st.returns[i], st.steps[i], st.fin_returns[i], st.fin_lengths[i], st.fin_counts[i], st.fin_terminated[i]};
@@ -269,9 +323,6 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // Control flow is wave-uniform around the MFMAs (see k_actor_step): lanes past the end of the
 // batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
 // the rare auto-reset branch (no MFMA inside) diverges.
-template <typename A> struct WavesPerSimd { static constexpr int value = 1; };
-template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; };
-template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; };
 
 template <bool NOISE, bool AUTORESET, bool RECORD, typename ACTOR>
 __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
@@ -474,6 +525,20 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
         k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash, mb);
     else
         k_actor_step<ActorF32><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash, mb);
+    return hipGetLastError();
+}
+
+hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, const float* packed, const float* obs,
+                                 uint32_t stride, float* hidden, uint32_t ld_h, float* act, int precision) {
+    if (n == 0 || steps == 0) return hipSuccess;
+    const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
+    precision &= 0xff;
+    const unsigned g = grid_for(n, kFusedBlock);
+    const bool lean = n > 65536u;          // two waves per SIMD only pay when there are that many
+#define RQ_LAUNCH_SEQ(ACT) k_actor_sequence<ACT><<<g, kFusedBlock, 0, s>>>(n, steps, packed, obs, stride, hidden, ld_h, act, squash)
+    if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_SEQ(ActorBF16Lean); else RQ_LAUNCH_SEQ(ActorBF16); }
+    else                                  { if (lean) RQ_LAUNCH_SEQ(ActorF32Lean); else RQ_LAUNCH_SEQ(ActorF32); }
+#undef RQ_LAUNCH_SEQ
     return hipGetLastError();
 }
 

@@ -103,6 +103,10 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
                              int precision, Mailbox mb = Mailbox{});
+// Raptor over a sequence: obs [steps][n][stride] (first 22 columns) -> act [steps][n][4], both row-major on
+// the device; hidden [16][ld_h] is the state before step 0 on entry and after the last step on return
+hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, const float* packed, const float* obs,
+                                 uint32_t stride, float* hidden, uint32_t ld_h, float* act, int precision);
 // vector.step (README.md:98) + reward/termination/statistics.  rollout != 0 adds the
 // episode-end handling of rq_rollout (freeze or auto-reset incl. hidden-state reset).
 // With mb.rows_in the actions come from the mailbox and are also written to `action` (field-major).

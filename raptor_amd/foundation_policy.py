@@ -152,6 +152,30 @@ class Raptor:
                   batch, stride, _lib.fptr(act))
         return act
 
+    def evaluate_sequence(self, observation):
+        """rl-tools' evaluate on a sequence tensor (the layout of the checkpoint's example, checkpoint.h:197-215):
+        ``observation`` [T, B, >=22] -> action [T, B, 4], the same result as T calls of ``evaluate_step`` (hidden
+        state carried from the current one and kept afterwards) in ONE kernel launch.  NumPy in -> NumPy out;
+        a CUDA/HIP torch tensor in (contiguous float32) -> torch tensor out, nothing leaves the device."""
+        if hasattr(observation, "data_ptr"):                # torch tensor on the device
+            import torch
+            obs = observation
+            if obs.dim() != 3 or obs.shape[2] < POLICY_INPUT_DIM or obs.dtype != torch.float32 or not obs.is_cuda \
+                    or not obs.is_contiguous():
+                raise ValueError("observation must be a contiguous float32 device tensor [T, B, >=22]")
+            act = torch.empty((obs.shape[0], obs.shape[1], POLICY_OUTPUT_DIM), dtype=torch.float32, device=obs.device)
+            torch.cuda.current_stream(obs.device).synchronize()       # the engine runs on its own stream
+            _lib.call("rq_policy_evaluate_sequence", self._handle(), C.c_void_p(obs.data_ptr()), obs.shape[0],
+                      obs.shape[1], obs.shape[2], C.c_void_p(act.data_ptr()), 1)
+            return act
+        obs = np.ascontiguousarray(observation, np.float32)
+        if obs.ndim != 3 or obs.shape[2] < POLICY_INPUT_DIM:
+            raise ValueError("observation must be [T, B, >=22]")
+        act = np.empty((obs.shape[0], obs.shape[1], POLICY_OUTPUT_DIM), np.float32)
+        _lib.call("rq_policy_evaluate_sequence", self._handle(), obs.ctypes.data_as(C.c_void_p), obs.shape[0],
+                  obs.shape[1], obs.shape[2], act.ctypes.data_as(C.c_void_p), 0)
+        return act
+
     def evaluate_step_device(self, env):
         """Device-resident variant: reads the env's observation buffer (``observe(..., None, ...)``)
         and writes its action buffer (consumed by ``step(..., action=None, ...)``)."""

@@ -916,3 +916,54 @@ def test_overlapped_returns_exchange_on_the_gpu(device, oracle):
         finally:
             if with_group:
                 dist.destroy_process_group()
+
+
+def test_evaluate_sequence_against_reference_kats(device, kat, weights, oracle):
+    """Raptor.evaluate_sequence on the known-answer tensors in their own layout [500, 2, 22] -> [500, 2, 4]:
+    one kernel launch, < 1e-5 from the reference's outputs, and bit-identical to 500 evaluate_step calls."""
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    p = Raptor(device)
+    p.reset()
+    a = p.evaluate_sequence(x)
+    assert a.shape == y.shape and np.max(np.abs(a - y)) < ACTOR_TOL
+    q = Raptor(device)
+    q.reset()
+    steps = np.stack([q.evaluate_step(x[t]) for t in range(x.shape[0])])
+    assert np.array_equal(a, steps)
+    assert np.array_equal(p.hidden_state(2), q.hidden_state(2))
+
+
+@pytest.mark.parametrize("batch,stride", [(1, 22), (65, 26), (1000, 23), (4096, 22)])
+def test_evaluate_sequence_ragged_strided_and_carried(device, oracle, weights, batch, stride):
+    """Ragged batches, even/odd row strides (columns >= 22 never read), hidden state carried across calls:
+    two half sequences equal the whole one bit for bit; against the oracle within ACTOR_TOL."""
+    from raptor_amd.foundation_policy import Raptor
+    T = 24
+    rng = np.random.default_rng(batch)
+    wide = np.full((T, batch, stride), np.nan, np.float32)
+    wide[:, :, :22] = rng.standard_normal((T, batch, 22)).astype(np.float32)
+    p = Raptor(device)
+    p.reset()
+    whole = p.evaluate_sequence(wide)
+    q = Raptor(device)
+    q.reset()
+    halves = np.concatenate([q.evaluate_sequence(wide[:10]), q.evaluate_sequence(wide[10:])])
+    assert np.array_equal(whole, halves)
+    ref = oracle.actor_sequence(weights, np.ascontiguousarray(wide[:, :, :22]))
+    assert np.max(np.abs(whole - ref)) < ACTOR_TOL
+    assert np.array_equal(p.hidden_state(batch), q.hidden_state(batch))
+
+
+def test_evaluate_sequence_device_tensors_and_bf16(device, kat):
+    import torch
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    p = Raptor(device)
+    p.reset()
+    xt = torch.from_numpy(x).to("cuda:0")
+    at = p.evaluate_sequence(xt)
+    assert at.is_cuda and np.max(np.abs(at.cpu().numpy() - y)) < ACTOR_TOL
+    b = Raptor(device, precision="bf16")
+    b.reset()
+    assert np.max(np.abs(b.evaluate_sequence(x) - y)) < 5e-2
