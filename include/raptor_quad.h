@@ -321,6 +321,13 @@ RQ_API int rq_trajectory_destroy(rq_trajectory* t);
 RQ_API int rq_trajectory_reset(rq_trajectory* t);
 RQ_API int rq_trajectory_length(const rq_trajectory* t, uint32_t* steps, uint32_t* capacity);
 RQ_API int rq_trajectory_get(const rq_trajectory* t, float* obs, float* act, float* rew, uint8_t* done);
+/* Relabel the recorded steps with `policy` (any policy object of this device, e.g. a teacher or a newer
+ * student): actions of `policy` on the recorded observations, its GRU state
+ * starting from the policy's current one (rq_policy_reset for episode starts), reset after recorded episode ends
+ * (done 1/2) and held on frozen steps (done 4).  action_out: host [length, n_envs, 4] or NULL; overwrite != 0
+ * also replaces the trajectory's stored actions.  With the policy that recorded the trajectory the result
+ * equals the stored actions bit for bit. */
+RQ_API int rq_trajectory_relabel(rq_trajectory* t, rq_policy* policy, float* action_out, int overwrite);
 RQ_API int rq_trajectory_device_ptrs(const rq_trajectory* t, float** obs, float** act, float** rew,
                               uint8_t** done, uint32_t* ld);
 RQ_API int rq_rollout_record(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,

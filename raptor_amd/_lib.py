@@ -136,6 +136,7 @@ _SIGNATURES = {
     "rq_trajectory_get": [_vp, _fp, _fp, _fp, _u8p],
     "rq_trajectory_device_ptrs": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u32p],
     "rq_rollout_record": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32, _vp],
+    "rq_trajectory_relabel": [_vp, _vp, _fp, C.c_int],
 }
 _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 

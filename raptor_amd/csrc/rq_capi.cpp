@@ -1193,4 +1193,35 @@ RQ_API int rq_trajectory_get(const rq_trajectory* t, float* obs, float* act, flo
     return RQ_OK;
 }
 
+RQ_API int rq_trajectory_relabel(rq_trajectory* t, rq_policy* pol, float* action_out, int overwrite) {
+    RQ_REQUIRE(t && pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    rq_env* env = t->env;
+    rq_device* dev = env->dev;
+    RQ_REQUIRE(pol->dev == dev, RQ_ERR_SHAPE_MISMATCH, "policy lives on another device");
+    if (t->length == 0) return RQ_OK;
+    int rc = set_device(dev); if (rc) return rc;
+    rc = policy_size(pol, env->n); if (rc) return rc;
+    const size_t act_bytes = (size_t)t->length * RQ_ACTION_DIM * env->ld * sizeof(float);
+    float* d_act = t->act;
+    if (!overwrite) {
+        if (dev->rows2_bytes < act_bytes) {
+            RQ_HIP(hipStreamSynchronize(dev->stream));
+            if (dev->rows2) { RQ_HIP(hipFree(dev->rows2)); dev->rows2 = nullptr; dev->rows2_bytes = 0; }
+            RQ_HIP(hipMalloc(&dev->rows2, act_bytes));
+            dev->rows2_bytes = act_bytes;
+        }
+        d_act = dev->rows2;
+    }
+    RQ_HIP(rq::launch_actor_relabel(dev->stream, env->n, env->ld, t->length, packed_of(pol), t->obs, t->done, pol->hidden,
+                                    pol->ld, d_act, mode_of(pol)));
+    if (action_out) {
+        for (uint32_t s = 0; s < t->length; ++s) {
+            rc = soa_to_host(dev, d_act + (size_t)s * RQ_ACTION_DIM * env->ld, env->n, env->ld, RQ_ACTION_DIM,
+                             action_out + (size_t)s * env->n * RQ_ACTION_DIM);
+            if (rc) return rc;
+        }
+    }
+    return RQ_OK;
+}
+
 }  // extern "C"

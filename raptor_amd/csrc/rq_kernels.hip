@@ -237,6 +237,52 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
     store_hidden_q(hidden, ld_h, wave_base, __builtin_amdgcn_ballot_w64(valid), hQ);
 }
 
+// Relabel a recorded trajectory: evaluate `packed` - any policy of the
+// supported topology, e.g. a teacher or a newer student - on the observations a rollout stored, in the
+// trajectory's own field-major layout obs [T][22][ld] -> act [T][4][ld], following the recorded episode
+// structure: after a step whose done code is 1 or 2 (episode ended) the GRU state returns to the initial
+// hidden state, a step with code 4 (env frozen, not stepped) does not advance it.  With the policy that
+// recorded the trajectory this reproduces the recorded actions bit for bit.
+template <typename ACTOR>
+__global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_actor_relabel(
+        uint32_t n, uint32_t ld, uint32_t steps, const float* __restrict__ packed, const float* __restrict__ obs,
+        const uint8_t* __restrict__ done, float* __restrict__ hidden, uint32_t ld_h, float* __restrict__ act,
+        uint32_t squash) {
+    ACTOR actor;
+    actor.load(packed);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_base = blockIdx.x * kFusedBlock;
+    const uint32_t i0 = wave_base + lane;
+    const uint32_t i = i0 < n ? i0 : n - 1;
+    const bool valid = i0 < n;
+    float hQ[4][4], h0Q[4][4];
+    load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h0Q[t][r] = actor.h0(r);
+    for (uint32_t t = 0; t < steps; ++t) {
+        float x[22], a[4], hn[4][4];
+#pragma unroll
+        for (int k = 0; k < 22; ++k) x[k] = field(obs, t * 22 + k, ld)[i];
+        const uint8_t d = done[(size_t)t * ld + i];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
+        actor.step(x, hn, a);
+        if (squash) squash_action(a);
+        select_hidden_q(__builtin_amdgcn_ballot_w64(d != 4), hn, hQ);          // frozen: state not advanced
+        const uint64_t ended = __builtin_amdgcn_ballot_w64(d == 1 || d == 2);
+        if (ended != 0) select_hidden_q(ended, h0Q, hQ);                        // episode end: policy reset
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) field(act, t * 4 + k, ld)[i] = a[k];
+        }
+    }
+    store_hidden_q(hidden, ld_h, wave_base, __builtin_amdgcn_ballot_w64(valid), hQ);
+}
+
 // ------------------------------------------------------------------ step ---------------
 __device__ __forceinline__ Stats load_stats(const StatsPtrs& st, uint32_t i) {
     return {st.returns[i], st.steps[i], st.fin_returns[i], st.fin_lengths[i], st.fin_counts[i], st.fin_terminated[i]};
@@ -539,6 +585,21 @@ hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, cons
     if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_SEQ(ActorBF16Lean); else RQ_LAUNCH_SEQ(ActorBF16); }
     else                                  { if (lean) RQ_LAUNCH_SEQ(ActorF32Lean); else RQ_LAUNCH_SEQ(ActorF32); }
 #undef RQ_LAUNCH_SEQ
+    return hipGetLastError();
+}
+
+hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t steps, const float* packed,
+                                const float* obs, const uint8_t* done, float* hidden, uint32_t ld_h, float* act,
+                                int precision) {
+    if (n == 0 || steps == 0) return hipSuccess;
+    const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
+    precision &= 0xff;
+    const unsigned g = grid_for(n, kFusedBlock);
+    const bool lean = n > 65536u;
+#define RQ_LAUNCH_RELABEL(ACT) k_actor_relabel<ACT><<<g, kFusedBlock, 0, s>>>(n, ld, steps, packed, obs, done, hidden, ld_h, act, squash)
+    if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_RELABEL(ActorBF16Lean); else RQ_LAUNCH_RELABEL(ActorBF16); }
+    else                                  { if (lean) RQ_LAUNCH_RELABEL(ActorF32Lean); else RQ_LAUNCH_RELABEL(ActorF32); }
+#undef RQ_LAUNCH_RELABEL
     return hipGetLastError();
 }
 

@@ -107,6 +107,11 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
 // the device; hidden [16][ld_h] is the state before step 0 on entry and after the last step on return
 hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, const float* packed, const float* obs,
                                  uint32_t stride, float* hidden, uint32_t ld_h, float* act, int precision);
+// a policy over a recorded trajectory: obs [steps][22][ld], done [steps][ld] -> act [steps][4][ld] (field-major),
+// GRU state reset after done codes 1/2, held on code 4; hidden [16][ld_h] in/out
+hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t steps, const float* packed,
+                                const float* obs, const uint8_t* done, float* hidden, uint32_t ld_h, float* act,
+                                int precision);
 // vector.step (README.md:98) + reward/termination/statistics.  rollout != 0 adds the
 // episode-end handling of rq_rollout (freeze or auto-reset incl. hidden-state reset).
 // With mb.rows_in the actions come from the mailbox and are also written to `action` (field-major).

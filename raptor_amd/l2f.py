@@ -290,6 +290,18 @@ class VectorModule:
                           _lib.fptr(out["rew"]), out["done"].ctypes.data_as(C.POINTER(C.c_uint8)))
                 return out
 
+            def relabel(self, policy, overwrite=False, fetch=True):
+                """Actions of ``policy`` (a teacher, a newer student, ...) on the recorded observations, following
+                the recorded episode structure (GRU state reset after episode ends, held on frozen steps; it
+                starts from the policy's current hidden state: ``policy.reset()`` for episode starts).
+                -> [T, N, 4] (``fetch=False``: only on the device); ``overwrite=True`` also replaces the stored
+                actions.  With the policy that recorded the trajectory the result equals the stored actions."""
+                T, N = len(self), mod.N_ENVIRONMENTS
+                out = np.empty((T, N, 4), np.float32) if fetch else None
+                _lib.call("rq_trajectory_relabel", self._h, policy._handle(self._env._device),
+                          _lib.fptr(out) if fetch else None, 1 if overwrite else 0)
+                return out
+
         self.Trajectory = Trajectory
         self.VectorRng = VectorRng
         self.VectorEnvironment = VectorEnvironment

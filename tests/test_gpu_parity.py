@@ -967,3 +967,52 @@ def test_evaluate_sequence_device_tensors_and_bf16(device, kat):
     b = Raptor(device, precision="bf16")
     b.reset()
     assert np.max(np.abs(b.evaluate_sequence(x) - y)) < 5e-2
+
+
+@pytest.mark.parametrize("autoreset", [False, True])
+@pytest.mark.parametrize("n", [300, 70000])
+def test_trajectory_relabel_with_the_recording_policy_is_the_identity(device, oracle, n, autoreset):
+    """Relabelling a recorded rollout with the policy that produced it must give back the stored actions bit
+    for bit on every step that was taken - through episode ends (GRU reset), auto-resets and past frozen envs."""
+    from raptor_amd.foundation_policy import Raptor
+    w = World(device, oracle, n, seed=31, episode_step_limit=9, termination_position=0.6)
+    T = 64
+    traj = w.vector.Trajectory(w.env, T)
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T, "fused", autoreset=autoreset, trajectory=traj)
+    rec = traj.numpy()
+    assert {0, 2}.issubset(set(np.unique(rec["done"]).tolist()))          # episodes did end inside the recording
+    if not autoreset:
+        assert 4 in np.unique(rec["done"])                                 # and envs froze
+    teacher = Raptor(device)                      # same weights, separate object and hidden state
+    teacher.reset()
+    relabelled = traj.relabel(teacher)
+    live = rec["done"] != 4                       # steps of frozen envs carry no defined action in a recording
+    assert live.sum() >= 9 * n // 2 and np.array_equal(relabelled[live], rec["act"][live])
+    assert np.array_equal(traj.numpy()["act"], rec["act"])                 # overwrite=False left the buffer alone
+
+
+def test_trajectory_relabel_with_another_policy(device, oracle, weights):
+    """A different policy (perturbed weights, standing in for a teacher) on the recorded observations: equals
+    the oracle's actor run over each env's observation sequence with a reset after every recorded episode end;
+    overwrite=True replaces the stored actions."""
+    from raptor_amd.foundation_policy import Raptor
+    n, T = 200, 40
+    w = World(device, oracle, n, seed=33, episode_step_limit=11)
+    traj = w.vector.Trajectory(w.env, T)
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T, "fused", autoreset=True, trajectory=traj)
+    rec = traj.numpy()
+    w2 = (weights + np.random.default_rng(0).standard_normal(weights.size).astype(np.float32) * 0.02).astype(np.float32)
+    w2[2000:2016] = 0.05                          # a non-zero initial hidden state makes the resets visible
+    teacher = Raptor(device, weights=w2)
+    teacher.reset()
+    got = traj.relabel(teacher, overwrite=True)
+    H = np.tile(w2[2000:2016], (n, 1)).astype(np.float32)
+    for t in range(T):
+        ref = oracle.actor_batch_step(w2, np.ascontiguousarray(rec["obs"][t]), H)
+        assert np.max(np.abs(got[t] - ref)) < ACTOR_TOL, t
+        ended = (rec["done"][t] == 1) | (rec["done"][t] == 2)
+        H[ended] = w2[2000:2016]
+    assert np.array_equal(traj.numpy()["act"], got)
+    assert not np.array_equal(got, rec["act"])
