@@ -154,6 +154,47 @@ def kernel_probe(device, n, reps):
     return out
 
 
+def extension_probe(device, n):
+    """The two rows beside the loop body: the rollout WITH trajectory recording, and the
+    policy over a whole [T, n, 22] device tensor in one launch (Raptor.evaluate_sequence)."""
+    import torch
+    from raptor_amd.foundation_policy import Raptor
+    out = {}
+    sh = Shard(device, n, 0)
+    steps = 200
+    traj = sh.vector.Trajectory(sh.env, steps)
+    for _ in range(4):
+        sh.rollout(500, "fused")
+    best = 1e9
+    for _ in range(3):
+        traj.reset()
+        device.timer_start()
+        sh.vector.rollout(device, sh.env, sh.params, sh.state, sh.policy, sh.rng, steps, "fused", autoreset=True,
+                          trajectory=traj)
+        best = min(best, device.timer_stop())
+    rate = n * steps / (best * 1e-3)
+    out["rollout_recorded"] = {"env_steps_per_s": round(rate, 1), "us_per_step": round(best * 1e3 / steps, 3),
+                               "trajectory_bytes_per_env_step": 109, "trajectory_GBps": round(rate * 109 / 1e9, 1)}
+    del traj, sh
+    pol = Raptor(device)
+    pol.reset()
+    x = torch.randn(steps, n, 22, device="cuda:%d" % torch.cuda.current_device())
+    for _ in range(3):
+        pol.evaluate_sequence(x)
+    best = 1e9
+    for _ in range(3):
+        device.timer_start()
+        pol.evaluate_sequence(x)
+        best = min(best, device.timer_stop())
+    rate = n * steps / (best * 1e-3)
+    tf = rate * FLOP_ACTOR / 1e12
+    out["evaluate_sequence"] = {"bound": "mfma", "policy_steps_per_s": round(rate, 1),
+                                "us_per_step": round(best * 1e3 / steps, 3), "achieved_TFLOPs": round(tf, 2),
+                                "peak_TFLOPs": PEAK_FP32_TFLOPS, "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                                "bytes_per_step": 104, "achieved_GBps": round(rate * 104 / 1e9, 1)}
+    return out
+
+
 def api_loop_probe(device, n=8, iters=500):
     """BASELINE config 1 shape: the README loop (README.md:94-99), NumPy arrays crossing the boundary
     every call (PCIe-inclusive, host-bound by construction), and the same loop kept on the device.
@@ -375,6 +416,7 @@ def main():
         if world == 1 and not args.no_kernel_probe:
             result["kernels"] = {"n65536": kernel_probe(device, ENVS_PER_GPU, 200),
                                  "n2097152": kernel_probe(device, 2097152, 20)}
+            result["extensions_n65536"] = extension_probe(device, ENVS_PER_GPU)
             result["readme_loop_n8"] = api_loop_probe(device)
             result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
         if world == 1 and not args.no_cpu_baseline:

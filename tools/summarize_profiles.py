@@ -76,6 +76,24 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     f.write("| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
     for r in rows:
         f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {r['Percentage']} |\n")
+    # the dominant kernel, call by call: --stats averages every launch of the process, including the first
+    # ones at ramping clocks and the probes' launches; the timed region of bench.py is a known slice of them
+    trace = os.path.join(src, "trace", "bench_kernel_trace.csv")
+    bench_json = os.path.join(src, "bench_trace.json")
+    if os.path.exists(trace) and os.path.exists(bench_json):
+        b = json.loads(open(bench_json).read().strip().splitlines()[-1])
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace))
+                if "k_rollout_fused<false, true, false" in r["Kernel_Name"]]
+        untimed = 1 + -(-b["config"]["untimed_steps_before_timing"] // 500)     # the 1-step launch + warm-up chunks
+        timed = -(-b["steps"] // 500)
+        region = durs[untimed:untimed + timed]
+        if region:
+            f.write(f"\nDominant kernel `k_rollout_fused`, launch by launch (us): first {untimed} launches are "
+                    f"untimed (1 step, then {untimed - 1} x 500 steps while the clocks ramp): "
+                    f"{', '.join(str(round(x)) for x in durs[:untimed])}; the {timed} launches of the timed region: "
+                    f"mean **{sum(region) / len(region):.1f}**, min {min(region):.0f}, max {max(region):.0f} "
+                    f"(bench.py's HIP events in the same run: {b['roofline']['avg_launch_ms'] * 1e3:.1f} per launch incl. the "
+                    f"per-chunk copy of the returns); later launches belong to the probes.\n")
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
     f.write("| kernel@grid | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|\n")
     for k, d in out.items():
