@@ -5,7 +5,9 @@
  *   gcc -std=c11 -O2 -Iinclude examples/readme_loop.c -Lraptor_amd -lraptor_quad \
  *       -Wl,-rpath,$PWD/raptor_amd -o readme_loop && ./readme_loop raptor_amd/data/raptor_policy.bin
  */
+#define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include "raptor_quad.h"
 
@@ -43,6 +45,8 @@ int main(int argc, char** argv) {
 
     static float observation[N * RQ_OBSERVATION_DIM], action[N * RQ_ACTION_DIM], dts[N], s[N * RQ_STATE_DIM];
     CHECK(rq_policy_reset(policy));                                        /* policy.reset()                   :94 */
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int step = 0; step < STEPS; ++step) {
         CHECK(rq_observe(device, env, params, state, observation, rng));   /*                                  :96 */
         CHECK(rq_policy_evaluate_step(policy, NULL, observation, N, RQ_OBSERVATION_DIM, action));  /* [:, :22]   :97 */
@@ -50,6 +54,9 @@ int main(int argc, char** argv) {
         CHECK(rq_state_assign(state, next_state));                         /*                                  :99 */
     }
     CHECK(rq_state_get(state, s));
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    printf("%d iterations of observe -> evaluate_step -> step -> assign with host arrays: %.1f us per iteration\n", STEPS,
+           ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / STEPS);
     for (int i = 0; i < N; ++i)
         printf("env %d: position (%+.3f %+.3f %+.3f) after %d steps of %.0f ms\n", i, s[i * RQ_STATE_DIM],
                s[i * RQ_STATE_DIM + 1], s[i * RQ_STATE_DIM + 2], STEPS, dts[i] * 1e3f);
