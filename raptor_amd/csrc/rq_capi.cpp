@@ -1041,7 +1041,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     const rq::NoiseCfg nc = rq::noise_cfg(env->cfg);
     const rq::SampleCfg smp = rq::sample_cfg(env->cfg);
     const bool noise = rq::noise_enabled(env->cfg);
-    if (traj && n_steps)   // steps a frozen wave never reaches read as "not stepped"
+    if (traj && n_steps && !(flags & RQ_ROLLOUT_AUTORESET))   // steps a frozen wave never reaches read as "not stepped"
         RQ_HIP(hipMemsetAsync(traj->done + (size_t)traj->length * env->ld, 4, (size_t)n_steps * env->ld, dev->stream));
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
