@@ -59,9 +59,12 @@ class EnvConfig(C.Structure):
 
 
 _vp = C.c_void_p
-_fp = C.POINTER(C.c_float)
+# array arguments are declared void* so that a plain integer address can be passed: numpy's
+# ``a.ctypes.data_as(POINTER(c_float))`` costs 3 us per call, ``a.ctypes.data`` 1 us - five arrays cross the
+# boundary in one iteration of the reference's loop
+_fp = C.c_void_p
 _u32p = C.POINTER(C.c_uint32)
-_u8p = C.POINTER(C.c_uint8)
+_u8p = C.c_void_p
 
 # name -> argtypes (every function returns int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -197,10 +200,19 @@ def check(status):
     return status
 
 
+_fns = {}
+
+
 def call(name, *args):
-    return check(getattr(load(), name)(*args))
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    status = fn(*args)
+    if status != 0:
+        check(status)
+    return status
 
 
 def fptr(a):
-    """float32 C-contiguous numpy array -> float*"""
-    return a.ctypes.data_as(_fp)
+    """C-contiguous numpy array -> its address (an int; the argtypes of array arguments are void*)"""
+    return a.ctypes.data

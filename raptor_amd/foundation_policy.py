@@ -148,7 +148,7 @@ class Raptor:
             stride = obs.shape[1]
         batch = obs.shape[0]
         act = np.empty((batch, POLICY_OUTPUT_DIM), np.float32)
-        _lib.call("rq_policy_evaluate_step", self._handle(), None, obs.ctypes.data_as(C.POINTER(C.c_float)),
+        _lib.call("rq_policy_evaluate_step", self._handle(), None, obs.ctypes.data,
                   batch, stride, _lib.fptr(act))
         return act
 
@@ -172,8 +172,8 @@ class Raptor:
         if obs.ndim != 3 or obs.shape[2] < POLICY_INPUT_DIM:
             raise ValueError("observation must be [T, B, >=22]")
         act = np.empty((obs.shape[0], obs.shape[1], POLICY_OUTPUT_DIM), np.float32)
-        _lib.call("rq_policy_evaluate_sequence", self._handle(), obs.ctypes.data_as(C.c_void_p), obs.shape[0],
-                  obs.shape[1], obs.shape[2], act.ctypes.data_as(C.c_void_p), 0)
+        _lib.call("rq_policy_evaluate_sequence", self._handle(), obs.ctypes.data, obs.shape[0],
+                  obs.shape[1], obs.shape[2], act.ctypes.data, 0)
         return act
 
     def evaluate_step_device(self, env):

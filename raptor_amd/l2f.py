@@ -194,7 +194,7 @@ class VectorModule:
                     _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1 if wait else 2)   # the engine's stream
                     return out
                 a = np.empty(mod.N_ENVIRONMENTS, dtype)
-                _lib.call(fn, h, a.ctypes.data_as(C.c_void_p), 0)
+                _lib.call(fn, h, a.ctypes.data, 0)
                 return a
 
             def rewards(self, out=None): return self._stat("rq_env_get_rewards", np.float32, out)
@@ -287,7 +287,7 @@ class VectorModule:
                 out = dict(obs=np.empty((T, N, 22), np.float32), act=np.empty((T, N, 4), np.float32),
                            rew=np.empty((T, N), np.float32), done=np.empty((T, N), np.uint8))
                 _lib.call("rq_trajectory_get", self._h, _lib.fptr(out["obs"]), _lib.fptr(out["act"]),
-                          _lib.fptr(out["rew"]), out["done"].ctypes.data_as(C.POINTER(C.c_uint8)))
+                          _lib.fptr(out["rew"]), out["done"].ctypes.data)
                 return out
 
             def relabel(self, policy, overwrite=False, fetch=True):
