@@ -242,16 +242,38 @@ class VectorModule:
             _destroy, _create, _get, _set, _dim = ("rq_state_destroy", "rq_state_create", "rq_state_get",
                                                    "rq_state_set", STATE_DIM)
 
+            _mirror = None      # host copy handed out by ``.states``; written back before the next device use
+
+            def _flush(self):
+                m, self._mirror = self._mirror, None
+                if m is not None and self._h is not None:
+                    _lib.call(self._set, self._h, _lib.fptr(m))
+
+            def _require(self, what):
+                if self._mirror is not None:
+                    self._flush()
+                return super()._require(what)
+
+            def _ensure(self, env):
+                if self._mirror is not None:
+                    self._flush()
+                return super()._ensure(env)
+
             def assign(self, other):
                 """``state.assign(next_state)`` (README.md:99)."""
                 if self._h is None:
                     self._ensure(other._env)
+                self._mirror = None                       # overwritten anyway
                 _lib.call("rq_state_assign", self._h, other._require("VectorState"))
 
             @property
             def states(self):
-                """Host snapshot, one view per env (``.position`` etc., README.md:73-75)."""
-                return [_StateView(r) for r in self.numpy()]
+                """One view per env (``.position`` etc., README.md:73-75).  Like the reference's, the views are
+                writable - ``s.position[0] += 0.1`` (README.md:74) changes this VectorState: they alias a host
+                copy that is written back to the device before the next call that uses the state (views kept
+                beyond that call are stale)."""
+                self._mirror = m = self.numpy()
+                return [_StateView(r) for r in m]
 
             def __copy__(self):
                 c = VectorState()

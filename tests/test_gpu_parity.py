@@ -1016,3 +1016,29 @@ def test_trajectory_relabel_with_another_policy(device, oracle, weights):
         H[ended] = w2[2000:2016]
     assert np.array_equal(traj.numpy()["act"], got)
     assert not np.array_equal(got, rec["act"])
+
+
+def test_state_views_are_writable_like_the_reference(device):
+    """README.md:72-76: ``ui_state = copy(state); for i, s in enumerate(ui_state.states): s.position[0] += i * 0.1``
+    must move the copy (and only the copy)."""
+    from copy import copy
+    import raptor_amd.l2f as l2f
+    vector = l2f.vector(8)
+    rng, env, params, state = vector.VectorRng(), vector.VectorEnvironment(), vector.VectorParameters(), vector.VectorState()
+    vector.initialize_rng(device, rng, 0)
+    vector.initialize_environment(device, env)
+    vector.sample_initial_parameters(device, env, params, rng)
+    vector.sample_initial_state(device, env, params, state, rng)
+    before = state.numpy()
+    ui_state = copy(state)
+    for i, s in enumerate(ui_state.states):
+        s.position[0] += i * 0.1
+    shifted = before.copy()
+    shifted[:, 0] += (np.arange(8) * 0.1).astype(np.float32)
+    assert np.array_equal(ui_state.numpy(), shifted)
+    assert np.array_equal(state.numpy(), before)
+    # the written-back state is what the device functions see
+    obs = np.zeros((8, 26), np.float32)
+    vector.observe(device, env, params, ui_state, obs, rng)
+    assert np.array_equal(obs[:, 0], shifted[:, 0])
+    assert [tuple(s.position) for s in ui_state.states] == [tuple(r[:3]) for r in shifted]
