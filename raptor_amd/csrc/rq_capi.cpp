@@ -6,6 +6,7 @@
 // There is NO CPU fallback: without a HIP device rq_device_create fails with RQ_ERR_NO_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1172,21 +1173,33 @@ RQ_API int rq_trajectory_device_ptrs(const rq_trajectory* t, float** obs, float*
 }
 
 // host copies, learner layout: obs [T, N, 22], act [T, N, 4], rew [T, N], done [T, N]; any pointer may be NULL
+// [steps][dim][ld] on the device -> host [steps][n][dim]: one layout launch per chunk of steps, one copy
+static int traj_block_to_host(rq_device* dev, const float* d_soa, uint32_t steps, uint32_t n, uint32_t ld, uint32_t dim,
+                              float* host) {
+    const size_t per_step = (size_t)n * dim * sizeof(float);
+    uint32_t chunk = (uint32_t)std::min<size_t>(steps, std::max<size_t>(1, ((size_t)1 << 30) / per_step));   // <= 1 GiB scratch
+    if (chunk > 65535u) chunk = 65535u;
+    int rc = ensure_rows(dev, per_step * chunk); if (rc) return rc;
+    for (uint32_t s0 = 0; s0 < steps; s0 += chunk) {
+        const uint32_t c = std::min(chunk, steps - s0);
+        RQ_HIP(rq::launch_soa_to_rows(dev->stream, d_soa + (size_t)s0 * dim * ld, ld, dim, n, dev->rows, c));
+        RQ_HIP(hipMemcpyAsync(host + (size_t)s0 * n * dim, dev->rows, per_step * c, hipMemcpyDeviceToHost, dev->stream));
+        RQ_HIP(hipStreamSynchronize(dev->stream));
+    }
+    return RQ_OK;
+}
+
 RQ_API int rq_trajectory_get(const rq_trajectory* t, float* obs, float* act, float* rew, uint8_t* done) {
     RQ_REQUIRE(t, RQ_ERR_INVALID_ARGUMENT, "null argument");
     rq_env* env = t->env;
     rq_device* dev = env->dev;
     const uint32_t n = env->n, ld = env->ld;
-    for (uint32_t s = 0; s < t->length; ++s) {
-        int rc;
-        if (obs) { rc = soa_to_host(dev, t->obs + (size_t)s * RQ_POLICY_INPUT_DIM * ld, n, ld, RQ_POLICY_INPUT_DIM,
-                                    obs + (size_t)s * n * RQ_POLICY_INPUT_DIM); if (rc) return rc; }
-        if (act) { rc = soa_to_host(dev, t->act + (size_t)s * RQ_ACTION_DIM * ld, n, ld, RQ_ACTION_DIM,
-                                    act + (size_t)s * n * RQ_ACTION_DIM); if (rc) return rc; }
-        if (rew) { rc = soa_to_host(dev, t->rew + (size_t)s * ld, n, ld, 1, rew + (size_t)s * n); if (rc) return rc; }
-    }
+    int rc = set_device(dev); if (rc) return rc;
+    if (t->length == 0) return RQ_OK;
+    if (obs) { rc = traj_block_to_host(dev, t->obs, t->length, n, ld, RQ_POLICY_INPUT_DIM, obs); if (rc) return rc; }
+    if (act) { rc = traj_block_to_host(dev, t->act, t->length, n, ld, RQ_ACTION_DIM, act); if (rc) return rc; }
+    if (rew) { rc = traj_block_to_host(dev, t->rew, t->length, n, ld, 1, rew); if (rc) return rc; }
     if (done) {
-        int rc = set_device(dev); if (rc) return rc;
         RQ_HIP(hipMemcpy2DAsync(done, n, t->done, ld, n, t->length, hipMemcpyDeviceToHost, dev->stream));
         RQ_HIP(hipStreamSynchronize(dev->stream));
     }
@@ -1214,13 +1227,7 @@ RQ_API int rq_trajectory_relabel(rq_trajectory* t, rq_policy* pol, float* action
     }
     RQ_HIP(rq::launch_actor_relabel(dev->stream, env->n, env->ld, t->length, packed_of(pol), t->obs, t->done, pol->hidden,
                                     pol->ld, d_act, mode_of(pol)));
-    if (action_out) {
-        for (uint32_t s = 0; s < t->length; ++s) {
-            rc = soa_to_host(dev, d_act + (size_t)s * RQ_ACTION_DIM * env->ld, env->n, env->ld, RQ_ACTION_DIM,
-                             action_out + (size_t)s * env->n * RQ_ACTION_DIM);
-            if (rc) return rc;
-        }
-    }
+    if (action_out) return traj_block_to_host(dev, d_act, t->length, env->n, env->ld, RQ_ACTION_DIM, action_out);
     return RQ_OK;
 }
 

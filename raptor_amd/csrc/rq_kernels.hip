@@ -678,10 +678,13 @@ hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* 
 // row per instruction, row-major side the tile's 64*dim contiguous floats.  kMaxDim bounds the LDS tile.
 static constexpr int kMaxDim = 32;
 
+// blockIdx.y = slab: slab s reads soa + s*dim*ld and writes rows + s*n*dim (the steps of a trajectory)
 __global__ __launch_bounds__(64) void k_soa_to_rows(const float* __restrict__ soa, uint32_t ld, uint32_t dim,
                                                       uint32_t n, float* __restrict__ rows) {
     __shared__ float tile[64 * (kMaxDim + 1)];
     const uint32_t lane = threadIdx.x, base = blockIdx.x * 64u;
+    soa += (size_t)blockIdx.y * dim * ld;
+    rows += (size_t)blockIdx.y * n * dim;
     const uint32_t pitch = dim + 1;                       // odd pitch for dim = 4, 16, 26: no bank conflicts
     for (uint32_t f = 0; f < dim; ++f) tile[lane * pitch + f] = soa[(size_t)f * ld + base + lane];   // ld >= base + 64
     __syncthreads();
@@ -706,10 +709,11 @@ __global__ __launch_bounds__(64) void k_rows_to_soa(const float* __restrict__ ro
     for (uint32_t f = 0; f < dim; ++f) soa[(size_t)f * ld + base + lane] = lane < envs ? tile[lane * pitch + f] : 0.0f;
 }
 
-hipError_t launch_soa_to_rows(hipStream_t s, const float* soa, uint32_t ld, uint32_t dim, uint32_t n, float* rows) {
-    if (n == 0 || dim == 0) return hipSuccess;
-    if (dim > (uint32_t)kMaxDim) return hipErrorInvalidValue;
-    k_soa_to_rows<<<(n + 63u) / 64u, 64, 0, s>>>(soa, ld, dim, n, rows);
+hipError_t launch_soa_to_rows(hipStream_t s, const float* soa, uint32_t ld, uint32_t dim, uint32_t n, float* rows,
+                              uint32_t slabs) {
+    if (n == 0 || dim == 0 || slabs == 0) return hipSuccess;
+    if (dim > (uint32_t)kMaxDim || slabs > 65535u) return hipErrorInvalidValue;
+    k_soa_to_rows<<<dim3((n + 63u) / 64u, slabs), 64, 0, s>>>(soa, ld, dim, n, rows);
     return hipGetLastError();
 }
 

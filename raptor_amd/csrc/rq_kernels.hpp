@@ -161,7 +161,9 @@ void pack_policy_bf16(const float* weights, float* packed);
 
 // layout changes at the boundary (device pointers): field-major [dim][ld] <-> row-major [n][dim|stride],
 // dim <= 32; rows_to_soa zeroes the padding lanes n..ld-1
-hipError_t launch_soa_to_rows(hipStream_t s, const float* soa, uint32_t ld, uint32_t dim, uint32_t n, float* rows);
+// slabs > 1: consecutive [dim][ld] blocks (the steps of a trajectory) -> consecutive [n][dim] blocks, one launch
+hipError_t launch_soa_to_rows(hipStream_t s, const float* soa, uint32_t ld, uint32_t dim, uint32_t n, float* rows,
+                              uint32_t slabs = 1);
 hipError_t launch_rows_to_soa(hipStream_t s, const float* rows, uint32_t stride, uint32_t dim, uint32_t n, uint32_t ld,
                               float* soa);
 
