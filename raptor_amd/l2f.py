@@ -90,6 +90,22 @@ class _Handle:
         return self._h
 
 
+class _DeviceArray:
+    """A device buffer of the engine described by ``__cuda_array_interface__`` (version 3): PyTorch (and CuPy,
+    Numba) wrap it WITHOUT a copy - ``torch.as_tensor(x, device="cuda")`` - so a learner reads rollouts where
+    the engine wrote them.  ``owner`` keeps the C object alive as long as a tensor made from this exists."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(int(d) for d in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+def _as_torch(ptr, shape, typestr, owner):
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, shape, typestr, owner), device="cuda")
+
+
 class _StateView:
     """One element of ``VectorState.states`` (README.md:73-75): a host-side snapshot."""
     __slots__ = ("_row",)
@@ -182,6 +198,25 @@ class VectorModule:
                 _lib.call("rq_env_get_action", self._require("environment"), _lib.fptr(out))
                 return out
 
+            def _ld(self):
+                ld = C.c_uint32()
+                _lib.call("rq_env_leading_dim", self._require("environment"), C.byref(ld))
+                return ld.value
+
+            def observation_tensor(self):
+                """The env's device observation buffer as a torch tensor view, field-major [OBSERVATION_DIM, ld]
+                (env i = column i < N_ENVIRONMENTS); zero copy.  Order your torch work behind the engine's stream
+                (``device.synchronize()`` or an event on ``device.stream``)."""
+                p = C.c_void_p()
+                _lib.call("rq_env_observation_device_ptr", self._require("environment"), C.byref(p))
+                return _as_torch(p.value, (OBSERVATION_DIM, self._ld()), "<f4", self)
+
+            def action_tensor(self):
+                """The env's device action buffer, field-major [4, ld]; zero copy (a learner may write it)."""
+                p = C.c_void_p()
+                _lib.call("rq_env_action_device_ptr", self._require("environment"), C.byref(p))
+                return _as_torch(p.value, (ACTION_DIM, self._ld()), "<f4", self)
+
             def set_action(self, action):
                 a = np.ascontiguousarray(action, np.float32)
                 assert a.shape == (mod.N_ENVIRONMENTS, ACTION_DIM)
@@ -234,13 +269,21 @@ class VectorModule:
                 assert a.shape == (mod.N_ENVIRONMENTS, self._dim), a.shape
                 _lib.call(self._set, self._require(type(self).__name__), _lib.fptr(a))
 
+            def tensor(self):
+                """The container's device buffer as a torch tensor view, field-major [dim, ld]; zero copy."""
+                p = C.c_void_p()
+                _lib.call(self._ptr, self._require(type(self).__name__), C.byref(p))
+                return _as_torch(p.value, (self._dim, self._env._ld()), "<f4", self)
+
         class VectorParameters(_Container):
             _destroy, _create, _get, _set, _dim = ("rq_params_destroy", "rq_params_create", "rq_params_get",
                                                    "rq_params_set", PARAM_DIM)
+            _ptr = "rq_params_device_ptr"
 
         class VectorState(_Container):
             _destroy, _create, _get, _set, _dim = ("rq_state_destroy", "rq_state_create", "rq_state_get",
                                                    "rq_state_set", STATE_DIM)
+            _ptr = "rq_state_device_ptr"
 
             _mirror = None      # host copy handed out by ``.states``; written back before the next device use
 
@@ -311,6 +354,17 @@ class VectorModule:
                 _lib.call("rq_trajectory_get", self._h, _lib.fptr(out["obs"]), _lib.fptr(out["act"]),
                           _lib.fptr(out["rew"]), out["done"].ctypes.data)
                 return out
+
+            def tensors(self):
+                """The recorded steps as torch tensor VIEWS of the device buffers (zero copy), in the device layout:
+                obs [T, 22, ld], act [T, 4, ld], rew [T, ld], done [T, ld] uint8 - env i is index i < N of the
+                last axis.  ``obs.permute(0, 2, 1)[:, :N]`` is the learner layout [T, N, 22]."""
+                o, a, r, d, ld = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+                _lib.call("rq_trajectory_device_ptrs", self._require("trajectory"), C.byref(o), C.byref(a), C.byref(r),
+                          C.byref(d), C.byref(ld))
+                T, L = len(self), ld.value
+                return dict(obs=_as_torch(o.value, (T, 22, L), "<f4", self), act=_as_torch(a.value, (T, 4, L), "<f4", self),
+                            rew=_as_torch(r.value, (T, L), "<f4", self), done=_as_torch(d.value, (T, L), "|u1", self))
 
             def relabel(self, policy, overwrite=False, fetch=True):
                 """Actions of ``policy`` (a teacher, a newer student, ...) on the recorded observations, following

@@ -1042,3 +1042,36 @@ def test_state_views_are_writable_like_the_reference(device):
     vector.observe(device, env, params, ui_state, obs, rng)
     assert np.array_equal(obs[:, 0], shifted[:, 0])
     assert [tuple(s.position) for s in ui_state.states] == [tuple(r[:3]) for r in shifted]
+
+
+def test_zero_copy_torch_views_of_device_buffers(device, oracle):
+    """Learner interop: trajectory, state, parameter, observation and action buffers as torch tensors that
+    ALIAS the engine's device memory (__cuda_array_interface__), no copies."""
+    import torch
+    n, T = 1000, 12
+    w = World(device, oracle, n, seed=41)
+    traj = w.vector.Trajectory(w.env, T)
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T, "fused", autoreset=True, trajectory=traj)
+    device.synchronize()
+    host = traj.numpy()
+    t = traj.tensors()
+    assert t["obs"].is_cuda and t["obs"].shape == (T, 22, 1024) and t["done"].dtype == torch.uint8
+    assert np.array_equal(t["obs"].permute(0, 2, 1)[:, :n].cpu().numpy(), host["obs"])
+    assert np.array_equal(t["act"].permute(0, 2, 1)[:, :n].cpu().numpy(), host["act"])
+    assert np.array_equal(t["rew"][:, :n].cpu().numpy(), host["rew"])
+    assert np.array_equal(t["done"][:, :n].cpu().numpy(), host["done"])
+    # aliasing, not copying: a write through the tensor is seen by the engine's own getter
+    t["rew"][0, 0] = 123.0
+    torch.cuda.synchronize()
+    assert traj.numpy()["rew"][0, 0] == 123.0
+    # state / params / env buffers
+    assert np.array_equal(w.state.tensor()[:, :n].T.cpu().numpy(), w.state.numpy())
+    assert np.array_equal(w.params.tensor()[:, :n].T.cpu().numpy(), w.params.numpy())
+    w.vector.observe(device, w.env, w.params, w.state, None, w.rng)
+    device.synchronize()
+    assert np.array_equal(w.env.observation_tensor()[:, :n].T.cpu().numpy(), w.env.observation())
+    a = torch.rand(4, 1024, device="cuda") * 2 - 1
+    w.env.action_tensor().copy_(a)             # a learner writes actions in place
+    torch.cuda.synchronize()
+    assert np.array_equal(w.env.action(), a[:, :n].T.cpu().numpy())
