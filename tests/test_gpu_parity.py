@@ -7,6 +7,7 @@ Bars (DESIGN.md "Parity"):
     Box-Muller noise): float32 tolerance stated per test;
   * the actor additionally against the reference's own known-answer vectors (< 1e-5).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -1075,3 +1076,13 @@ def test_zero_copy_torch_views_of_device_buffers(device, oracle):
     w.env.action_tensor().copy_(a)             # a learner writes actions in place
     torch.cuda.synchronize()
     assert np.array_equal(w.env.action(), a[:, :n].T.cpu().numpy())
+
+
+def test_collect_and_relabel_example_runs(tmp_path):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "collect_and_relabel.py"), "--envs", "2048",
+                        "--steps", "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "episode ends" in r.stdout and "cuda" in r.stdout
