@@ -935,7 +935,7 @@ def test_evaluate_sequence_against_reference_kats(device, kat, weights, oracle):
     assert np.array_equal(p.hidden_state(2), q.hidden_state(2))
 
 
-@pytest.mark.parametrize("batch,stride", [(1, 22), (65, 26), (1000, 23), (4096, 22)])
+@pytest.mark.parametrize("batch,stride", [(1, 22), (65, 26), (1000, 23), (4096, 22), (70000, 22)])
 def test_evaluate_sequence_ragged_strided_and_carried(device, oracle, weights, batch, stride):
     """Ragged batches, even/odd row strides (columns >= 22 never read), hidden state carried across calls:
     two half sequences equal the whole one bit for bit; against the oracle within ACTOR_TOL."""
