@@ -24,8 +24,8 @@ device = l2f.Device()
 sh = Shard(device, args.envs, 0, precision=args.precision)
 if args.noise:
     cfg = sh.env.config
-    cfg.observation_noise_position = 0.001
-    cfg.observation_noise_linear_velocity = 0.002
+    cfg.noise_position, cfg.noise_orientation = 0.001, 0.001
+    cfg.noise_linear_velocity, cfg.noise_angular_velocity = 0.002, 0.002
     sh.env.config = cfg
 sh.rollout(2000, "fused")
 device.synchronize()
