@@ -44,6 +44,14 @@ class EnvConfig(C.Structure):
         ("termination_angular_velocity", C.c_float),
     ]
 
+    def __setattr__(self, name, value):       # a misspelt field must not silently configure nothing
+        if name not in EnvConfig._field_names:
+            raise AttributeError(f"oracle config has no field '{name}'")
+        super().__setattr__(name, value)
+
+
+EnvConfig._field_names = frozenset(n for n, _ in EnvConfig._fields_)
+
 
 def build(force=False):
     """Compile the restatement with oracle/Makefile (gcc only; seconds)."""

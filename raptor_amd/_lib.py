@@ -54,8 +54,17 @@ class EnvConfig(C.Structure):
         ("termination_angular_velocity", C.c_float),
     ]
 
+    def __setattr__(self, name, value):
+        # a ctypes Structure takes any attribute name; a misspelt field would silently configure nothing
+        if name not in self._field_names:
+            raise AttributeError(f"rq_env_config has no field '{name}'")
+        super().__setattr__(name, value)
+
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EnvConfig._field_names = frozenset(n for n, _ in EnvConfig._fields_)
 
 
 _vp = C.c_void_p
