@@ -240,6 +240,9 @@ RQ_API int rq_env_set_action(rq_env* env, const float* host_in);
 #define RQ_DST_DEVICE_ASYNC 2
 RQ_API int rq_env_get_rewards(const rq_env* env, float* dst, int dst_is_device);          /* last transition */
 RQ_API int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dst_is_device);     /* last transition */
+RQ_API int rq_env_get_done_codes(const rq_env* env, uint8_t* dst, int dst_is_device);     /* last transition: 0 running, 1 terminated, 2 step limit, 4 frozen (not stepped) */
+RQ_API int rq_env_get_frozen(const rq_env* env, uint8_t* dst, int dst_is_device);         /* 1: episode over, waits for sample_initial_state (rq_rollout without AUTORESET) */
+RQ_API int rq_env_get_episode_index(const rq_env* env, uint32_t* dst, int dst_is_device); /* episodes started so far (RNG counter of the next reset) */
 RQ_API int rq_env_get_returns(const rq_env* env, float* dst, int dst_is_device);          /* running episode */
 RQ_API int rq_env_get_episode_steps(const rq_env* env, uint32_t* dst, int dst_is_device);
 RQ_API int rq_env_get_finished_returns(const rq_env* env, float* dst, int dst_is_device); /* last finished episode */

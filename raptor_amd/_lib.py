@@ -122,6 +122,9 @@ _SIGNATURES = {
     "rq_env_set_action": [_vp, _fp],
     "rq_env_get_rewards": [_vp, _vp, C.c_int],
     "rq_env_get_terminated": [_vp, _vp, C.c_int],
+    "rq_env_get_done_codes": [_vp, _vp, C.c_int],
+    "rq_env_get_frozen": [_vp, _vp, C.c_int],
+    "rq_env_get_episode_index": [_vp, _vp, C.c_int],
     "rq_env_get_returns": [_vp, _vp, C.c_int],
     "rq_env_get_episode_steps": [_vp, _vp, C.c_int],
     "rq_env_get_finished_returns": [_vp, _vp, C.c_int],

@@ -766,6 +766,9 @@ RQ_API int rq_env_set_action(rq_env* env, const float* host_in) {
 // ---------------------------------------------------------------------------- statistics
 RQ_API int rq_env_get_rewards(const rq_env* env, float* dst, int dev_dst) { return copy_out(env, env ? env->st.last_reward : nullptr, dst, dev_dst); }
 RQ_API int rq_env_get_terminated(const rq_env* env, uint8_t* dst, int dev_dst) { return copy_out(env, env ? env->st.last_terminated : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_done_codes(const rq_env* env, uint8_t* dst, int dev_dst) { return copy_out(env, env ? env->st.last_done : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_frozen(const rq_env* env, uint8_t* dst, int dev_dst) { return copy_out(env, env ? env->st.frozen : nullptr, dst, dev_dst); }
+RQ_API int rq_env_get_episode_index(const rq_env* env, uint32_t* dst, int dev_dst) { return copy_out(env, env ? env->st.episode : nullptr, dst, dev_dst); }
 RQ_API int rq_env_get_returns(const rq_env* env, float* dst, int dev_dst) { return copy_out(env, env ? env->st.returns : nullptr, dst, dev_dst); }
 RQ_API int rq_env_get_episode_steps(const rq_env* env, uint32_t* dst, int dev_dst) { return copy_out(env, env ? env->st.steps : nullptr, dst, dev_dst); }
 RQ_API int rq_env_get_finished_returns(const rq_env* env, float* dst, int dev_dst) { return copy_out(env, env ? env->st.fin_returns : nullptr, dst, dev_dst); }

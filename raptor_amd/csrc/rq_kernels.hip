@@ -511,6 +511,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         if (AUTORESET) st.episode[i] = ep;
         if (frozen) st.frozen[i] = 1;
     }
+    if (valid && was_frozen && n_steps > 0) st.last_done[i] = 4;   // not stepped by this rollout (as k_step reports it)
     store_hidden_q(hidden, ld, wave_base, __builtin_amdgcn_ballot_w64(valid && !was_frozen), hQ);
 }
 

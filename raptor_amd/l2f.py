@@ -234,6 +234,9 @@ class VectorModule:
 
             def rewards(self, out=None): return self._stat("rq_env_get_rewards", np.float32, out)
             def terminated(self, out=None): return self._stat("rq_env_get_terminated", np.uint8, out)
+            def done_codes(self, out=None): return self._stat("rq_env_get_done_codes", np.uint8, out)
+            def frozen(self, out=None): return self._stat("rq_env_get_frozen", np.uint8, out)
+            def episode_index(self, out=None): return self._stat("rq_env_get_episode_index", np.uint32, out)
             def returns(self, out=None): return self._stat("rq_env_get_returns", np.float32, out)
             def episode_steps(self, out=None): return self._stat("rq_env_get_episode_steps", np.uint32, out)
             def finished_returns(self, out=None, wait=True):

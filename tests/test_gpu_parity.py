@@ -1086,3 +1086,25 @@ def test_collect_and_relabel_example_runs(tmp_path):
                         "--steps", "40"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "episode ends" in r.stdout and "cuda" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["fused", "chained"])
+def test_done_codes_frozen_and_episode_index_getters(device, oracle, mode):
+    """Freeze mode: after an episode of 20 steps every env is frozen with done code 2 (step limit) or 1
+    (terminated), further steps leave them at 4; sample_initial_state unfreezes and advances the episode index.
+    Auto-reset: nothing freezes, the episode index counts the resets."""
+    n = 300
+    w = World(device, oracle, n, seed=51, episode_step_limit=20)
+    assert not w.env.frozen().any() and (w.env.episode_index() == 1).all()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 20, mode, False)
+    codes = w.env.done_codes()
+    assert w.env.frozen().all() and set(np.unique(codes)) <= {1, 2} and (codes == 2).sum() > n // 2
+    assert np.array_equal(codes == 1, w.env.terminated() == 1)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 3, mode, False)
+    assert (w.env.done_codes() == 4).all()
+    w.vector.sample_initial_state(device, w.env, w.params, w.state, w.rng)
+    assert not w.env.frozen().any() and (w.env.episode_index() == 2).all()
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 45, mode, True)
+    assert not w.env.frozen().any()
+    assert np.array_equal(w.env.episode_index(), 2 + w.env.finished_counts() - 1)
