@@ -578,7 +578,7 @@ def test_rollout_fused_equals_chained_bit_exact(device, oracle, autoreset):
     assert np.array_equal(a.state.numpy(), b.state.numpy())
     assert np.array_equal(a.policy.hidden_state(777), b.policy.hidden_state(777))
     for name in ("returns", "episode_steps", "finished_returns", "finished_lengths", "finished_counts",
-                 "finished_terminated", "rewards", "terminated"):
+                 "finished_terminated", "rewards", "terminated", "done_codes", "frozen", "episode_index"):
         assert np.array_equal(getattr(a.env, name)(), getattr(b.env, name)()), name
     assert a.rng.epoch == b.rng.epoch == 125
     if autoreset:
