@@ -308,6 +308,10 @@ enum rq_rollout_flags {
                                   that env) and keeps stepping; otherwise it freezes. */
 };
 
+/* Both modes leave the same state, hidden state, episode statistics and done codes, bit for bit.  The env's
+ * device observation / action buffers (rq_env_get_observation / _action) are scratch of the chained mode only:
+ * after a fused rollout they still hold what the last observe / evaluate_step call left there; use
+ * rq_rollout_record to keep per-step observations and actions. */
 RQ_API int rq_rollout(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state,
                rq_policy* policy, rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags);
 
