@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -944,6 +945,9 @@ RQ_API int rq_policy_evaluate_sequence(rq_policy* pol, const float* observation,
     RQ_REQUIRE(steps > 0 && batch > 0, RQ_ERR_INVALID_ARGUMENT, "empty sequence");
     RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
     RQ_REQUIRE(memory >= RQ_DST_HOST && memory <= RQ_DST_DEVICE_ASYNC, RQ_ERR_INVALID_ARGUMENT, "memory must be 0, 1 or 2");
+    if (memory != RQ_DST_HOST)      // the kernel moves rows with 8-byte loads and actions with 16-byte stores
+        RQ_REQUIRE((reinterpret_cast<uintptr_t>(observation) & 7u) == 0 && (reinterpret_cast<uintptr_t>(action) & 15u) == 0,
+                   RQ_ERR_INVALID_ARGUMENT, "device tensors must be 8-byte (observation) / 16-byte (action) aligned");
     rq_device* dev = pol->dev;
     int rc = set_device(dev); if (rc) return rc;
     rc = policy_size(pol, batch); if (rc) return rc;
