@@ -111,7 +111,7 @@ def load_checkpoint_h5(path):
     """-> (weights float32 [2084], example or None, meta str or None) from an rl-tools `checkpoint.h5`
     (groups `/actor/layers/{0,1,2}`, string attributes `type` / `activation_function`; `h5:/actor...` in
     SURVEY.md).  Only Dense(22->16, RELU) -> GRU(16) -> Dense(16->4, IDENTITY) is accepted."""
-    from .hdf5_min import File, Hdf5FormatError
+    from .hdf5_min import File
     root = File(path).root
     try:
         actor = root["actor"]

@@ -8,7 +8,6 @@ Bars (DESIGN.md "Parity"):
   * the actor additionally against the reference's own known-answer vectors (< 1e-5).
 """
 import os
-import ctypes as C
 
 import numpy as np
 import pytest
