@@ -35,6 +35,12 @@ __global__ __launch_bounds__(256) void k(int iters, const float* __restrict__ in
                 if (VOP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(0.999f), "v"(b));
                 if (VOP == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
                 if (VOP == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[r]) : "v"(a2), "v"(b2));
+                if (VOP == 3) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[r]) : "v"(b));
+                if (VOP == 4) asm volatile("v_mov_b32 %0, %1" : "+v"(v[r]) : "v"(b));
+                if (VOP == 5) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[r]) : "v"(b));
+                if (VOP == 6) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[r]) : "v"(b));
+                if (VOP == 7) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(v[r]));
+                if (VOP == 8) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(v[r]), "+v"(v[(r + 1) & 15]));
             }
         }
     }
@@ -54,7 +60,7 @@ void run(int blocks, int iters, const float* in, float* out) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }
     static const char* kn[] = {"f32 16x16x4", "bf16 16x16x32", "no mfma"};
-    static const char* vn[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32"};
+    static const char* vn[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_xor_b32", "v_mov_b32", "v_max_f32", "v_add_f32", "v_cvt_f32_u32", "v_permlane32_swap"};
     printf("%-14s + %2d x %-13s %d waves/SIMD: %8.1f ns per (mfma + K valu) group per wave-slot\n", kn[KIND], K, vn[VOP],
            blocks / 256, best * 1e6 / iters / 4 / (blocks / 256));
 }
@@ -83,6 +89,14 @@ int main() {
         sweep<2, 1>(blocks, it, in, out);
         sweep<0, 1>(blocks, it, in, out);
         sweep<0, 2>(blocks, it, in, out);
+        if (blocks == 256) {       // which VALU classes, if any, run in the shadow of an f32 MFMA?
+            sweep<2, 3>(blocks, it, in, out); sweep<0, 3>(blocks, it, in, out);
+            sweep<2, 4>(blocks, it, in, out); sweep<0, 4>(blocks, it, in, out);
+            sweep<0, 5>(blocks, it, in, out);
+            sweep<0, 6>(blocks, it, in, out);
+            sweep<0, 7>(blocks, it, in, out);
+            sweep<2, 8>(blocks, it, in, out); sweep<0, 8>(blocks, it, in, out);
+        }
     }
     return 0;
 }
