@@ -1107,3 +1107,17 @@ def test_done_codes_frozen_and_episode_index_getters(device, oracle, mode):
     w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 45, mode, True)
     assert not w.env.frozen().any()
     assert np.array_equal(w.env.episode_index(), 2 + w.env.finished_counts() - 1)
+
+
+def test_closed_loop_statistics_against_the_reference_training_log_on_the_gpu(device, oracle):
+    """The HIP path's own closed-loop statistics against numbers the reference produced (its training log, see
+    tests/test_closed_loop.py::REFERENCE_LOG): 65 536 randomised quadrotors, shipped policy, position termination
+    threshold 1 m -> share of terminated episodes 0.042 +- 0.008 and mean episode length 482.8 +- 4."""
+    from test_closed_loop import REFERENCE_LOG
+    w = World(device, oracle, 65536, seed=7, termination_position=1.0)
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 500, "fused", autoreset=False)
+    assert (w.env.finished_counts() == 1).all()
+    share, length = w.env.finished_terminated().mean(), w.env.finished_lengths().mean()
+    assert abs(share - REFERENCE_LOG["share_terminated"]) < 0.008, share
+    assert abs(length - REFERENCE_LOG["episode_length"]) < 4.0, length
