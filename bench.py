@@ -112,6 +112,23 @@ def pmc_traffic(kernel, grid, also=""):
     return None
 
 
+def sq_profile(precision):
+    """MFMA utilisation of the fused kernel from the committed SQ-counter pass (tools/sq_profile.sh):
+    matrix-pipe busy cycles / wave cycles (SQ_WAVE_CYCLES counts quad-cycles) and the co-execution share."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+        try:
+            d = json.load(open(path))[precision]
+            busy, wave = d["SQ_VALU_MFMA_BUSY_CYCLES"], 4.0 * d["SQ_WAVE_CYCLES"]
+            return {"mfma_busy_frac": round(busy / wave, 4),
+                    "mfma_valu_coexec_frac_of_busy": round(d["SQ_VALU_MFMA_COEXEC_CYCLES"] / busy, 4),
+                    "issue_stall_frac": round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4),
+                    "source": os.path.basename(path)}
+        except Exception:
+            continue
+    return None
+
+
 def chunks(total, size):
     out = []
     while total > 0:
@@ -386,7 +403,7 @@ def main():
                 "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
                         f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the bf16 MFMA pipe at "
                         f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak",
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches}
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches, "sq_counters": sq_profile("bf16")}
         elif args.mode == "fused":
             steps_per_launch = args.steps / len(plan)
             flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
@@ -404,7 +421,8 @@ def main():
                         "the 17.9 KB operand image every wave loads and ~700 B/env of loop-invariant registers the "
                         "256-register build parks in scratch before the loop - about 3 B per env-step, HBM idle",
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3)}
+                "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
+                "sq_counters": sq_profile("fp32")}
         else:
             bytes_per_step = (BYTES_OBSERVE + BYTES_ACTOR + BYTES_STEP) * n
             achieved = bytes_per_step * args.steps / (kernel_ms * 1e-3) / 1e9
