@@ -132,10 +132,34 @@ struct rq_policy {
 
 namespace {
 
-int set_device(const rq_device* dev) {
-    RQ_HIP(hipSetDevice(dev->ordinal));
-    return RQ_OK;
-}
+// Every entry point runs on its rq_device's HIP device and leaves the calling thread's current device as it
+// found it: a host that drives several GPUs from one thread (or PyTorch with another current device) must
+// not find its device switched behind its back.
+thread_local int tl_scope_depth = 0, tl_scope_device = -1;     // innermost live DeviceScope of this thread
+
+struct DeviceScope {
+    int previous = -1, target, rc = RQ_OK;
+    bool nested = false;                 // inside another scope of the same device: nothing to query or restore
+    explicit DeviceScope(const rq_device* dev) : DeviceScope(dev->ordinal) {}
+    explicit DeviceScope(int ordinal) : target(ordinal) {
+        if (tl_scope_depth > 0 && tl_scope_device == target) { nested = true; ++tl_scope_depth; return; }
+        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+        if (previous != target) {
+            const hipError_t e = hipSetDevice(target);
+            if (e != hipSuccess) rc = fail(RQ_ERR_HIP, std::string("hipSetDevice -> ") + hipGetErrorString(e));
+        }
+        outer_depth = tl_scope_depth; outer_device = tl_scope_device;
+        tl_scope_depth = 1; tl_scope_device = target;
+    }
+    ~DeviceScope() {
+        if (nested) { --tl_scope_depth; return; }
+        tl_scope_depth = outer_depth; tl_scope_device = outer_device;
+        if (previous >= 0 && previous != target) (void)hipSetDevice(previous);
+    }
+    int outer_depth = 0, outer_device = -1;
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 int ensure_staging(rq_device* dev, size_t bytes) {
     if (dev->staging_bytes >= bytes) return RQ_OK;
@@ -162,7 +186,7 @@ int ensure_rows(rq_device* dev, size_t bytes) {
 
 // device SoA [dim][ld] -> host row-major [n][dim]
 int soa_to_host(rq_device* dev, const float* d_soa, uint32_t n, uint32_t ld, uint32_t dim, float* host) {
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     if (n >= kGpuLayoutMinEnvs) {
         const size_t row_bytes = (size_t)n * dim * sizeof(float);
         rc = ensure_rows(dev, row_bytes); if (rc) return rc;
@@ -189,7 +213,7 @@ int soa_to_host(rq_device* dev, const float* d_soa, uint32_t n, uint32_t ld, uin
 // caller's block is copied as it is and re-laid out on the GPU; the call returns when the copy has read it.
 int host_to_soa(rq_device* dev, const float* host, uint32_t n, uint32_t stride, uint32_t ld, uint32_t dim,
                 float* d_soa) {
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     if (n >= kGpuLayoutMinEnvs && stride <= 2 * dim) {
         const size_t row_bytes = ((size_t)(n - 1) * stride + dim) * sizeof(float);   // last row: only its first dim columns
         rc = ensure_rows(dev, (size_t)n * stride * sizeof(float)); if (rc) return rc;
@@ -281,7 +305,7 @@ rq::Mailbox mailbox_for(rq_device* dev, const float* rows_in, uint32_t in_stride
 template <typename T>
 int copy_out(const rq_env* env, const T* src, T* dst, int dst_is_device) {
     RQ_REQUIRE(env && dst, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(env->dev); if (rc) return rc;
+    DeviceScope on_device(env->dev); int rc = on_device.rc; if (rc) return rc;
     RQ_REQUIRE(dst_is_device >= RQ_DST_HOST && dst_is_device <= RQ_DST_DEVICE_ASYNC, RQ_ERR_INVALID_ARGUMENT,
                "dst_is_device must be 0, 1 or 2");
     RQ_HIP(hipMemcpyAsync(dst, src, (size_t)env->n * sizeof(T),
@@ -312,7 +336,7 @@ const float* packed_of(const rq_policy* pol) {
 // Size the per-batch buffers on first use (Raptor sizes its hidden state on the first
 // batch, README.md:24) and apply a pending reset(): h <- initial_hidden_state.
 int policy_size(rq_policy* pol, uint32_t batch) {
-    int rc = set_device(pol->dev); if (rc) return rc;
+    DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
     if (pol->batch != batch || !pol->hidden) {
         RQ_REQUIRE(pol->batch == 0 || pol->needs_reset, RQ_ERR_SHAPE_MISMATCH,
                    "batch size changed without reset (hidden state is per batch element)");
@@ -382,7 +406,8 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     if (e != hipSuccess || n <= 0)
         return fail(RQ_ERR_NO_DEVICE, "rq_device_create: no HIP device available (this library has no CPU path)");
     RQ_REQUIRE(ordinal >= 0 && ordinal < n, RQ_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    RQ_HIP(hipSetDevice(ordinal));
+    DeviceScope on_device(ordinal);
+    if (on_device.rc) return on_device.rc;
     rq_device* d = new (std::nothrow) rq_device();
     RQ_REQUIRE(d, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     d->ordinal = ordinal;
@@ -400,7 +425,7 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
 
 RQ_API int rq_device_destroy(rq_device* dev) {
     if (!dev) return RQ_OK;
-    (void)hipSetDevice(dev->ordinal);
+    DeviceScope on_device(dev->ordinal);
     if (dev->stream) { (void)hipStreamSynchronize(dev->stream); (void)hipStreamDestroy(dev->stream); }
     if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
@@ -419,21 +444,21 @@ RQ_API int rq_device_destroy(rq_device* dev) {
 
 RQ_API int rq_device_synchronize(rq_device* dev) {
     RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipStreamSynchronize(dev->stream));
     return RQ_OK;
 }
 
 RQ_API int rq_device_timer_start(rq_device* dev) {
     RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipEventRecord(dev->ev_start, dev->stream));
     return RQ_OK;
 }
 
 RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms) {
     RQ_REQUIRE(dev && elapsed_ms, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipEventRecord(dev->ev_stop, dev->stream));
     RQ_HIP(hipEventSynchronize(dev->ev_stop));
     RQ_HIP(hipEventElapsedTime(elapsed_ms, dev->ev_start, dev->ev_stop));
@@ -511,7 +536,7 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
     RQ_REQUIRE(n_envs > 0, RQ_ERR_INVALID_ARGUMENT, "n_envs must be positive");
     RQ_REQUIRE(n_envs <= 0xFFFFFF00u, RQ_ERR_INVALID_ARGUMENT, "n_envs too large");
     *out = nullptr;
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     rq_env* e = new (std::nothrow) rq_env();
     RQ_REQUIRE(e, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     e->dev = dev; e->ordinal = dev->ordinal; e->n = n_envs; e->ld = round_up64(n_envs); e->offset = global_env_offset;
@@ -555,7 +580,7 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
 
 RQ_API int rq_env_destroy(rq_env* env) {
     if (!env) return RQ_OK;
-    (void)hipSetDevice(env->ordinal);   // hipFree synchronises the device; the parent is not touched
+    DeviceScope on_device(env->ordinal);   // hipFree synchronises the device; the parent is not touched
     if (env->obs) (void)hipFree(env->obs);
     if (env->act) (void)hipFree(env->act);
     if (env->stats_block) (void)hipFree(env->stats_block);
@@ -603,7 +628,7 @@ RQ_API int rq_env_get_config(const rq_env* env, rq_env_config* cfg) {
 // ---------------------------------------------------------------------------- containers
 RQ_API int rq_params_create(rq_env* env, rq_params** out) {
     RQ_REQUIRE(env && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(env->dev); if (rc) return rc;
+    DeviceScope on_device(env->dev); int rc = on_device.rc; if (rc) return rc;
     rq_params* p = new (std::nothrow) rq_params();
     RQ_REQUIRE(p, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     p->env = env; p->ordinal = env->ordinal;
@@ -616,7 +641,7 @@ RQ_API int rq_params_create(rq_env* env, rq_params** out) {
 }
 RQ_API int rq_params_destroy(rq_params* p) {
     if (!p) return RQ_OK;
-    (void)hipSetDevice(p->ordinal);
+    DeviceScope on_device(p->ordinal);
     if (p->d) (void)hipFree(p->d);
     delete p;
     return RQ_OK;
@@ -636,7 +661,7 @@ RQ_API int rq_params_device_ptr(const rq_params* p, float** dev_ptr) {
 
 RQ_API int rq_state_create(rq_env* env, rq_state** out) {
     RQ_REQUIRE(env && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(env->dev); if (rc) return rc;
+    DeviceScope on_device(env->dev); int rc = on_device.rc; if (rc) return rc;
     rq_state* s = new (std::nothrow) rq_state();
     RQ_REQUIRE(s, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->env = env; s->ordinal = env->ordinal;
@@ -649,7 +674,7 @@ RQ_API int rq_state_create(rq_env* env, rq_state** out) {
 }
 RQ_API int rq_state_destroy(rq_state* s) {
     if (!s) return RQ_OK;
-    (void)hipSetDevice(s->ordinal);
+    DeviceScope on_device(s->ordinal);
     if (s->d) (void)hipFree(s->d);
     delete s;
     return RQ_OK;
@@ -658,7 +683,7 @@ RQ_API int rq_state_assign(rq_state* dst, const rq_state* src) {
     RQ_REQUIRE(dst && src, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(dst->env == src->env, RQ_ERR_SHAPE_MISMATCH, "states belong to different envs");
     if (dst == src) return RQ_OK;
-    int rc = set_device(dst->env->dev); if (rc) return rc;
+    DeviceScope on_device(dst->env->dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)RQ_STATE_DIM * dst->env->ld * sizeof(float),
                           hipMemcpyDeviceToDevice, dst->env->dev->stream));
     return RQ_OK;
@@ -681,7 +706,7 @@ RQ_API int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* 
     int rc = check_env_objects(dev, env, params, nullptr); if (rc) return rc;
     RQ_REQUIRE(params && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
-    rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     RQ_HIP(rq::launch_sample_params(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed,
                                     rng->param_epoch, params->d));
     rng->param_epoch += 1;
@@ -692,7 +717,7 @@ RQ_API int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params*
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
     RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
-    rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     RQ_HIP(rq::launch_sample_state(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed, params->d,
                                    state->d, env->st.episode, env->st.frozen));
     return RQ_OK;
@@ -703,7 +728,7 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
     RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
-    rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     const bool mailbox = observation && env->n < kGpuLayoutMinEnvs;
     rq::Mailbox mb{};
     if (mailbox) { rc = ensure_mailbox(dev); if (rc) return rc; mb = mailbox_for(dev, nullptr, 0, dev->mb_out); }
@@ -724,7 +749,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
     RQ_REQUIRE(params && state && next_state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(next_state->env == env, RQ_ERR_SHAPE_MISMATCH, "next_state belongs to another env");
-    rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     rq::Mailbox mb{};
     if (action && env->n < kGpuLayoutMinEnvs) {
         // the kernel reads the actions from the mailbox (and files them in env->act); nothing to wait for
@@ -779,7 +804,7 @@ RQ_API int rq_env_get_finished_terminated(const rq_env* env, uint32_t* dst, int 
 
 RQ_API int rq_env_reset_statistics(rq_env* env) {
     RQ_REQUIRE(env, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(env->dev); if (rc) return rc;
+    DeviceScope on_device(env->dev); int rc = on_device.rc; if (rc) return rc;
     const size_t ld = env->ld;
     // everything except the per-env episode counters (they key the initial-state RNG)
     RQ_HIP(hipMemsetAsync(env->stats_block, 0, 7 * 4 * ld, env->dev->stream));
@@ -807,7 +832,7 @@ static int policy_upload(rq_policy* p) {
     std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS);
     rq::pack_policy(p->w_eff, packed.data());
     rq::pack_policy_bf16(p->w_eff, packed16.data());
-    int rc = set_device(p->dev); if (rc) return rc;
+    DeviceScope on_device(p->dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipStreamSynchronize(p->dev->stream));
     RQ_HIP(hipMemcpy(p->w_dev, p->w_eff, sizeof(p->w_eff), hipMemcpyHostToDevice));
     RQ_HIP(hipMemcpy(p->w_packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -820,7 +845,7 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
     RQ_REQUIRE(n_weights == RQ_POLICY_NUM_WEIGHTS, RQ_ERR_INVALID_ARGUMENT,
                "expected 2084 weights: W0[16,22] b0[16] Wi[48,16] Wh[48,16] bi[48] bh[48] h0[16] W2[4,16] b2[4]");
     *out = nullptr;
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     rq_policy* p = new (std::nothrow) rq_policy();
     RQ_REQUIRE(p, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     p->dev = dev; p->ordinal = dev->ordinal;
@@ -841,7 +866,7 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
 
 RQ_API int rq_policy_destroy(rq_policy* pol) {
     if (!pol) return RQ_OK;
-    (void)hipSetDevice(pol->ordinal);
+    DeviceScope on_device(pol->ordinal);
     policy_free_buffers(pol);
     if (pol->w_dev) (void)hipFree(pol->w_dev);
     if (pol->w_packed) (void)hipFree(pol->w_packed);
@@ -880,7 +905,7 @@ RQ_API int rq_policy_set_squash(rq_policy* pol, int enable) {
 
 RQ_API int rq_policy_reset(rq_policy* pol) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(pol->dev); if (rc) return rc;
+    DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
     pol->needs_reset = true;   // applied (h <- initial_hidden_state, checkpoint.h:123) on the next use
     return RQ_OK;
 }
@@ -896,7 +921,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     }
     RQ_REQUIRE(batch > 0, RQ_ERR_INVALID_ARGUMENT, "batch must be positive");
     if (observation) RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
-    int rc = set_device(pol->dev); if (rc) return rc;
+    DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
     rc = policy_size(pol, batch); if (rc) return rc;
     rq_device* dev = pol->dev;
     const bool mailbox = batch < kGpuLayoutMinEnvs && (observation || action);
@@ -949,7 +974,7 @@ RQ_API int rq_policy_evaluate_sequence(rq_policy* pol, const float* observation,
         RQ_REQUIRE((reinterpret_cast<uintptr_t>(observation) & 7u) == 0 && (reinterpret_cast<uintptr_t>(action) & 15u) == 0,
                    RQ_ERR_INVALID_ARGUMENT, "device tensors must be 8-byte (observation) / 16-byte (action) aligned");
     rq_device* dev = pol->dev;
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     rc = policy_size(pol, batch); if (rc) return rc;
     const size_t rows = (size_t)steps * batch;
     const float* d_obs = observation;
@@ -982,7 +1007,7 @@ RQ_API int rq_policy_get_hidden(const rq_policy* pol, float* host_out, uint32_t 
 
 RQ_API int rq_policy_set_hidden(rq_policy* pol, const float* host_in, uint32_t batch) {
     RQ_REQUIRE(pol && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = set_device(pol->dev); if (rc) return rc;
+    DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
     rc = policy_size(pol, batch); if (rc) return rc;
     return host_to_soa(pol->dev, host_in, batch, RQ_POLICY_HIDDEN_DIM, pol->ld, RQ_POLICY_HIDDEN_DIM, pol->hidden);
 }
@@ -1041,7 +1066,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                    "trajectory buffer too small for this rollout");
         tp = {traj->obs, traj->act, traj->rew, traj->done, traj->length};
     }
-    rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     rc = policy_size(policy, env->n); if (rc) return rc;
     RQ_REQUIRE(policy->ld == env->ld, RQ_ERR_SHAPE_MISMATCH, "policy batch does not match the env");
     const rq::Batch b = batch_of(env);
@@ -1127,7 +1152,7 @@ RQ_API int rq_trajectory_create(rq_env* env, uint32_t capacity_steps, rq_traject
     RQ_REQUIRE((uint64_t)env->ld * RQ_POLICY_INPUT_DIM * sizeof(float) < (1ull << 32), RQ_ERR_INVALID_ARGUMENT,
                "trajectory recording supports up to 48 million envs per device");
     *out = nullptr;
-    int rc = set_device(env->dev); if (rc) return rc;
+    DeviceScope on_device(env->dev); int rc = on_device.rc; if (rc) return rc;
     rq_trajectory* t = new (std::nothrow) rq_trajectory();
     RQ_REQUIRE(t, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     t->env = env; t->ordinal = env->ordinal; t->capacity = capacity_steps;
@@ -1146,7 +1171,7 @@ RQ_API int rq_trajectory_create(rq_env* env, uint32_t capacity_steps, rq_traject
 
 RQ_API int rq_trajectory_destroy(rq_trajectory* t) {
     if (!t) return RQ_OK;
-    (void)hipSetDevice(t->ordinal);
+    DeviceScope on_device(t->ordinal);
     if (t->obs) (void)hipFree(t->obs);
     if (t->act) (void)hipFree(t->act);
     if (t->rew) (void)hipFree(t->rew);
@@ -1201,7 +1226,7 @@ RQ_API int rq_trajectory_get(const rq_trajectory* t, float* obs, float* act, flo
     rq_env* env = t->env;
     rq_device* dev = env->dev;
     const uint32_t n = env->n, ld = env->ld;
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     if (t->length == 0) return RQ_OK;
     if (obs) { rc = traj_block_to_host(dev, t->obs, t->length, n, ld, RQ_POLICY_INPUT_DIM, obs); if (rc) return rc; }
     if (act) { rc = traj_block_to_host(dev, t->act, t->length, n, ld, RQ_ACTION_DIM, act); if (rc) return rc; }
@@ -1219,7 +1244,7 @@ RQ_API int rq_trajectory_relabel(rq_trajectory* t, rq_policy* pol, float* action
     rq_device* dev = env->dev;
     RQ_REQUIRE(pol->dev == dev, RQ_ERR_SHAPE_MISMATCH, "policy lives on another device");
     if (t->length == 0) return RQ_OK;
-    int rc = set_device(dev); if (rc) return rc;
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     rc = policy_size(pol, env->n); if (rc) return rc;
     const size_t act_bytes = (size_t)t->length * RQ_ACTION_DIM * env->ld * sizeof(float);
     float* d_act = t->act;
