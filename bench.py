@@ -383,7 +383,8 @@ def main():
                    "envs_per_gpu": n, "total_envs": n_total, "episode_length": EPISODE,
                    "parallelism": f"env-sharded x{world}, all-gather of returns per episode" if world > 1
                                   else "single GPU", "mode": args.mode,
-                   "untimed_steps_before_timing": untimed},
+                   "untimed_steps_before_timing": untimed,
+                   "device": torch.cuda.get_device_name(local_rank), "hip_runtime": torch.version.hip},
     }
 
     if rank == 0:
