@@ -249,6 +249,11 @@ RQ_API int rq_env_get_finished_returns(const rq_env* env, float* dst, int dst_is
 RQ_API int rq_env_get_finished_lengths(const rq_env* env, uint32_t* dst, int dst_is_device);
 RQ_API int rq_env_get_finished_counts(const rq_env* env, uint32_t* dst, int dst_is_device); /* #episodes finished */
 RQ_API int rq_env_get_finished_terminated(const rq_env* env, uint32_t* dst, int dst_is_device); /* #of those that terminated */
+/* Forget the episode bookkeeping: running and finished returns / lengths / counts, last reward, terminated and
+ * done codes are zeroed AND the frozen flags are cleared - every env then counts as running a fresh episode
+ * from whatever state it is in (what a caller that overwrites states with rq_state_set wants).  An env whose
+ * episode had ended is NOT re-sampled by this call (rq_sample_initial_state does that, and also zeroes the
+ * env's running return and step count).  The per-env episode counters that key the initial-state RNG are kept. */
 RQ_API int rq_env_reset_statistics(rq_env* env);
 
 /* ---- Policy (README.md:19-24,48,94,97; checkpoint.h:34-194) ---------------------------- */

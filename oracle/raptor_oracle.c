@@ -348,43 +348,49 @@ typedef struct {
     float tdx, tdy, tdz;      /* disturbance torque */
 } dyn_consts;
 
-/* y = (p[3], q[4], v[3], w[3], rpm[4]) ; sp = rotor set-points ; d = dy/dt */
+/* y = (p[3], q[4], v[3], w[3], rpm[4]) ; sp = rotor set-points ; d = dy/dt
+ * The association order below IS the specification (DESIGN.md "Environment specification"): it is the
+ * one that maps onto two-wide fp32 instructions without register shuffles on the GPU side, where every
+ * power-of-two factor is moved around freely (exact), everything else is evaluated in this order. */
 static void dynamics(const dyn_consts* k, const float* y, const float* sp, float* d) {
     const float qw = y[3], qx = y[4], qy = y[5], qz = y[6];
     const float wx = y[10], wy = y[11], wz = y[12];
     float T[4];
     for (int i = 0; i < 4; ++i) T[i] = fmaf(fmaf(k->c2, y[13 + i], k->c1), y[13 + i], k->c0);
-    float Tsum = ((T[0] + T[1]) + T[2]) + T[3];
-    float tx = fmaf(k->py[3], T[3], fmaf(k->py[2], T[2], fmaf(k->py[1], T[1], k->py[0] * T[0])));
-    float ty = -fmaf(k->px[3], T[3], fmaf(k->px[2], T[2], fmaf(k->px[1], T[1], k->px[0] * T[0])));
-    float tz = k->kq * (((T[1] + T[3]) - T[0]) - T[2]);   /* spin directions (-1,+1,-1,+1) */
-    tx += k->tdx; ty += k->tdy; tz += k->tdz;
+    const float u02 = T[0] + T[2], u13 = T[1] + T[3];
+    const float Tsum = u02 + u13;
+    /* torque = sum r_i x (0,0,T_i) + yaw reaction (spin directions -1,+1,-1,+1) + disturbance */
+    float tx = fmaf(k->py[0], T[0], k->tdx);
+    tx = fmaf(k->py[1], T[1], tx); tx = fmaf(k->py[2], T[2], tx); tx = fmaf(k->py[3], T[3], tx);
+    float ty = fmaf(-k->px[0], T[0], k->tdy);
+    ty = fmaf(-k->px[1], T[1], ty); ty = fmaf(-k->px[2], T[2], ty); ty = fmaf(-k->px[3], T[3], ty);
+    const float tz = fmaf(k->kq, u13 - u02, k->tdz);
     /* dp = v */
     d[0] = y[7]; d[1] = y[8]; d[2] = y[9];
     /* dq = 1/2 q (x) (0, w) */
-    d[3] = -0.5f * fmaf(qz, wz, fmaf(qy, wy, qx * wx));
-    d[4] = 0.5f * fmaf(-qz, wy, fmaf(qy, wz, qw * wx));
+    d[3] = 0.5f * fmaf(-qy, wy, fmaf(-qx, wx, -(qz * wz)));
+    d[4] = 0.5f * fmaf(qy, wz, fmaf(-qz, wy, qw * wx));
     d[5] = 0.5f * fmaf(-qx, wz, fmaf(qz, wx, qw * wy));
     d[6] = 0.5f * fmaf(-qy, wx, fmaf(qx, wy, qw * wz));
     /* dv = R(q) (0,0,Tsum)/m + g + F/m : third column of R */
-    float r02 = 2.0f * fmaf(qx, qz, qw * qy);
-    float r12 = 2.0f * fmaf(qy, qz, -(qw * qx));
-    float r22 = fmaf(-2.0f, fmaf(qx, qx, qy * qy), 1.0f);
-    float acc = Tsum * k->inv_m;
+    const float r02 = 2.0f * fmaf(qx, qz, qw * qy);
+    const float r12 = 2.0f * fmaf(qy, qz, -(qw * qx));
+    const float r22 = fmaf(-2.0f, fmaf(qx, qx, qy * qy), 1.0f);
+    const float acc = Tsum * k->inv_m;
     d[7] = fmaf(r02, acc, k->adx);
     d[8] = fmaf(r12, acc, k->ady);
     d[9] = fmaf(r22, acc, k->adz);
     /* dw = J^-1 (tau - w x J w) */
-    float jwx = k->jx * wx, jwy = k->jy * wy, jwz = k->jz * wz;
-    float cx = fmaf(wy, jwz, -(wz * jwy));
-    float cy = fmaf(wz, jwx, -(wx * jwz));
-    float cz = fmaf(wx, jwy, -(wy * jwx));
+    const float jwx = k->jx * wx, jwy = k->jy * wy, jwz = k->jz * wz;
+    const float cx = fmaf(-wz, jwy, wy * jwz);
+    const float cy = fmaf(wz, jwx, -(wx * jwz));
+    const float cz = fmaf(wx, jwy, -(wy * jwx));
     d[10] = (tx - cx) * k->ijx;
     d[11] = (ty - cy) * k->ijy;
     d[12] = (tz - cz) * k->ijz;
     /* first-order rotors */
     for (int i = 0; i < 4; ++i) {
-        float e = sp[i] - y[13 + i];
+        const float e = sp[i] - y[13 + i];
         d[13 + i] = e * (sp[i] >= y[13 + i] ? k->itr : k->itf);
     }
 }
@@ -414,20 +420,25 @@ static void step_one(const rq_env_config* c, const float* p, const float* s, con
         ac[i] = fminf(fmaxf(a[i], -1.0f), 1.0f);
         sp[i] = fmaf(ac[i], half, mid);
     }
-    const float dt = c->dt, hdt = 0.5f * c->dt, dt6 = c->dt / 6.0f;
-    float y[17], yt[17], k1[17], k2[17], k3[17], k4[17];
+    /* classical RK4, accumulated stage by stage: y' = y + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 */
+    const float dt = c->dt, hdt = 0.5f * c->dt, dt6 = c->dt / 6.0f, dt3 = c->dt / 3.0f;
+    float y[17], yt[17], acc[17], kk[17];
     for (int i = 0; i < 17; ++i) y[i] = s[i];
-    dynamics(&k, y, sp, k1);
-    for (int i = 0; i < 17; ++i) yt[i] = fmaf(hdt, k1[i], y[i]);
-    dynamics(&k, yt, sp, k2);
-    for (int i = 0; i < 17; ++i) yt[i] = fmaf(hdt, k2[i], y[i]);
-    dynamics(&k, yt, sp, k3);
-    for (int i = 0; i < 17; ++i) yt[i] = fmaf(dt, k3[i], y[i]);
-    dynamics(&k, yt, sp, k4);
-    for (int i = 0; i < 17; ++i) y[i] = fmaf(dt6, fmaf(2.0f, k2[i] + k3[i], k1[i] + k4[i]), y[i]);
-    /* post: unit quaternion, rotor limits */
-    float nq = sqrtf(fmaf(y[6], y[6], fmaf(y[5], y[5], fmaf(y[4], y[4], y[3] * y[3]))));
-    float inq = 1.0f / nq;
+    dynamics(&k, y, sp, kk);
+    for (int i = 0; i < 17; ++i) { acc[i] = fmaf(dt6, kk[i], y[i]); yt[i] = fmaf(hdt, kk[i], y[i]); }
+    dynamics(&k, yt, sp, kk);
+    for (int i = 0; i < 17; ++i) { acc[i] = fmaf(dt3, kk[i], acc[i]); yt[i] = fmaf(hdt, kk[i], y[i]); }
+    dynamics(&k, yt, sp, kk);
+    for (int i = 0; i < 17; ++i) { acc[i] = fmaf(dt3, kk[i], acc[i]); yt[i] = fmaf(dt, kk[i], y[i]); }
+    dynamics(&k, yt, sp, kk);
+    for (int i = 0; i < 17; ++i) y[i] = fmaf(dt6, kk[i], acc[i]);
+    /* post: quaternion back to unit length, rotor limits.  1/|q| by its series around |q|^2 = 1
+     * (e = 1 - |q|^2 is ~1e-5 after one RK4 step from a unit quaternion, the next term 0.3125 e^3 is far
+     * below one ulp): fused multiply-adds only, so both sides round identically, and e is clamped so that
+     * a state set with a non-unit quaternion is pulled back geometrically instead of diverging. */
+    const float sq = fmaf(y[4], y[4], y[3] * y[3]) + fmaf(y[5], y[5], y[6] * y[6]);
+    const float eq = fminf(fmaxf(1.0f - sq, -0.5f), 0.5f);
+    const float inq = fmaf(eq, fmaf(0.375f, eq, 0.5f), 1.0f);
     for (int i = 3; i < 7; ++i) y[i] *= inq;
     for (int i = 13; i < 17; ++i) y[i] = fminf(fmaxf(y[i], rmin), rmax);
 
@@ -523,6 +534,13 @@ ORC_EXPORT void orc_rollout_record(const rq_env_config* c, const float* w, uint6
         float* s = state + (size_t)i * RQ_STATE_DIM;
         float* h = hidden + (size_t)i * 16;
         float obs[RQ_OBSERVATION_DIM], act[4];
+        if ((flags & 1u) && st.frozen[i] && K > 0) {
+            /* auto-reset: an env left frozen by an earlier rollout without it starts its next episode now */
+            sample_state_one(c, seed, st.episode[i], env_offset + i, p, s);
+            st.episode[i] += 1;
+            memcpy(h, w + OFF_H0, 16 * sizeof(float));
+            st.frozen[i] = 0;
+        }
         for (uint32_t k = 0; k < K; ++k) {
             const size_t slot = (size_t)k * n + i;
             if (st.frozen[i]) {

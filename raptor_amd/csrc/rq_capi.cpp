@@ -302,6 +302,22 @@ rq::Mailbox mailbox_for(rq_device* dev, const float* rows_in, uint32_t in_stride
     return mb;
 }
 
+// a launch that was handed a mailbox failed: nothing will ever publish its sequence number
+void mailbox_abort(rq_device* dev, const rq::Mailbox& mb) {
+    if (mb.flag == nullptr) return;
+    if (dev->mb_in_busy == mb.seq) dev->mb_in_busy = 0;
+    if (dev->mb_seq == mb.seq) dev->mb_seq = mb.seq - 1;      // 0 ("nothing pending") is skipped by mailbox_for
+}
+
+#define RQ_HIP_MB(expr, dev, mb)                                                                  \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            mailbox_abort((dev), (mb));                                                           \
+            return fail(RQ_ERR_HIP, std::string(__func__) + ": " #expr " -> " + hipGetErrorString(e_)); \
+        }                                                                                         \
+    } while (0)
+
 template <typename T>
 int copy_out(const rq_env* env, const T* src, T* dst, int dst_is_device) {
     RQ_REQUIRE(env && dst, RQ_ERR_INVALID_ARGUMENT, "null argument");
@@ -719,7 +735,7 @@ RQ_API int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params*
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     RQ_HIP(rq::launch_sample_state(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed, params->d,
-                                   state->d, env->st.episode, env->st.frozen));
+                                   state->d, env->st));
     return RQ_OK;
 }
 
@@ -732,8 +748,8 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
     const bool mailbox = observation && env->n < kGpuLayoutMinEnvs;
     rq::Mailbox mb{};
     if (mailbox) { rc = ensure_mailbox(dev); if (rc) return rc; mb = mailbox_for(dev, nullptr, 0, dev->mb_out); }
-    RQ_HIP(rq::launch_observe(dev->stream, batch_of(env), rq::noise_cfg(env->cfg), rq::noise_enabled(env->cfg),
-                              rng->seed, rng->epoch, nullptr, params->d, state->d, env->obs, mb));
+    RQ_HIP_MB(rq::launch_observe(dev->stream, batch_of(env), rq::noise_cfg(env->cfg), rq::noise_enabled(env->cfg),
+                                 rng->seed, rng->epoch, nullptr, params->d, state->d, env->obs, mb), dev, mb);
     rng->epoch += 1;
     if (mailbox) {
         rc = mailbox_wait(dev, mb.seq); if (rc) return rc;
@@ -761,9 +777,9 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
         rc = host_to_soa(dev, action, env->n, RQ_ACTION_DIM, env->ld, RQ_ACTION_DIM, env->act);
         if (rc) return rc;
     }
-    RQ_HIP(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
-                           next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
-                           nullptr, nullptr, mb));
+    RQ_HIP_MB(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
+                              next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
+                              nullptr, nullptr, mb), dev, mb);
     if (dts) for (uint32_t i = 0; i < env->n; ++i) dts[i] = env->cfg.dt;
     return RQ_OK;
 }
@@ -806,7 +822,8 @@ RQ_API int rq_env_reset_statistics(rq_env* env) {
     RQ_REQUIRE(env, RQ_ERR_INVALID_ARGUMENT, "null argument");
     DeviceScope on_device(env->dev); int rc = on_device.rc; if (rc) return rc;
     const size_t ld = env->ld;
-    // everything except the per-env episode counters (they key the initial-state RNG)
+    // everything except the per-env episode counters (they key the initial-state RNG); the frozen flags go too:
+    // every env counts as running a fresh episode from its current state (contract in raptor_quad.h)
     RQ_HIP(hipMemsetAsync(env->stats_block, 0, 7 * 4 * ld, env->dev->stream));
     RQ_HIP(hipMemsetAsync(env->st.last_terminated, 0, 3 * ld, env->dev->stream));
     return RQ_OK;
@@ -953,8 +970,8 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
         rc = ensure_mailbox(dev); if (rc) return rc;
         mb = mailbox_for(dev, rows_in, RQ_POLICY_INPUT_DIM, action ? dev->mb_out : nullptr);
     }
-    RQ_HIP(rq::launch_actor_step(dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
-                                 ld_act, nullptr, mode_of(pol), mb));
+    RQ_HIP_MB(rq::launch_actor_step(dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
+                                    ld_act, nullptr, mode_of(pol), mb), dev, mb);
     if (action && mailbox) {
         rc = mailbox_wait(dev, mb.seq); if (rc) return rc;
         std::memcpy(action, dev->mb_out, (size_t)batch * RQ_ACTION_DIM * sizeof(float));
@@ -1097,6 +1114,9 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
             }
             return e;
         };
+        if (n_steps && (flags & RQ_ROLLOUT_AUTORESET))   // envs frozen by an earlier rollout start their next episode
+            RQ_HIP(rq::launch_thaw_frozen(dev->stream, b, smp, rng->seed, params->d, state->d, env->st, policy->hidden,
+                                          policy->w_dev));
         uint32_t done_steps = 0;
         if (!traj && n_steps >= kGraphSteps) {
             // replay a captured graph of kGraphSteps steps; kernel boundaries stay (~1.5 us each) but the

@@ -65,11 +65,37 @@ __device__ __forceinline__ void box_muller_fast(float u1, float u2, float& n0, f
     n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
+// ------------------------------------------------------------------ two-wide fp32 -------
+// A lone wave issues one vector instruction per ~4.7 cycles whatever its width (tools/overlap.hip), and the
+// f32 MFMAs of the actor share the FMA hardware with the VALU, so the env step is priced in issue slots.
+// v_pk_{fma,mul,add}_f32 do two lanes of arithmetic per slot; the source modifiers of the packed encoding
+// (op_sel / op_sel_hi pick which half of each 64-bit source feeds the low / high result, neg_lo / neg_hi
+// negate per half) make swaps, broadcasts and mixed signs free.  The compiler folds broadcasts and whole-
+// vector negations into those modifiers but not mixed signs (it materialises v_xor + v_mov), so the
+// quaternion / cross-product terms are written as single instructions with explicit modifiers.  Per
+// element every operation and its order are those of DESIGN.md "Environment specification".
+// The asm statements are not volatile: the scheduler moves them like any other VALU instruction.  None of
+// them reads an MFMA or transcendental result directly and none feeds a v_permlane (the hazards the
+// compiler only tracks for instructions it can see): their inputs come from loads, copies or plain VALU code.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define RQ_PK_MUL(d, a, b, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
+#define RQ_PK_FMA(d, a, b, c, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(d) : "v"(a), "v"(b), "v"(c))
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float s) { return f32x2{s, s}; }
+// a pair whose low half is s and whose high half is never read (no instruction spent on it)
+__device__ __forceinline__ f32x2 lo_only(float s) { const f32x2 v = {s, s}; return __builtin_shufflevector(v, v, 0, -1); }
+// clamp in ONE instruction; v_med3_f32 returns min3 when an operand is NaN, which is what
+// fminf(fmaxf(x, lo), hi) gives for a NaN x (lo); fminf(fmaxf()) itself costs a canonicalising v_max first
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
 // ------------------------------------------------------------------ per-env constants --
-// What one transition needs from the parameter fields, with the divisions hoisted.
+// What one transition needs from the parameter fields, with the divisions hoisted, in the pair layout
+// the dynamics read.
 struct EnvConsts {
-    float inv_m, jx, jy, jz, ijx, ijy, ijz;
-    float px[4], py[4];
+    f32x2 IM;              // (1/m, 2/m)
+    f32x2 J12, IJ12;       // (Jxx, Jyy), (1/Jxx, 1/Jyy)
+    float jz, ijz;
+    f32x2 PYX[4];          // (y_i, -x_i) of rotor i: torque (x, y) = sum PYX_i T_i
     float c0, c1, c2, kq, itr, itf;
     float rmin, rmax, half, mid;   // action -> set-point map
     float ha;                      // hover action (reward baseline)
@@ -79,11 +105,15 @@ struct EnvConsts {
 template <typename F>
 __device__ __forceinline__ EnvConsts make_consts(F p) {
     EnvConsts k;
-    k.inv_m = 1.0f / p(RQ_P_MASS);
-    k.jx = p(RQ_P_JXX); k.jy = p(RQ_P_JYY); k.jz = p(RQ_P_JZZ);
-    k.ijx = 1.0f / k.jx; k.ijy = 1.0f / k.jy; k.ijz = 1.0f / k.jz;
+    const float inv_m = 1.0f / p(RQ_P_MASS);
+    k.IM = f32x2{inv_m, inv_m + inv_m};
+    const float jx = p(RQ_P_JXX), jy = p(RQ_P_JYY);
+    k.J12 = f32x2{jx, jy};
+    k.IJ12 = f32x2{1.0f / jx, 1.0f / jy};
+    k.jz = p(RQ_P_JZZ);
+    k.ijz = 1.0f / k.jz;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { k.px[i] = p(RQ_P_ROTOR_POS + 3 * i); k.py[i] = p(RQ_P_ROTOR_POS + 3 * i + 1); }
+    for (int i = 0; i < 4; ++i) k.PYX[i] = f32x2{p(RQ_P_ROTOR_POS + 3 * i + 1), -p(RQ_P_ROTOR_POS + 3 * i)};
     k.c0 = p(RQ_P_THRUST_C0); k.c1 = p(RQ_P_THRUST_C1); k.c2 = p(RQ_P_THRUST_C2);
     k.kq = p(RQ_P_TORQUE_CONST);
     k.itr = 1.0f / p(RQ_P_TAU_RISE); k.itf = 1.0f / p(RQ_P_TAU_FALL);
@@ -95,57 +125,123 @@ __device__ __forceinline__ EnvConsts make_consts(F p) {
 }
 
 // per-episode disturbance, folded: acceleration incl. gravity, and body torque
-struct Disturbance { float adx, ady, adz, tdx, tdy, tdz; };
+struct Disturbance { f32x2 AD01, TD01; float adz, tdz; };
 
 __device__ __forceinline__ Disturbance make_disturbance(const EnvConsts& k, float gravity, const float (&f)[6]) {
     Disturbance d;
-    d.adx = f[0] * k.inv_m;
-    d.ady = f[1] * k.inv_m;
-    d.adz = fmaf(f[2], k.inv_m, -gravity);
-    d.tdx = f[3]; d.tdy = f[4]; d.tdz = f[5];
+    d.AD01 = f32x2{f[0] * k.IM[0], f[1] * k.IM[0]};
+    d.adz = fmaf(f[2], k.IM[0], -gravity);
+    d.TD01 = f32x2{f[3], f[4]};
+    d.tdz = f[5];
     return d;
 }
 
-// ------------------------------------------------------------------ dynamics + RK4 -----
-// y = (p[0..2], q[3..6] = (w,x,y,z), v[7..9], w_body[10..12], rpm[13..16]); d = dy/dt
-__device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& ds, const float (&y)[17],
-                                         const float (&sp)[4], float (&d)[17]) {
-    const float qw = y[3], qx = y[4], qy = y[5], qz = y[6];
-    const float wx = y[10], wy = y[11], wz = y[12];
-    float T[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[i] = fmaf(fmaf(k.c2, y[13 + i], k.c1), y[13 + i], k.c0);
-    const float Tsum = ((T[0] + T[1]) + T[2]) + T[3];
-    float tx = fmaf(k.py[3], T[3], fmaf(k.py[2], T[2], fmaf(k.py[1], T[1], k.py[0] * T[0])));
-    float ty = -fmaf(k.px[3], T[3], fmaf(k.px[2], T[2], fmaf(k.px[1], T[1], k.px[0] * T[0])));
-    float tz = k.kq * (((T[1] + T[3]) - T[0]) - T[2]);   // spin directions (-1,+1,-1,+1)
-    tx += ds.tdx; ty += ds.tdy; tz += ds.tdz;
-    d[0] = y[7]; d[1] = y[8]; d[2] = y[9];
-    d[3] = -0.5f * fmaf(qz, wz, fmaf(qy, wy, qx * wx));
-    d[4] = 0.5f * fmaf(-qz, wy, fmaf(qy, wz, qw * wx));
-    d[5] = 0.5f * fmaf(-qx, wz, fmaf(qz, wx, qw * wy));
-    d[6] = 0.5f * fmaf(-qy, wx, fmaf(qx, wy, qw * wz));
-    const float r02 = 2.0f * fmaf(qx, qz, qw * qy);
-    const float r12 = 2.0f * fmaf(qy, qz, -(qw * qx));
-    const float r22 = fmaf(-2.0f, fmaf(qx, qx, qy * qy), 1.0f);
-    const float acc = Tsum * k.inv_m;
-    d[7] = fmaf(r02, acc, ds.adx);
-    d[8] = fmaf(r12, acc, ds.ady);
-    d[9] = fmaf(r22, acc, ds.adz);
-    const float jwx = k.jx * wx, jwy = k.jy * wy, jwz = k.jz * wz;
-    const float cx = fmaf(wy, jwz, -(wz * jwy));
-    const float cy = fmaf(wz, jwx, -(wx * jwz));
-    const float cz = fmaf(wx, jwy, -(wy * jwx));
-    d[10] = (tx - cx) * k.ijx;
-    d[11] = (ty - cy) * k.ijy;
-    d[12] = (tz - cz) * k.ijz;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float e = sp[i] - y[13 + i];
-        d[13 + i] = e * (sp[i] >= y[13 + i] ? k.itr : k.itf);
+// ------------------------------------------------------------------ state in registers -
+// The 17 dynamic state components of one env as 8 pairs + 1: the pairing is chosen so that every term
+// of the dynamics is ONE packed instruction on existing pairs (swap / broadcast / sign by modifier).
+// Field order in memory (RQ_S_*): p0 p1 p2 | qw qx qy qz | v0 v1 v2 | wx wy wz | r0 r1 r2 r3.
+struct QuadState {
+    f32x2 P01; float p2;
+    f32x2 Q1, Q2;       // (qw, qz), (qx, qy)
+    f32x2 V01, VW;      // (vx, vy), (vz, wz)
+    f32x2 Wa;           // (wx, wy)
+    f32x2 R01, R23;     // rotor speeds
+
+    template <typename F> __device__ __forceinline__ void load(F g) {   // g(j) = state field j
+        P01 = f32x2{g(0), g(1)}; p2 = g(2);
+        Q1 = f32x2{g(3), g(6)}; Q2 = f32x2{g(4), g(5)};
+        V01 = f32x2{g(7), g(8)}; VW = f32x2{g(9), g(12)};
+        Wa = f32x2{g(10), g(11)};
+        R01 = f32x2{g(13), g(14)}; R23 = f32x2{g(15), g(16)};
     }
+    template <typename F> __device__ __forceinline__ void store(F put) const {   // put(j, value)
+        put(0, P01[0]); put(1, P01[1]); put(2, p2);
+        put(3, Q1[0]); put(4, Q2[0]); put(5, Q2[1]); put(6, Q1[1]);
+        put(7, V01[0]); put(8, V01[1]); put(9, VW[0]);
+        put(10, Wa[0]); put(11, Wa[1]); put(12, VW[1]);
+        put(13, R01[0]); put(14, R01[1]); put(15, R23[0]); put(16, R23[1]);
+    }
+};
+
+// lane-wise select: take ? a : b (frozen envs of a non-auto-reset rollout keep their state)
+__device__ __forceinline__ f32x2 sel2(bool take, f32x2 a, f32x2 b) { return f32x2{take ? a[0] : b[0], take ? a[1] : b[1]}; }
+__device__ __forceinline__ void select_state(bool take, const QuadState& a, QuadState& y) {
+    y.P01 = sel2(take, a.P01, y.P01); y.p2 = take ? a.p2 : y.p2;
+    y.Q1 = sel2(take, a.Q1, y.Q1); y.Q2 = sel2(take, a.Q2, y.Q2);
+    y.V01 = sel2(take, a.V01, y.V01); y.VW = sel2(take, a.VW, y.VW); y.Wa = sel2(take, a.Wa, y.Wa);
+    y.R01 = sel2(take, a.R01, y.R01); y.R23 = sel2(take, a.R23, y.R23);
 }
 
+// ------------------------------------------------------------------ dynamics + RK4 -----
+// Derivative of everything but the position (dp = v of the evaluated state).  Q1 / Q2 hold 2 dq/dt: the
+// factor 1/2 rides in the RK4 coefficient of those two pairs (exact).
+struct Deriv { f32x2 Q1, Q2, V01, VW, Wa, R01, R23; };
+
+// 28 packed + 20 single instructions (the scalar form is 86)
+__device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& ds, const QuadState& y,
+                                         f32x2 SP01, f32x2 SP23, Deriv& d) {
+    // rotor thrusts T_i = c0 + c1 r_i + c2 r_i^2, their sum and the three torques
+    const f32x2 c2 = splat(k.c2), c1 = splat(k.c1), c0 = splat(k.c0);
+    const f32x2 T01 = pk_fma(pk_fma(c2, y.R01, c1), y.R01, c0);
+    const f32x2 T23 = pk_fma(pk_fma(c2, y.R23, c1), y.R23, c0);
+    const f32x2 U = T01 + T23;                         // (T0 + T2, T1 + T3)
+    const f32x2 TS = lo_only(U[0] + U[1]);
+    const float tz = fmaf(k.kq, U[1] - U[0], ds.tdz);  // spin directions (-1,+1,-1,+1)
+    f32x2 TXY;                                         // (tx, ty) = TD + sum_i (y_i, -x_i) T_i
+    RQ_PK_FMA(TXY, k.PYX[0], T01, ds.TD01, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+    RQ_PK_FMA(TXY, k.PYX[1], T01, TXY, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+    RQ_PK_FMA(TXY, k.PYX[2], T23, TXY, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+    RQ_PK_FMA(TXY, k.PYX[3], T23, TXY, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+    // 2 dq/dt = q (x) (0, w);   Q1 = (qw, qz), Q2 = (qx, qy), Wa = (wx, wy), VW = (vz, wz)
+    f32x2 S1, S2;
+    RQ_PK_MUL(S1, y.Q1, y.VW, "op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]");                          // (-qz wz,  qw wz)
+    RQ_PK_FMA(S1, y.Q2, y.Wa, S1, "op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]");                  // (-qx wx, +qx wy)
+    RQ_PK_FMA(S1, y.Q2, y.Wa, S1, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]");   // (-qy wy, -qy wx)
+    RQ_PK_MUL(S2, y.Q1, y.Wa, "op_sel:[0,0] op_sel_hi:[0,1]");                                       // ( qw wx,  qw wy)
+    RQ_PK_FMA(S2, y.Q1, y.Wa, S2, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]");                  // (-qz wy, +qz wx)
+    RQ_PK_FMA(S2, y.Q2, y.VW, S2, "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]");                  // (+qy wz, -qx wz)
+    d.Q1 = S1; d.Q2 = S2;
+    // dv = R(q) (0,0,Tsum) / m + g + F/m: H = half of the third column of R, (acc, 2 acc) = Tsum (1/m, 2/m)
+    f32x2 H, AC;
+    RQ_PK_MUL(H, y.Q1, y.Q2, "op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]");                           // (qw qy, -qw qx)
+    RQ_PK_FMA(H, y.Q2, y.Q1, H, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");                                  // (+qx qz, +qy qz)
+    RQ_PK_MUL(AC, TS, k.IM, "op_sel:[0,0] op_sel_hi:[0,1]");
+    RQ_PK_FMA(d.V01, H, AC, ds.AD01, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+    const float qx = y.Q2[0], qy = y.Q2[1];
+    const float r22 = fmaf(-2.0f, fmaf(qx, qx, qy * qy), 1.0f);
+    const float dv2 = fmaf(r22, AC[0], ds.adz);
+    // dw = J^-1 (tau - w x J w)
+    const f32x2 JW = k.J12 * y.Wa;                     // (Jx wx, Jy wy)
+    const f32x2 JWZ = splat(k.jz) * y.VW;             // (unused, Jz wz): a packed multiply lands it in a pair as is
+    f32x2 C;
+    RQ_PK_MUL(C, y.Wa, JWZ, "op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]");                            // (wy Jz wz, -wx Jz wz)
+    RQ_PK_FMA(C, y.VW, JW, C, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]");                     // (-wz Jy wy, +wz Jx wx)
+    const float cz = fmaf(y.Wa[0], JW[1], -(y.Wa[1] * JW[0]));
+    d.Wa = (TXY - C) * k.IJ12;
+    const float dwz = (tz - cz) * k.ijz;
+    d.VW = f32x2{dv2, dwz};
+    // first-order rotors
+    const f32x2 IT01 = {SP01[0] >= y.R01[0] ? k.itr : k.itf, SP01[1] >= y.R01[1] ? k.itr : k.itf};
+    const f32x2 IT23 = {SP23[0] >= y.R23[0] ? k.itr : k.itf, SP23[1] >= y.R23[1] ? k.itr : k.itf};
+    d.R01 = (SP01 - y.R01) * IT01;
+    d.R23 = (SP23 - y.R23) * IT23;
+}
+
+// o = a + c * (derivative): position advances with the velocity of the state the derivative was taken at
+// (vs); ch = c / 2 for the quaternion pairs.  8 packed + 1 single instruction.
+__device__ __forceinline__ void rk_axpy(QuadState& o, const QuadState& a, float c, float ch, const QuadState& vs,
+                                        const Deriv& d) {
+    const f32x2 C = splat(c), CH = splat(ch);
+    o.P01 = pk_fma(C, vs.V01, a.P01);
+    o.p2 = fmaf(c, vs.VW[0], a.p2);
+    o.Q1 = pk_fma(CH, d.Q1, a.Q1);
+    o.Q2 = pk_fma(CH, d.Q2, a.Q2);
+    o.V01 = pk_fma(C, d.V01, a.V01);
+    o.VW = pk_fma(C, d.VW, a.VW);
+    o.Wa = pk_fma(C, d.Wa, a.Wa);
+    o.R01 = pk_fma(C, d.R01, a.R01);
+    o.R23 = pk_fma(C, d.R23, a.R23);
+}
 
 __device__ __forceinline__ bool finite_(float x) { return fabsf(x) <= 3.402823466e+38f; }
 // max(|a|, |b|, |c|), NaN if any operand is NaN (one v_maximum3_f32 with |.| source modifiers)
@@ -154,36 +250,36 @@ __device__ __forceinline__ float amax3(float a, float b, float c) {
                                          __builtin_fabsf(c));
 }
 
-// One transition, in place: y[17] <- RK4(y, clip(a)); ac = clipped action; returns reward, sets term.
+// One transition, in place: y <- RK4(y, clip(a)); (AC01, AC23) = clipped action; returns reward, sets term.
 __device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts& k, const Disturbance& ds,
-                                              float (&y)[17], const float (&a)[4], float (&ac)[4], bool& term) {
-    float sp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ac[i] = fminf(fmaxf(a[i], -1.0f), 1.0f);
-        sp[i] = fmaf(ac[i], k.half, k.mid);
-    }
-    const float dt = c.dt, hdt = 0.5f * c.dt, dt6 = c.dt / 6.0f;
-    float yt[17], kk[17], ks[17];   // ks accumulates k1 + k4 and (k2 + k3) is folded in place
-    dynamics(k, ds, y, sp, kk);                       // k1
-#pragma unroll
-    for (int i = 0; i < 17; ++i) { ks[i] = kk[i]; yt[i] = fmaf(hdt, kk[i], y[i]); }
-    float k2[17];
-    dynamics(k, ds, yt, sp, k2);                      // k2
-#pragma unroll
-    for (int i = 0; i < 17; ++i) yt[i] = fmaf(hdt, k2[i], y[i]);
-    dynamics(k, ds, yt, sp, kk);                      // k3
-#pragma unroll
-    for (int i = 0; i < 17; ++i) { k2[i] = k2[i] + kk[i]; yt[i] = fmaf(dt, kk[i], y[i]); }
-    dynamics(k, ds, yt, sp, kk);                      // k4
-#pragma unroll
-    for (int i = 0; i < 17; ++i) y[i] = fmaf(dt6, fmaf(2.0f, k2[i], ks[i] + kk[i]), y[i]);
-    const float nq = sqrtf(fmaf(y[6], y[6], fmaf(y[5], y[5], fmaf(y[4], y[4], y[3] * y[3]))));
-    const float inq = 1.0f / nq;
-#pragma unroll
-    for (int i = 3; i < 7; ++i) y[i] *= inq;
-#pragma unroll
-    for (int i = 13; i < 17; ++i) y[i] = fminf(fmaxf(y[i], k.rmin), k.rmax);
+                                              QuadState& y, const float (&a)[4], f32x2& AC01, f32x2& AC23, bool& term) {
+    AC01 = f32x2{clampf(a[0], -1.0f, 1.0f), clampf(a[1], -1.0f, 1.0f)};
+    AC23 = f32x2{clampf(a[2], -1.0f, 1.0f), clampf(a[3], -1.0f, 1.0f)};
+    const f32x2 SP01 = pk_fma(AC01, splat(k.half), splat(k.mid));
+    const f32x2 SP23 = pk_fma(AC23, splat(k.half), splat(k.mid));
+    // classical RK4 accumulated stage by stage: y' = y + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4
+    const float dt = c.dt, hdt = 0.5f * c.dt, dt6 = c.dt / 6.0f, dt3 = c.dt / 3.0f;
+    Deriv d;
+    QuadState acc, yt, yu;
+    dynamics(k, ds, y, SP01, SP23, d);                          // k1
+    rk_axpy(acc, y, dt6, 0.5f * dt6, y, d);
+    rk_axpy(yt, y, hdt, 0.5f * hdt, y, d);
+    dynamics(k, ds, yt, SP01, SP23, d);                         // k2
+    rk_axpy(acc, acc, dt3, 0.5f * dt3, yt, d);
+    rk_axpy(yu, y, hdt, 0.5f * hdt, yt, d);
+    dynamics(k, ds, yu, SP01, SP23, d);                         // k3
+    rk_axpy(acc, acc, dt3, 0.5f * dt3, yu, d);
+    rk_axpy(yt, y, dt, 0.5f * dt, yu, d);
+    dynamics(k, ds, yt, SP01, SP23, d);                         // k4
+    rk_axpy(y, acc, dt6, 0.5f * dt6, yt, d);
+    // quaternion back to unit length: 1/|q| from its series around |q|^2 = 1 (fmas only: rounds the same
+    // on both sides; e clamped so that a non-unit quaternion handed in is pulled back, not blown up)
+    const f32x2 SQ = pk_fma(y.Q2, y.Q2, y.Q1 * y.Q1);           // (qx^2 + qw^2, qy^2 + qz^2)
+    const float eq = clampf(1.0f - (SQ[0] + SQ[1]), -0.5f, 0.5f);
+    const f32x2 INQ = splat(fmaf(eq, fmaf(0.375f, eq, 0.5f), 1.0f));
+    y.Q1 = y.Q1 * INQ; y.Q2 = y.Q2 * INQ;
+    y.R01 = f32x2{clampf(y.R01[0], k.rmin, k.rmax), clampf(y.R01[1], k.rmin, k.rmax)};
+    y.R23 = f32x2{clampf(y.R23[0], k.rmin, k.rmax), clampf(y.R23[1], k.rmin, k.rmax)};
 
     // Termination: any |p_i| > termination_position, |v_i| > termination_linear_velocity, |w_i| >
     // termination_angular_velocity, or any non-finite state component.  Evaluated on NaN-PROPAGATING
@@ -193,24 +289,24 @@ __device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts&
     // the i1 bit-vector code the compiler builds for a 26-term OR (measured: ~75 VALU instructions).
     bool t = false;
     if (c.termination_enabled) {
-        const float mp = amax3(y[0], y[1], y[2]);
-        const float mv = amax3(y[7], y[8], y[9]);
-        const float mw = amax3(y[10], y[11], y[12]);
-        float m = amax3(y[3], y[4], y[5]);
-        m = amax3(m, y[6], y[13]);
-        m = amax3(m, y[14], y[15]);
-        m = amax3(m, y[16], mp);
+        const float mp = amax3(y.P01[0], y.P01[1], y.p2);
+        const float mv = amax3(y.V01[0], y.V01[1], y.VW[0]);
+        const float mw = amax3(y.Wa[0], y.Wa[1], y.VW[1]);
+        float m = amax3(y.Q1[0], y.Q2[0], y.Q2[1]);
+        m = amax3(m, y.Q1[1], y.R01[0]);
+        m = amax3(m, y.R01[1], y.R23[0]);
+        m = amax3(m, y.R23[1], mp);
         m = amax3(m, mv, mw);
         t = (mp > c.termination_position) | (mv > c.termination_linear_velocity) |
             (mw > c.termination_angular_velocity) | !finite_(m);
     }
     term = t;
-    const float pc = fmaf(y[2], y[2], fmaf(y[1], y[1], y[0] * y[0]));
-    const float oc = fmaf(-y[3], y[3], 1.0f);
-    const float vc = fmaf(y[9], y[9], fmaf(y[8], y[8], y[7] * y[7]));
-    const float wc = fmaf(y[12], y[12], fmaf(y[11], y[11], y[10] * y[10]));
-    const float d0 = ac[0] - k.ha, d1 = ac[1] - k.ha, d2 = ac[2] - k.ha, d3 = ac[3] - k.ha;
-    const float acst = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+    const float pc = fmaf(y.p2, y.p2, fmaf(y.P01[1], y.P01[1], y.P01[0] * y.P01[0]));
+    const float oc = fmaf(-y.Q1[0], y.Q1[0], 1.0f);
+    const float vc = fmaf(y.VW[0], y.VW[0], fmaf(y.V01[1], y.V01[1], y.V01[0] * y.V01[0]));
+    const float wc = fmaf(y.VW[1], y.VW[1], fmaf(y.Wa[1], y.Wa[1], y.Wa[0] * y.Wa[0]));
+    const f32x2 D01 = AC01 - splat(k.ha), D23 = AC23 - splat(k.ha);
+    const float acst = fmaf(D23[1], D23[1], fmaf(D23[0], D23[0], fmaf(D01[1], D01[1], D01[0] * D01[0])));
     const float cost = fmaf(c.reward_action, acst,
                        fmaf(c.reward_angular_velocity, wc,
                        fmaf(c.reward_linear_velocity, vc,
@@ -220,20 +316,30 @@ __device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts&
 
 // ------------------------------------------------------------------ observe ------------
 
-// policy-visible head: o[0..21] = [p, R(q) row-major, v, w_body, previous action]
+// policy-visible head: o[0..21] = [p, R(q) row-major, v, w_body, previous action].
+// R from the doubled quaternion: x (2y) = 2 (x y) and 2a - 2b = 2 (a - b) exactly, so every entry equals the
+// oracle's 2 (xy - wz) / 1 - 2 (yy + zz) forms bit for bit in 15 instructions instead of 27.
 template <bool NOISE>
-__device__ __forceinline__ void observe_head(const float (&y)[17], const float (&last_action)[4],
+__device__ __forceinline__ void observe_head(const QuadState& y, f32x2 LA01, f32x2 LA23,
                                              const NoiseCfg& nc, uint64_t seed, uint32_t epoch, uint64_t genv,
                                              float (&o)[22]) {
-    const float w = y[3], x = y[4], yy_ = y[5], z = y[6];
-    const float xx = x * x, yy = yy_ * yy_, zz = z * z, xy = x * yy_, xz = x * z, yz = yy_ * z;
-    const float wx = w * x, wy = w * yy_, wz = w * z;
-    o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
-    o[3] = fmaf(-2.0f, yy + zz, 1.0f); o[4] = 2.0f * (xy - wz);           o[5] = 2.0f * (xz + wy);
-    o[6] = 2.0f * (xy + wz);           o[7] = fmaf(-2.0f, xx + zz, 1.0f); o[8] = 2.0f * (yz - wx);
-    o[9] = 2.0f * (xz - wy);           o[10] = 2.0f * (yz + wx);          o[11] = fmaf(-2.0f, xx + yy, 1.0f);
-    o[12] = y[7]; o[13] = y[8]; o[14] = y[9];
-    o[15] = y[10]; o[16] = y[11]; o[17] = y[12];
+    const float w = y.Q1[0], z = y.Q1[1];
+    const f32x2 D2 = y.Q2 + y.Q2;                // (2x, 2y)
+    const float z2 = z + z;
+    const f32x2 SQ = y.Q2 * D2;                  // (2xx, 2yy)
+    const f32x2 XZ = y.Q2 * splat(z2);           // (2xz, 2yz)
+    const f32x2 WX = splat(w) * D2;              // (2wx, 2wy)
+    const f32x2 WZ = y.Q1 * splat(z2);           // (2wz, 2zz)
+    const float xy = y.Q2[0] * D2[1];            // 2xy
+    const f32x2 DG = splat(1.0f) - (SQ + splat(WZ[1]));                      // (1 - 2(xx + zz), 1 - 2(yy + zz))
+    const f32x2 PL = XZ + __builtin_shufflevector(WX, WX, 1, 0);            // (2(xz + wy), 2(yz + wx))
+    const f32x2 MI = XZ - __builtin_shufflevector(WX, WX, 1, 0);            // (2(xz - wy), 2(yz - wx))
+    o[0] = y.P01[0]; o[1] = y.P01[1]; o[2] = y.p2;
+    o[3] = DG[1];            o[4] = xy - WZ[0];       o[5] = PL[0];
+    o[6] = xy + WZ[0];       o[7] = DG[0];            o[8] = MI[1];
+    o[9] = MI[0];            o[10] = PL[1];           o[11] = 1.0f - (SQ[0] + SQ[1]);
+    o[12] = y.V01[0]; o[13] = y.V01[1]; o[14] = y.VW[0];
+    o[15] = y.Wa[0]; o[16] = y.Wa[1]; o[17] = y.VW[1];
     if (NOISE) {
         float nrm[20];
 #pragma unroll
@@ -251,8 +357,7 @@ __device__ __forceinline__ void observe_head(const float (&y)[17], const float (
 #pragma unroll
         for (int i = 15; i < 18; ++i) o[i] = fmaf(nc.angular_velocity, nrm[i], o[i]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[18 + i] = last_action[i];
+    o[18] = LA01[0]; o[19] = LA01[1]; o[20] = LA23[0]; o[21] = LA23[1];
 }
 
 // ------------------------------------------------------------------ parameter sampling -
@@ -410,7 +515,6 @@ enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF
 // Packed weight image: enum QW_* in rq_kernels.hpp (shared with the host-side packer rq_pack.cpp).
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // max(x, 0) in ONE instruction (v_max_i32 on the bit pattern: non-negative floats order like ints, every
 // negative float and -0 is a negative int).  fmaxf() on an MFMA result costs two: the compiler first
@@ -423,7 +527,6 @@ __device__ __forceinline__ float relu(float x) {
 }
 
 // two-wide fp32 helpers (v_pk_fma_f32 and friends; the transcendentals have no packed form)
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_exp2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
 __device__ __forceinline__ f32x2 pk_rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
 

@@ -58,10 +58,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_params(Batch b, SampleCfg c, 
 
 __global__ __launch_bounds__(kBlock) void k_sample_state(Batch b, SampleCfg c, uint64_t seed,
                                                          const float* __restrict__ params, float* __restrict__ state,
-                                                         uint32_t* __restrict__ episode, uint8_t* __restrict__ frozen) {
+                                                         StatsPtrs st) {
     const uint32_t i = env_index();
     if (i >= b.n) return;
-    const uint32_t ep = episode[i];
+    const uint32_t ep = st.episode[i];
     float s[17], la[4], f[6];
     sample_state(c, seed, ep, b.env_offset + i, field(params, RQ_P_MASS, b.ld)[i],
                  field(params, RQ_P_HOVER_RPM, b.ld)[i], field(params, RQ_P_ROTOR_POS, b.ld)[i],
@@ -72,8 +72,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_state(Batch b, SampleCfg c, u
     for (int k = 0; k < 4; ++k) field(state, (RQ_S_LAST_ACTION + k), b.ld)[i] = la[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) field(state, (RQ_S_FORCE + k), b.ld)[i] = f[k];
-    episode[i] = ep + 1;
-    frozen[i] = 0;
+    st.episode[i] = ep + 1;
+    st.frozen[i] = 0;
+    st.returns[i] = 0.0f;      // a new episode begins: no return / step count carried over from an abandoned one
+    st.steps[i] = 0;
 }
 
 // ------------------------------------------------------------------ observe ------------
@@ -88,21 +90,20 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
         // inside a replayed hipGraph the noise epoch cannot be a baked-in argument: it is read from a
         // device counter the graph itself advances (k_advance_u32); eager launches pass nullptr
         const uint32_t epoch = epoch_offset + (epoch_base != nullptr ? *epoch_base : 0u);
-        float y[17], la[4];
-#pragma unroll
-        for (int k = 0; k < 17; ++k) y[k] = field(state, k, b.ld)[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) la[k] = field(state, (RQ_S_LAST_ACTION + k), b.ld)[i];
+        QuadState y;
+        y.load([&](int k) { return field(state, k, b.ld)[i]; });
+        const f32x2 LA01 = {field(state, (RQ_S_LAST_ACTION + 0), b.ld)[i], field(state, (RQ_S_LAST_ACTION + 1), b.ld)[i]};
+        const f32x2 LA23 = {field(state, (RQ_S_LAST_ACTION + 2), b.ld)[i], field(state, (RQ_S_LAST_ACTION + 3), b.ld)[i]};
         const float rmin = field(params, RQ_P_RPM_MIN, b.ld)[i];
         const float rmax = field(params, RQ_P_RPM_MAX, b.ld)[i];
         float head[22], o[RQ_OBSERVATION_DIM];
-        observe_head<NOISE>(y, la, nc, seed, epoch, b.env_offset + i, head);
+        observe_head<NOISE>(y, LA01, LA23, nc, seed, epoch, b.env_offset + i, head);
 #pragma unroll
         for (int k = 0; k < 22; ++k) o[k] = head[k];
         // privileged tail: normalised rotor speeds
         const float inv = 2.0f / (rmax - rmin);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[22 + k] = fmaf(y[13 + k] - rmin, inv, -1.0f);
+        o[22] = fmaf(y.R01[0] - rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - rmin, inv, -1.0f);
+        o[24] = fmaf(y.R23[0] - rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - rmin, inv, -1.0f);
 #pragma unroll
         for (int k = 0; k < RQ_OBSERVATION_DIM; ++k) field(obs, k, b.ld)[i] = o[k];
         if (mb.rows_out != nullptr) {            // wave-uniform (kernel argument)
@@ -305,9 +306,10 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
-    float y[17], f6[6], a[4], ac[4];
-#pragma unroll
-    for (int j = 0; j < 17; ++j) y[j] = field(state, j, ld)[i];
+    QuadState y;
+    float f6[6], a[4];
+    f32x2 AC01, AC23;
+    y.load([&](int j) { return field(state, j, ld)[i]; });
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
     if (mb.rows_in != nullptr) {             // actions handed over in the host mailbox (kernel argument)
@@ -320,7 +322,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     Stats s = load_stats(st, i);
     const Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool term;
-    const float r = step_inplace(c, k, ds, y, a, ac, term);
+    const float r = step_inplace(c, k, ds, y, a, AC01, AC23, term);
     const bool ended = stats_update(c.episode_step_limit, r, term, s);
     st.last_reward[i] = r;
     st.last_terminated[i] = term ? 1 : 0;
@@ -330,9 +332,12 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     if (ROLLOUT && ended) {
         if (flags & RQ_ROLLOUT_AUTORESET) {
             const uint32_t ep = st.episode[i];
+            float fresh[17], la0[4];
             sample_state(sc, seed, ep, b.env_offset + i, field(params, RQ_P_MASS, ld)[i],
                          field(params, RQ_P_HOVER_RPM, ld)[i], field(params, RQ_P_ROTOR_POS, ld)[i],
-                         field(params, (RQ_P_ROTOR_POS + 1), ld)[i], y, ac, f6);
+                         field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh, la0, f6);
+            y.load([&](int j) { return fresh[j]; });
+            AC01 = f32x2{la0[0], la0[1]}; AC23 = f32x2{la0[2], la0[3]};
             st.episode[i] = ep + 1;
             write_dist = true;
 #pragma unroll
@@ -341,10 +346,9 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
             st.frozen[i] = 1;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 17; ++j) field(next_state, j, ld)[i] = y[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) field(next_state, (RQ_S_LAST_ACTION + j), ld)[i] = ac[j];
+    y.store([&](int j, float v) { field(next_state, j, ld)[i] = v; });
+    field(next_state, (RQ_S_LAST_ACTION + 0), ld)[i] = AC01[0]; field(next_state, (RQ_S_LAST_ACTION + 1), ld)[i] = AC01[1];
+    field(next_state, (RQ_S_LAST_ACTION + 2), ld)[i] = AC23[0]; field(next_state, (RQ_S_LAST_ACTION + 3), ld)[i] = AC23[1];
     if (write_dist) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) field(next_state, (RQ_S_FORCE + j), ld)[i] = f6[j];
@@ -388,11 +392,12 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     const size_t ld = b.ld;
     const uint64_t genv = b.env_offset + i;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
-    float y[17], la[4], f6[6], hQ[4][4];
-#pragma unroll
-    for (int j = 0; j < 17; ++j) y[j] = field(state, j, ld)[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) la[j] = field(state, (RQ_S_LAST_ACTION + j), ld)[i];
+    QuadState y;
+    f32x2 LA01, LA23;
+    float f6[6], hQ[4][4];
+    y.load([&](int j) { return field(state, j, ld)[i]; });
+    LA01 = f32x2{field(state, (RQ_S_LAST_ACTION + 0), ld)[i], field(state, (RQ_S_LAST_ACTION + 1), ld)[i]};
+    LA23 = f32x2{field(state, (RQ_S_LAST_ACTION + 2), ld)[i], field(state, (RQ_S_LAST_ACTION + 3), ld)[i]};
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
     load_hidden_q(hidden, ld, wave_base, b.n, hQ);
@@ -402,19 +407,41 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
 #pragma unroll
         for (int r = 0; r < 4; ++r) h0Q[t][r] = actor.h0(r);
     Stats s = load_stats(st, i);
-    Disturbance ds = make_disturbance(k, c.gravity, f6);
     float last_r = st.last_reward[i];
     bool last_t = st.last_terminated[i] != 0;
     uint8_t last_d = st.last_done[i];
     const bool was_frozen = st.frozen[i] != 0;
-    bool frozen = was_frozen, any_end = false, dist_changed = false;
+    bool any_end = false, dist_changed = false;
     uint32_t ep = AUTORESET ? st.episode[i] : 0u;
+    // sample_initial_state for this lane's env, episode counter ep (out of line: rare, see rq_device_math.hpp)
+    auto resample = [&]() {
+        float fresh[27];
+        sample_state_outlined(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i],
+                              field(params, RQ_P_HOVER_RPM, ld)[i], field(params, RQ_P_ROTOR_POS, ld)[i],
+                              field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh);
+        y.load([&](int j) { return fresh[j]; });
+        LA01 = f32x2{fresh[17], fresh[18]}; LA23 = f32x2{fresh[19], fresh[20]};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) f6[j] = fresh[21 + j];
+        ep += 1;
+        dist_changed = true;
+    };
+    if (AUTORESET) {
+        // An env left frozen by an earlier rollout WITHOUT auto-reset (its episode is over) starts its next
+        // episode here, as every episode end under auto-reset does: re-sampled, policy state reset.  The
+        // chained mode does the same before its first step (k_thaw_frozen).
+        if (was_frozen) resample();
+        const uint64_t thaw = __builtin_amdgcn_ballot_w64(was_frozen);
+        if (thaw != 0) select_hidden_q(thaw, h0Q, hQ);
+    }
+    Disturbance ds = make_disturbance(k, c.gravity, f6);
+    bool frozen = AUTORESET ? false : was_frozen;
 
     for (uint32_t t = 0; t < n_steps; ++t) {
         const uint64_t live = AUTORESET ? ~0ull : __builtin_amdgcn_ballot_w64(!frozen);
         if (!AUTORESET && live == 0) break;   // wave-uniform exit: every env of the wave is frozen
-        float o[22], a[4], ac[4];
-        observe_head<NOISE>(y, la, nc, seed, epoch0 + t, genv, o);
+        float o[22], a[4];
+        observe_head<NOISE>(y, LA01, LA23, nc, seed, epoch0 + t, genv, o);
         float hn[4][4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
@@ -449,18 +476,18 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         } else {
             select_hidden_q(live, hn, hQ);    // frozen envs keep their hidden state
         }
-        float yn[17];
-#pragma unroll
-        for (int j = 0; j < 17; ++j) yn[j] = y[j];
+        // everything above belongs to the actor (MFMA results consumed, transposes done); the env step below
+        // contains hand-placed packed instructions the compiler's hazard tracking does not see through
+        __builtin_amdgcn_sched_barrier(0);
+        QuadState yn = y;
+        f32x2 A01, A23;
         bool term;
-        const float r = step_inplace(c, k, ds, yn, a, ac, term);
+        const float r = step_inplace(c, k, ds, yn, a, A01, A23, term);
         bool ended = false;
         uint8_t done_code = 4;          // frozen: computed on a scratch copy, not committed
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
-#pragma unroll
-            for (int j = 0; j < 17; ++j) y[j] = yn[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) la[j] = ac[j];
+            y = yn;
+            LA01 = A01; LA23 = A23;
             last_r = r; last_t = term;
             ended = stats_update(c.episode_step_limit, r, term, s);
             done_code = term ? 1 : (ended ? 2 : 0);
@@ -468,20 +495,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             if (ended) {
                 any_end = true;
                 if (AUTORESET) {
-                    float fresh[27];
-                    sample_state_outlined(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i],
-                                          field(params, RQ_P_HOVER_RPM, ld)[i],
-                                          field(params, RQ_P_ROTOR_POS, ld)[i],
-                                          field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh);
-#pragma unroll
-                    for (int j = 0; j < 17; ++j) y[j] = fresh[j];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) la[j] = fresh[17 + j];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) f6[j] = fresh[21 + j];
-                    ep += 1;
+                    resample();
                     ds = make_disturbance(k, c.gravity, f6);
-                    dist_changed = true;
                 } else {
                     frozen = true;
                 }
@@ -501,11 +516,11 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         }
     }
 
-    if (valid && !was_frozen) {
-#pragma unroll
-        for (int j = 0; j < 17; ++j) field(state, j, ld)[i] = y[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) field(state, (RQ_S_LAST_ACTION + j), ld)[i] = la[j];
+    const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
+    if (valid && commit) {
+        y.store([&](int j, float v) { field(state, j, ld)[i] = v; });
+        field(state, (RQ_S_LAST_ACTION + 0), ld)[i] = LA01[0]; field(state, (RQ_S_LAST_ACTION + 1), ld)[i] = LA01[1];
+        field(state, (RQ_S_LAST_ACTION + 2), ld)[i] = LA23[0]; field(state, (RQ_S_LAST_ACTION + 3), ld)[i] = LA23[1];
         if (dist_changed) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), ld)[i] = f6[j];
@@ -514,11 +529,39 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         st.last_reward[i] = last_r;
         st.last_terminated[i] = last_t ? 1 : 0;
         st.last_done[i] = last_d;
-        if (AUTORESET) st.episode[i] = ep;
+        if (AUTORESET) {
+            st.episode[i] = ep;
+            if (was_frozen) st.frozen[i] = 0;
+        }
         if (frozen) st.frozen[i] = 1;
     }
-    if (valid && was_frozen && n_steps > 0) st.last_done[i] = 4;   // not stepped by this rollout (as k_step reports it)
-    store_hidden_q(hidden, ld, wave_base, __builtin_amdgcn_ballot_w64(valid && !was_frozen), hQ);
+    if (valid && !commit && n_steps > 0) st.last_done[i] = 4;   // not stepped by this rollout (as k_step reports it)
+    store_hidden_q(hidden, ld, wave_base, __builtin_amdgcn_ballot_w64(valid && commit), hQ);
+}
+
+// Chained-mode counterpart of the fused kernel's prologue under auto-reset: envs left frozen by an earlier
+// rollout start their next episode (sample_initial_state with the env's episode counter, policy state reset).
+__global__ __launch_bounds__(kBlock) void k_thaw_frozen(Batch b, SampleCfg c, uint64_t seed,
+                                                        const float* __restrict__ params, float* __restrict__ state,
+                                                        StatsPtrs st, float* __restrict__ hidden,
+                                                        const float* __restrict__ weights) {
+    const uint32_t i = env_index();
+    if (i >= b.n || !st.frozen[i]) return;
+    const size_t ld = b.ld;
+    const uint32_t ep = st.episode[i];
+    float s[17], la[4], f[6];
+    sample_state(c, seed, ep, b.env_offset + i, field(params, RQ_P_MASS, ld)[i], field(params, RQ_P_HOVER_RPM, ld)[i],
+                 field(params, RQ_P_ROTOR_POS, ld)[i], field(params, (RQ_P_ROTOR_POS + 1), ld)[i], s, la, f);
+#pragma unroll
+    for (int k = 0; k < 17; ++k) field(state, k, ld)[i] = s[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) field(state, (RQ_S_LAST_ACTION + k), ld)[i] = la[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) field(state, (RQ_S_FORCE + k), ld)[i] = f[k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) field(hidden, j, ld)[i] = weights[OFF_H0 + j];
+    st.episode[i] = ep + 1;
+    st.frozen[i] = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, float v, uint32_t count) {
@@ -536,9 +579,9 @@ hipError_t launch_sample_params(hipStream_t s, Batch b, SampleCfg c, uint64_t se
 }
 
 hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params,
-                               float* state, uint32_t* episode, uint8_t* frozen) {
+                               float* state, StatsPtrs st) {
     if (b.n == 0) return hipSuccess;
-    k_sample_state<<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, seed, params, state, episode, frozen);
+    k_sample_state<<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, seed, params, state, st);
     return hipGetLastError();
 }
 
@@ -621,6 +664,13 @@ hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, c
     else
         k_step<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
                                                                sc, seed, hidden, weights, mb);
+    return hipGetLastError();
+}
+
+hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params, float* state,
+                              StatsPtrs st, float* hidden, const float* weights) {
+    if (b.n == 0) return hipSuccess;
+    k_thaw_frozen<<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, seed, params, state, st, hidden, weights);
     return hipGetLastError();
 }
 

@@ -85,9 +85,10 @@ struct Mailbox {
 
 // vector.sample_initial_parameters (README.md:60)
 hipError_t launch_sample_params(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, uint32_t epoch, float* params);
-// vector.sample_initial_state (README.md:61): uses episode[i] as the RNG counter, increments it, unfreezes
+// vector.sample_initial_state (README.md:61): uses episode[i] as the RNG counter, increments it, unfreezes the
+// env and starts its running return / step count at zero (a new episode begins)
 hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params,
-                               float* state, uint32_t* episode, uint8_t* frozen);
+                               float* state, StatsPtrs st);
 // vector.observe (README.md:96): obs [RQ_OBSERVATION_DIM][ld]
 // epoch used = epoch + (epoch_base ? *epoch_base : 0): epoch_base is a device counter for launches
 // replayed from a hipGraph (see rq_rollout, chained mode)
@@ -118,6 +119,10 @@ hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t
 hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
                        float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
                        SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb = Mailbox{});
+// chained rollouts under auto-reset: envs left frozen by an earlier rollout start their next episode
+// (sample_initial_state with the env's episode counter + policy state reset), as the fused kernel's prologue does
+hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params, float* state,
+                              StatsPtrs st, float* hidden, const float* weights);
 // the loop body README.md:95-99 x n_steps in one launch
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,

@@ -601,17 +601,41 @@ def _well_conditioned(w, weights, steps, flags, threads=8):
     return Sp, stp
 
 
-def _closed_loop_agreement(w, weights, steps, flags):
+_FRACTIONS = []
+
+
+def _report_fractions(w, steps, flags, same_history, insensitive, same_history_of_insensitive):
+    """The measured fractions behind the long-horizon bars: printed (pytest -s) and, on the GPU box, collected in
+    gpurun_out/closed_loop_fractions.json so that the thresholds can be checked against what was measured."""
+    import json
+    rec = dict(n=int(w.n), seed=int(w.seed), steps=int(steps), autoreset=int(flags),
+               domain_randomization=int(w.cfg.domain_randomization), same_history=round(float(same_history), 4),
+               insensitive=round(float(insensitive), 4),
+               same_history_of_insensitive=round(float(same_history_of_insensitive), 4))
+    _FRACTIONS.append(rec)
+    print("closed-loop fractions:", rec)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out):
+            json.dump(_FRACTIONS, open(os.path.join(out, "closed_loop_fractions.json"), "w"), indent=1)
+    except OSError:
+        pass
+
+
+def _closed_loop_agreement(w, weights, steps, flags, min_same_history=0.99, min_insensitive=0.80):
     S0 = w.S.copy()
     Sp, stp = _well_conditioned(w, weights, steps, flags)
     w.O.rollout(w.cfg, weights, w.seed, 0, w.offset, w.P, w.S, w.H, steps, flags, w.st, 8)
     S = w.state.numpy()
     g_cnt, g_len, g_term = w.env.finished_counts(), w.env.finished_lengths(), w.env.finished_terminated()
     same_history = (g_cnt == w.st.fin_counts) & (g_len == w.st.fin_lengths) & (g_term == w.st.fin_terminated)
-    assert same_history.mean() > 0.97, same_history.mean()
     insensitive = (np.abs(Sp[:, :13] - w.S[:, :13]).max(axis=1) < 1e-5) & \
                   (stp.fin_counts == w.st.fin_counts) & (stp.fin_lengths == w.st.fin_lengths)
-    assert insensitive.mean() > 0.7, insensitive.mean()
+    _report_fractions(w, steps, flags, same_history.mean(), insensitive.mean(), same_history[insensitive].mean())
+    # thresholds sit just under the fractions measured on the MI355X (profiles/r02_closed_loop_fractions.json:
+    # 500 steps: same history 0.996-1.0, insensitive 0.83 with domain randomisation, 0.875 without)
+    assert same_history.mean() >= min_same_history, same_history.mean()
+    assert insensitive.mean() >= min_insensitive, insensitive.mean()
     sel = insensitive & same_history
     # the 1-ulp-of-x probe is a proxy for sensitivity to the actor's ulps: allow 1 % escapes
     assert same_history[insensitive].mean() > 0.99
@@ -642,7 +666,7 @@ def test_rollout_autoreset_vs_oracle(device, oracle, weights):
     w = World(device, oracle, 256, seed=12, episode_step_limit=60)
     w.sync_oracle_to_gpu_state()
     w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 200, "fused", True)
-    sel = _closed_loop_agreement(w, weights, 200, 1)
+    sel = _closed_loop_agreement(w, weights, 200, 1, min_same_history=0.99, min_insensitive=0.97)   # measured 1.0 / 1.0
     assert np.array_equal(w.env.episode_steps()[sel], w.st.steps[sel])
 
 
@@ -703,6 +727,37 @@ def test_trajectory_fused_equals_chained(device, oracle, autoreset):
         assert ((A["done"] == 1) | (A["done"] == 2)).sum() == 200
     with pytest.raises(Exception):                   # capacity exhausted
         a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 1, "fused", autoreset, trajectory=ta)
+
+
+def test_autoreset_after_a_freezing_rollout_thaws_frozen_envs(device, oracle, weights):
+    """A rollout WITHOUT auto-reset leaves envs frozen; a later rollout WITH auto-reset must start their next
+    episode (re-sampled state, policy state reset) before its first step - in the fused kernel's prologue and in
+    the chained mode's thaw launch alike - and record real transitions for them (never done code 4).  Both modes
+    bit for bit, and against the oracle's recorded rollout of the same history."""
+    kw = dict(seed=21, episode_step_limit=25, noise_position=0.01)
+    a, b = World(device, oracle, 300, **kw), World(device, oracle, 300, **kw)
+    a.sync_oracle_to_gpu_state()
+    for w, mode in ((a, "fused"), (b, "chained")):
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 40, mode, False)
+        assert w.env.frozen().all()                  # every episode ended within 25 steps
+    ta, tb = a.vector.Trajectory(a.env, 30), b.vector.Trajectory(b.env, 30)
+    a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 30, "fused", True, trajectory=ta)
+    b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 30, "chained", True, trajectory=tb)
+    A, B = ta.numpy(), tb.numpy()
+    assert (A["done"] != 4).all() and np.array_equal(A["done"], B["done"])
+    for k in ("obs", "act", "rew"):
+        assert np.array_equal(A[k], B[k]), k
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(300), b.policy.hidden_state(300))
+    assert not a.env.frozen().any() and not b.env.frozen().any()
+    assert np.array_equal(a.env.episode_index(), b.env.episode_index()) and (a.env.episode_index() >= 2).all()
+    # the oracle through the same history: its first recorded observation is the thawed (re-sampled) state
+    oracle.rollout(a.cfg, weights, 21, 0, 0, a.P, a.S, a.H, 40, 0, a.st, 4)
+    assert a.st.frozen.all()
+    ref = oracle.rollout_record(a.cfg, weights, 21, 40, 0, a.P, a.S, a.H, 30, 1, a.st, 4)
+    assert np.array_equal(ref["done"][0], A["done"][0])
+    assert np.abs(A["obs"][0][:, :3] - ref["obs"][0][:, :3]).max() <= 0.011 * 6      # position + N(0, 0.01) noise
+    assert np.array_equal(a.env.episode_index(), a.st.episode)
 
 
 def test_trajectory_vs_oracle(device, oracle, weights):
