@@ -557,6 +557,26 @@ __device__ __forceinline__ void gru_gates_q(const f32x4& gr, const f32x4& gz, co
     }
 }
 
+// The same update for the f32 operand image, whose gate rows are PRE-SCALED (r, z rows by -log2 e, n rows by
+// -2 log2 e: pack_policy) and whose pre-scaled biases enter through the C operand of each chain's first MFMA
+// (a loop-invariant register quad, no copy): the accumulators ARE the exp2 arguments.
+//   r = 1 / (1 + 2^gr), z = 1 / (1 + 2^gz), n = 2 / (1 + 2^(gni + r gnh)) - 1, h <- n + z (h - n)
+// 12 transcendental + 7 packed instructions per row pair instead of 12 + 11.
+__device__ __forceinline__ void gru_gates_prescaled(const f32x4& gr, const f32x4& gz, const f32x4& gni, const f32x4& gnh,
+                                                    float (&h)[4]) {
+    const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const f32x2 rr = pk_rcp(one + pk_exp2(f32x2{gr[r], gr[r + 1]}));
+        const f32x2 zz = pk_rcp(one + pk_exp2(f32x2{gz[r], gz[r + 1]}));
+        const f32x2 arg = pk_fma(rr, f32x2{gnh[r], gnh[r + 1]}, f32x2{gni[r], gni[r + 1]});
+        const f32x2 nn = pk_fma(two, pk_rcp(one + pk_exp2(arg)), -one);
+        const f32x2 hn = pk_fma(zz, f32x2{h[r], h[r + 1]} - nn, nn);
+        h[r] = hn[0];
+        h[r + 1] = hn[1];
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -624,12 +644,16 @@ struct ActorF32T {
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TP) {
             f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];
+            const f32x4 cbr = {W[QW_BR], W[QW_BR + 1], W[QW_BR + 2], W[QW_BR + 3]};
+            const f32x4 cbz = {W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]};
+            const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
+            const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
 #pragma unroll
             for (int u = 0; u < TP; ++u) {
-                gr[u] = mfma16(W[QW_GI + 0], y0[t0 + u][0], zero);
-                gz[u] = mfma16(W[QW_GI + 4], y0[t0 + u][0], zero);
-                gni[u] = mfma16(W[QW_GI + 8], y0[t0 + u][0], zero);
-                gnh[u] = mfma16(W[QW_GH + 8], hQ[t0 + u][0], zero);
+                gr[u] = mfma16(W[QW_GI + 0], y0[t0 + u][0], cbr);
+                gz[u] = mfma16(W[QW_GI + 4], y0[t0 + u][0], cbz);
+                gni[u] = mfma16(W[QW_GI + 8], y0[t0 + u][0], cbni);
+                gnh[u] = mfma16(W[QW_GH + 8], hQ[t0 + u][0], cbnh);
             }
 #pragma unroll
             for (int s = 1; s < 4; ++s)
@@ -648,12 +672,12 @@ struct ActorF32T {
                     gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
                 }
 #pragma unroll
-            for (int u = 0; u < TP; ++u)
-                gru_gates_q(gr[u], gz[u], gni[u], gnh[u], &W[QW_BR], &W[QW_BZ], &W[QW_BNI], &W[QW_BNH], hQ[t0 + u]);
+            for (int u = 0; u < TP; ++u) gru_gates_prescaled(gr[u], gz[u], gni[u], gnh[u], hQ[t0 + u]);
             if (LEAN) __builtin_amdgcn_sched_barrier(0);   // keep the two passes apart (register footprint)
         }
         // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
-        f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], zero);
+        const f32x4 cb2 = {W[QW_B2], W[QW_B2 + 1], W[QW_B2 + 2], W[QW_B2 + 3]};
+        f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], cb2);
         f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
         d0 = mfma16(W[QW_L2 + 8], hQ[2][0], d0);
         d1 = mfma16(W[QW_L2 + 12], hQ[3][0], d1);
@@ -665,7 +689,7 @@ struct ActorF32T {
             d1 = mfma16(W[QW_L2 + 12 + s], hQ[3][s], d1);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + W[QW_B2 + r];
+        for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
     }
 };
 

@@ -19,14 +19,17 @@ void pack_policy(const float* w, float* packed) {
             const int f = 4 * s + q;     // input feature of k-slot q in K-step s
             img(QW_L0 + s) = f < 22 ? w[W0 + j * 22 + f] : (f == 22 ? w[B0 + j] : 0.0f);
         }
+        // gate rows pre-scaled so that the MFMA accumulators are the exp2 arguments of the gates
+        // (gru_gates_prescaled): r and z rows by -log2 e, n rows by -2 log2 e; the biases below likewise
+        const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
         for (int m = 0; m < 3; ++m)
             for (int s = 0; s < 4; ++s) {
-                img(QW_GI + 4 * m + s) = w[WI + (16 * m + j) * 16 + 4 * q + s];
-                img(QW_GH + 4 * m + s) = w[WH + (16 * m + j) * 16 + 4 * q + s];
+                const float k = m < 2 ? kS : kT;
+                img(QW_GI + 4 * m + s) = k * w[WI + (16 * m + j) * 16 + 4 * q + s];
+                img(QW_GH + 4 * m + s) = k * w[WH + (16 * m + j) * 16 + 4 * q + s];
             }
         for (int t = 0; t < 4; ++t)
             for (int s = 0; s < 4; ++s) img(QW_L2 + 4 * t + s) = ((j >> 2) == t) ? w[W2 + (j & 3) * 16 + 4 * q + s] : 0.0f;
-        const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
         for (int r = 0; r < 4; ++r) {
             img(QW_BR + r) = kS * (w[BI + 4 * q + r] + w[BH + 4 * q + r]);
             img(QW_BZ + r) = kS * (w[BI + 16 + 4 * q + r] + w[BH + 16 + 4 * q + r]);
