@@ -14,7 +14,17 @@ Multi-GPU is weak scaling: each rank owns 65 536 envs (global ids rank*65536 ...
 collective, one all-gather of episode returns per 500-step episode (RCCL over xGMI), enqueued behind
 the rollout that produced them and overlapped with the next one.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Timing: after exactly --warmup untimed steps, the timed region - exactly --steps steps (one fused launch
+per <= 500 of them + one exchange each), bracketed by barrier + synchronize on both sides - is REPEATED
+(at least 5 times and until 0.25 s of timed regions have accumulated, at most 2000) and the MEDIAN region
+defines `ms_per_step` and `value` (max over ranks per region); every region is timed and `timing` reports
+first / min / median / max.  A short region (the driver's --steps 20 is one 70 us launch) is bound by launch
+overhead and by the clock ramp of the first ~20 ms; `steady_state` therefore adds 10 back-to-back 500-step
+launches measured in the same run, so that the record carries the steady-state figure too.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  timing        repetitions and the spread of the timed regions
+  steady_state  10 x 500-step launches back to back: env-steps/s, us/step, fraction of the fp32 peak
   roofline      dominant kernel of the timed region (the fused rollout kernel)
   cpu_baseline  the oracle's C restatement timed on this box's host cores (a reported
                 baseline, not the target)
@@ -36,14 +46,14 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 65536
 EPISODE = 500
-MIN_UNTIMED_STEPS = 5000     # clock ramp, see main()
+MIN_REPETITIONS, MAX_REPETITIONS, MIN_TIMED_SECONDS = 5, 2000, 0.25
 
 # ---- algorithmic work per env-step (DESIGN.md "Work per env-step") ---------------------------
-# actor: 2*(16*22 + 48*16 + 48*16 + 4*16) = 3904 FLOP + 48 gates
-#        (sigmoid/tanh ~5 ops each) = 240
-# env:   4 dynamics evaluations x 110 + RK4 combination 204 + set-points/normalise/clamp 37 +
-#        reward/termination 70 + observation 30 = 781
-FLOP_ACTOR, FLOP_GATES, FLOP_ENV = 3904, 240, 781
+# actor: 2*(16*22 + 48*16 + 48*16 + 4*16) = 3904 FLOP + gates: per hidden element
+#        2 sigmoids (exp, add, rcp) + tanh (fma, exp, add, rcp, fma) + blend (sub, fma) = 16 -> 256
+# env:   4 dynamics evaluations x 108 + RK4 accumulation 7 x 17 fma = 238 + set-points 16 +
+#        normalise 18 + rotor clamp 8 + reward/termination 70 + observation 26 = 808
+FLOP_ACTOR, FLOP_GATES, FLOP_ENV = 3904, 256, 808
 FLOP_PER_ENV_STEP = FLOP_ACTOR + FLOP_GATES + FLOP_ENV
 # bytes per env per launch of the API-granular kernels (float32 fields actually touched)
 BYTES_OBSERVE = 4 * (17 + 4 + 2) + 4 * 26                      # read state+action history+2 params, write obs
@@ -93,10 +103,12 @@ class Shard:
                             autoreset=True)
 
 
-def pmc_traffic(kernel, grid, also=""):
-    """HBM bytes per launch of the kernel whose profiled name starts with `kernel` (and contains `also`)
-    from the committed rocprofv3 PMC summary (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE
-    passes of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).
+def pmc_traffic(kernel, grid):
+    """HBM bytes per launch of EXACTLY the kernel instantiation `kernel` (profiled name without its argument
+    list, e.g. "rq::k_rollout_fused<false, true, false, rq::ActorF32T<false> >") at grid size `grid`, from the
+    newest committed rocprofv3 PMC summary that has it (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; the
+    median over that kernel's launches, so the handful of warm-up launches of another length do not count).
     None when no profile covers it."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
@@ -104,12 +116,21 @@ def pmc_traffic(kernel, grid, also=""):
             table = json.load(open(path))
         except Exception:
             continue
-        for key, d in sorted(table.items()):
-            name, _, g = key.rpartition("@")
-            if g == str(grid) and name.startswith(kernel) and also in name and d.get("hbm_bytes_per_launch_corrected"):
-                return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path),
-                        "kernel": name}
+        d = table.get(f"{kernel}@{grid}")
+        if d and d.get("hbm_bytes_per_launch_corrected"):
+            return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path),
+                    "kernel": kernel, "profiled_launch_us": d.get("median_dur_us", d.get("avg_dur_us_fetch")),
+                    "profiled_launches": d.get("calls_fetch")}
     return None
+
+
+def fused_kernel_name(precision, n, steps_per_launch):
+    """The instantiation launch_rollout_fused picks (raptor_amd/csrc/rq_kernels.hip), as rocprofv3 prints it."""
+    if precision == "bf16":
+        actor = "rq::ActorBF16Lean" if n > 65536 else "rq::ActorBF16"
+    else:
+        actor = "rq::ActorF32T<true> " if (n > 65536 or steps_per_launch >= 48) else "rq::ActorF32T<false> "
+    return f"rq::k_rollout_fused<false, true, false, {actor}>"
 
 
 def sq_profile(precision):
@@ -162,12 +183,23 @@ def kernel_probe(device, n, reps):
     ):
         us = timed(fn)
         gbps = nbytes * n / (us * 1e-6) / 1e9
-        tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": "rq::k_actor_step",
+        tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": "rq::k_actor_step<rq::ActorF32T<true> >",
                           "k_step": "rq::k_step<false>"}[name], n)
         out[name] = {"bound": "hbm", "us_per_launch": round(us, 3), "bytes_per_env": nbytes,
                      "achieved_GBps": round(gbps, 1), "peak_GBps": PEAK_HBM_GBPS,
                      "frac": round(gbps / PEAK_HBM_GBPS, 4),
                      "traffic": None if tr is None else tr["bytes_per_launch"]}
+    # What a standalone launch of this size can reach at all: back-to-back launches of a kernel that only stores
+    # one float per thread on the same grid take `floor` us each (rq_device_launch_floor, HIP events), and the
+    # bytes cannot arrive faster than the measured copy ceiling (6.29 TB/s, MI355X_MICROARCH.md) - so a launch
+    # takes >= floor + bytes / ceiling, which caps its fraction of the 8 TB/s spec well below 1 for small batches.
+    floor_us = device.launch_floor(n, 200)
+    for name in ("k_observe", "k_actor_step", "k_step"):
+        nb = out[name]["bytes_per_env"] * n
+        t_min = floor_us + nb / 6.29e12 * 1e6
+        out[name]["structural_bound"] = {"near_empty_launch_us": round(floor_us, 3), "copy_ceiling_GBps": 6290.0,
+                                         "min_launch_us": round(t_min, 3),
+                                         "max_frac_of_peak": round(nb / (t_min * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4)}
     return out
 
 
@@ -342,33 +374,76 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # ---- warm-up (untimed) ----
-    # The GPU needs ~20 ms of load to reach its steady clocks and loses them again after ~5 ms of idling
-    # (measured: 500-step launches take 1.87 ms back to back, 2.08 ms after a 20 ms pause, ramping back over
-    # ~15 ms).  So (1) a short --warmup is topped up to MIN_UNTIMED_STEPS of the same rollout, and (2) the
-    # one-off costs of the exchange (RCCL communicator creation, first barrier) are paid BEFORE the warm-up
-    # rollouts, so that only a warm, sub-millisecond barrier separates them from the timed region.
-    run([1])
-    exchange.finish()
-    sync_all()
-    untimed = max(args.warmup, MIN_UNTIMED_STEPS)
-    run(chunks(untimed, EPISODE))
-    exchange.finish()
+    def timed_region(plan):
+        """exactly sum(plan) steps between barrier + synchronize on both sides -> (wall s, ms of the region's LAST
+        rollout launch).  Fused mode: that launch's own begin/end timestamps (rq_device_last_rollout_ms, the figure
+        rocprofv3 prints per dispatch); chained mode: HIP events around the whole region divided by its steps."""
+        sync_all()
+        t0 = time.perf_counter()
+        if args.mode != "fused":
+            device.timer_start()
+        run(plan)
+        launch_ms = device.timer_stop() / sum(plan) if args.mode != "fused" else None   # chained: ms per step
+        exchange.finish()
+        sync_all()
+        wall = time.perf_counter() - t0
+        if launch_ms is None:
+            launch_ms = device.last_rollout_ms()     # after the clock is stopped: the event query is not timed
+        return wall, launch_ms
 
-    # ---- timed region: exactly --steps steps (and one exchange per chunk of <= 500 of them) ----
-    plan = chunks(args.steps, EPISODE)
-    sync_all()
-    t0 = time.perf_counter()
-    device.timer_start()
-    run(plan)
-    kernel_ms = device.timer_stop()          # HIP events on the kernels' stream (also drains it)
+    # ---- warm-up: one-off costs first (RCCL communicator, first barrier, lazy allocations), then EXACTLY
+    # --warmup untimed steps of the same rollout ----
+    run([1])
     gathered = exchange.finish()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if args.warmup > 0:
+        run(chunks(args.warmup, EPISODE))
+        exchange.finish()
+
+    # ---- timed regions: each exactly --steps steps; repeated, the median counts (module docstring) ----
+    plan = chunks(args.steps, EPISODE)
+    walls, kernels = [], []
+    while True:
+        w_s, k_ms = timed_region(plan)
+        walls.append(w_s)
+        kernels.append(k_ms)
+        total = sum(walls)
+        if dist is not None:      # every rank must take the same decision: the slowest rank's clock decides
+            t = torch.tensor([total], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            total = float(t.item())
+        if len(walls) >= MAX_REPETITIONS or (len(walls) >= MIN_REPETITIONS and total >= MIN_TIMED_SECONDS):
+            break
+    if dist is not None:          # max over ranks, region by region
+        t = torch.tensor(walls, dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        walls = t.tolist()
+    elapsed = float(np.median(walls))
+    launch_ms = float(np.median(kernels))         # median over the regions of one rollout launch's duration
+
+    # ---- steady state: 10 x 500-step launches back to back (clocks are warm now), one region ----
+    steady = None
+    if args.mode == "fused":
+        ss_plan = [EPISODE] * 10
+        run(ss_plan)                              # untimed: 17 ms of load, the clocks reach their steady state
+        ss_wall, ss_launch_ms = timed_region(ss_plan)
+        ss_kernel_ms = ss_launch_ms * len(ss_plan)
+        if dist is not None:
+            t = torch.tensor([ss_wall], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ss_wall = float(t.item())
+        ss_steps = sum(ss_plan)
+        ss_flops = (FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV) * n * ss_steps / (ss_kernel_ms * 1e-3) / 1e12
+        steady = {"launches": len(ss_plan), "steps_per_launch": EPISODE,
+                  "env_steps_per_s": round(n_total * ss_steps / ss_wall, 1),
+                  "us_per_step_wall": round(ss_wall / ss_steps * 1e6, 4),
+                  "us_per_step_kernel": round(ss_kernel_ms / ss_steps * 1e3, 4),
+                  "avg_launch_ms": round(ss_kernel_ms / len(ss_plan), 4),
+                  "kernel": fused_kernel_name(args.precision, n, EPISODE),
+                  "achieved_TFLOPs": round(ss_flops, 3), "peak_TFLOPs": PEAK_FP32_TFLOPS,
+                  "frac": round(ss_flops / PEAK_FP32_TFLOPS, 4),
+                  "note": "same process, after the timed regions and 10 untimed launches of the same kind; wall = barrier + synchronize on both sides, "
+                          "max over ranks; kernel = begin/end timestamps of the last of the 10 launches on rank 0"}
 
     value = n_total * args.steps / elapsed
     result = {
@@ -383,50 +458,62 @@ def main():
                    "envs_per_gpu": n, "total_envs": n_total, "episode_length": EPISODE,
                    "parallelism": f"env-sharded x{world}, all-gather of returns per episode" if world > 1
                                   else "single GPU", "mode": args.mode,
-                   "untimed_steps_before_timing": untimed,
                    "device": torch.cuda.get_device_name(local_rank), "hip_runtime": torch.version.hip},
+        "timing": {"repetitions": len(walls), "steps_per_region": args.steps, "statistic": "median",
+                   "region_ms": {"first": round(walls[0] * 1e3, 4), "min": round(min(walls) * 1e3, 4),
+                                 "median": round(elapsed * 1e3, 4), "max": round(max(walls) * 1e3, 4)},
+                   "untimed_steps_before_first_region": args.warmup + 1},
     }
+    if steady is not None:
+        result["steady_state"] = steady
 
     if rank == 0:
         launches = len(plan) if args.mode == "fused" else 3 * args.steps
-        avg_launch_s = kernel_ms * 1e-3 / len(plan)      # per rollout call
+        avg_launch_s = launch_ms * 1e-3                  # one rollout launch (median over the timed regions)
         if args.mode == "fused" and args.precision == "bf16":
             # config 5: the contractions run on the bf16 XDL pipe (24 MFMAs per wave-step, a few % of its
             # peak); what bounds the kernel is the fp32 VALU work that remains (gates + env)
             steps_per_launch = args.steps / len(plan)
             valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
             mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
-            tr = pmc_traffic("rq::k_rollout_fused<false, true, false", n, "BF16")
+            kname = fused_kernel_name("bf16", n, steps_per_launch)
+            tr = pmc_traffic(kname, n)
             result["roofline"] = {
-                "kernel": "k_rollout_fused<ActorBF16>", "bound": "mfma", "achieved": round(valu, 3),
+                "kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
                 "traffic": None if tr is None else tr["bytes_per_launch"],
+                "traffic_source": tr,
                 "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
                         f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the bf16 MFMA pipe at "
                         f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak",
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches, "sq_counters": sq_profile("bf16")}
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
+                "steps_per_launch": steps_per_launch, "sq_counters": sq_profile("bf16")}
         elif args.mode == "fused":
             steps_per_launch = args.steps / len(plan)
             flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
             achieved = flop_per_launch / avg_launch_s / 1e12
-            tr = pmc_traffic("rq::k_rollout_fused<false, true, false", n, "F32")
+            kname = fused_kernel_name("fp32", n, steps_per_launch)
+            tr = pmc_traffic(kname, n)
             result["roofline"] = {
-                "kernel": "k_rollout_fused", "bound": "mfma", "achieved": round(achieved, 3),
+                "kernel": kname, "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                 "traffic": None if tr is None else tr["bytes_per_launch"],
-                "traffic_source": None if tr is None else tr["source"],
+                "traffic_source": tr,
                 "note": "compute-bound: state, hidden and constants stay in VGPRs for the whole launch; "
                         f"algorithmic {FLOP_PER_ENV_STEP} FLOP/env-step (actor {FLOP_ACTOR} + gates {FLOP_GATES} + "
                         f"env {FLOP_ENV}) against the fp32 vector = f32-MFMA dense peak; algorithmic HBM bytes are "
                         f"{BYTES_FUSED_LAUNCH} B/env per launch of {int(steps_per_launch)} steps; the measured `traffic` adds "
-                        "the 17.9 KB operand image every wave loads and ~700 B/env of loop-invariant registers the "
-                        "256-register build parks in scratch before the loop - about 3 B per env-step, HBM idle",
+                        "the operand image every wave loads and the loop-invariant registers parked in scratch before "
+                        "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own begin/end "
+                        "timestamps (last launch of a region, median over the regions); short launches carry the "
+                        "kernel's prologue and epilogue (see steady_state for 500-step launches)",
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
+                "steps_per_launch": steps_per_launch,
                 "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
                 "sq_counters": sq_profile("fp32")}
         else:
             bytes_per_step = (BYTES_OBSERVE + BYTES_ACTOR + BYTES_STEP) * n
-            achieved = bytes_per_step * args.steps / (kernel_ms * 1e-3) / 1e9
+            achieved = bytes_per_step / (launch_ms * 1e-3) / 1e9       # one step = three launches
             result["roofline"] = {
                 "kernel": "k_observe+k_actor_step+k_step (chain)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
@@ -440,7 +527,7 @@ def main():
             result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        result["config"]["exchanges_in_timed_region"] = len(plan)
+        result["config"]["exchanges_per_timed_region"] = len(plan)
         result["config"]["gathered_returns"] = int(gathered.numel())
         print(json.dumps(result), flush=True)
 

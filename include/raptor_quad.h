@@ -170,6 +170,14 @@ RQ_API int rq_device_synchronize(rq_device* dev);
 /* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
 RQ_API int rq_device_timer_start(rq_device* dev);
 RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
+/* Duration of the most recent FUSED rollout kernel launched on this device (rq_rollout / rq_rollout_record in
+ * RQ_ROLLOUT_FUSED mode): the kernel's own begin and end timestamps (hipExtLaunchKernel events), i.e. the figure
+ * rocprofv3 --kernel-trace prints for that dispatch.  Waits for that kernel to finish. */
+RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
+/* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
+ * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves
+ * its own data (bench.py reports it beside the API-granular kernels' HBM fractions). */
+RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, float* us_per_launch);
 /* raw hipStream_t of the device, for callers that enqueue their own work behind ours */
 RQ_API int rq_device_stream(rq_device* dev, void** hip_stream);
 

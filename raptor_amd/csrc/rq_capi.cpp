@@ -49,6 +49,8 @@ struct rq_device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_kbegin = nullptr, ev_kend = nullptr;   // begin / end of the most recent fused rollout kernel
+    bool k_timed = false;
     void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
     float* rows = nullptr;         // device scratch, row-major side of the GPU layout changes (large batches)
     size_t rows_bytes = 0;
@@ -430,6 +432,8 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     hipError_t e1 = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&d->ev_start);
     hipError_t e3 = hipEventCreate(&d->ev_stop);
+    if (e3 == hipSuccess) e3 = hipEventCreate(&d->ev_kbegin);
+    if (e3 == hipSuccess) e3 = hipEventCreate(&d->ev_kend);
     if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&d->ev_h2d, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         delete d;
@@ -446,6 +450,8 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
     if (dev->ev_h2d) (void)hipEventDestroy(dev->ev_h2d);
+    if (dev->ev_kbegin) (void)hipEventDestroy(dev->ev_kbegin);
+    if (dev->ev_kend) (void)hipEventDestroy(dev->ev_kend);
     if (dev->staging) (void)hipHostFree(dev->staging);
     if (dev->rows) (void)hipFree(dev->rows);
     if (dev->rows2) (void)hipFree(dev->rows2);
@@ -478,6 +484,31 @@ RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms) {
     RQ_HIP(hipEventRecord(dev->ev_stop, dev->stream));
     RQ_HIP(hipEventSynchronize(dev->ev_stop));
     RQ_HIP(hipEventElapsedTime(elapsed_ms, dev->ev_start, dev->ev_stop));
+    return RQ_OK;
+}
+
+RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
+    RQ_REQUIRE(dev && kernel_ms, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(dev->k_timed, RQ_ERR_NOT_INITIALIZED, "no fused rollout was launched on this device yet");
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    RQ_HIP(hipEventSynchronize(dev->ev_kend));
+    RQ_HIP(hipEventElapsedTime(kernel_ms, dev->ev_kbegin, dev->ev_kend));
+    return RQ_OK;
+}
+
+RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, float* us_per_launch) {
+    RQ_REQUIRE(dev && us_per_launch, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(n > 0 && reps > 0, RQ_ERR_INVALID_ARGUMENT, "n and reps must be positive");
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    rc = ensure_rows(dev, (size_t)n * sizeof(float)); if (rc) return rc;
+    for (int i = 0; i < 3; ++i) RQ_HIP(rq::launch_fill_f32(dev->stream, dev->rows, 0.0f, n));
+    RQ_HIP(hipEventRecord(dev->ev_start, dev->stream));
+    for (uint32_t i = 0; i < reps; ++i) RQ_HIP(rq::launch_fill_f32(dev->stream, dev->rows, 0.0f, n));
+    RQ_HIP(hipEventRecord(dev->ev_stop, dev->stream));
+    RQ_HIP(hipEventSynchronize(dev->ev_stop));
+    float ms = 0.0f;
+    RQ_HIP(hipEventElapsedTime(&ms, dev->ev_start, dev->ev_stop));
+    *us_per_launch = ms * 1e3f / (float)reps;
     return RQ_OK;
 }
 
@@ -1096,7 +1127,8 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
-                                        mode_of(policy), tp));
+                                        mode_of(policy), tp, dev->ev_kbegin, dev->ev_kend));
+        dev->k_timed = n_steps > 0;
     } else {
         // one step = observe -> evaluate_step -> step (-> record) on the stream
         auto enqueue_step = [&](uint32_t epoch, const uint32_t* epoch_base, uint32_t t_record) -> hipError_t {

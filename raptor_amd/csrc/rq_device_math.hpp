@@ -177,7 +177,10 @@ __device__ __forceinline__ void select_state(bool take, const QuadState& a, Quad
 // factor 1/2 rides in the RK4 coefficient of those two pairs (exact).
 struct Deriv { f32x2 Q1, Q2, V01, VW, Wa, R01, R23; };
 
-// 28 packed + 20 single instructions (the scalar form is 86)
+// 28 packed + 20 single instructions (the scalar form is 86).  SYM_TAU: every env of the wave has
+// tau_rise == tau_fall (the default parameter distribution), so the rise / fall selection - a select between
+// equal values - is dropped: 8 instructions less per evaluation, same result.
+template <bool SYM_TAU>
 __device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& ds, const QuadState& y,
                                          f32x2 SP01, f32x2 SP23, Deriv& d) {
     // rotor thrusts T_i = c0 + c1 r_i + c2 r_i^2, their sum and the three torques
@@ -186,7 +189,11 @@ __device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& 
     const f32x2 T23 = pk_fma(pk_fma(c2, y.R23, c1), y.R23, c0);
     const f32x2 U = T01 + T23;                         // (T0 + T2, T1 + T3)
     const f32x2 TS = lo_only(U[0] + U[1]);
-    const float tz = fmaf(k.kq, U[1] - U[0], ds.tdz);  // spin directions (-1,+1,-1,+1)
+    float tz;                                          // kq (T1 + T3 - T0 - T2) + tdz: spin directions (-1,+1,-1,+1)
+    {   // as one opaque instruction: the SLP pass otherwise pairs this fma with cz's and pays two register moves
+        const float du = U[1] - U[0];
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tz) : "v"(k.kq), "v"(du), "v"(ds.tdz));
+    }
     f32x2 TXY;                                         // (tx, ty) = TD + sum_i (y_i, -x_i) T_i
     RQ_PK_FMA(TXY, k.PYX[0], T01, ds.TD01, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
     RQ_PK_FMA(TXY, k.PYX[1], T01, TXY, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
@@ -221,10 +228,15 @@ __device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& 
     const float dwz = (tz - cz) * k.ijz;
     d.VW = f32x2{dv2, dwz};
     // first-order rotors
-    const f32x2 IT01 = {SP01[0] >= y.R01[0] ? k.itr : k.itf, SP01[1] >= y.R01[1] ? k.itr : k.itf};
-    const f32x2 IT23 = {SP23[0] >= y.R23[0] ? k.itr : k.itf, SP23[1] >= y.R23[1] ? k.itr : k.itf};
-    d.R01 = (SP01 - y.R01) * IT01;
-    d.R23 = (SP23 - y.R23) * IT23;
+    if (SYM_TAU) {
+        d.R01 = (SP01 - y.R01) * splat(k.itr);
+        d.R23 = (SP23 - y.R23) * splat(k.itr);
+    } else {
+        const f32x2 IT01 = {SP01[0] >= y.R01[0] ? k.itr : k.itf, SP01[1] >= y.R01[1] ? k.itr : k.itf};
+        const f32x2 IT23 = {SP23[0] >= y.R23[0] ? k.itr : k.itf, SP23[1] >= y.R23[1] ? k.itr : k.itf};
+        d.R01 = (SP01 - y.R01) * IT01;
+        d.R23 = (SP23 - y.R23) * IT23;
+    }
 }
 
 // o = a + c * (derivative): position advances with the velocity of the state the derivative was taken at
@@ -251,6 +263,7 @@ __device__ __forceinline__ float amax3(float a, float b, float c) {
 }
 
 // One transition, in place: y <- RK4(y, clip(a)); (AC01, AC23) = clipped action; returns reward, sets term.
+template <bool SYM_TAU>
 __device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts& k, const Disturbance& ds,
                                               QuadState& y, const float (&a)[4], f32x2& AC01, f32x2& AC23, bool& term) {
     AC01 = f32x2{clampf(a[0], -1.0f, 1.0f), clampf(a[1], -1.0f, 1.0f)};
@@ -261,16 +274,16 @@ __device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts&
     const float dt = c.dt, hdt = 0.5f * c.dt, dt6 = c.dt / 6.0f, dt3 = c.dt / 3.0f;
     Deriv d;
     QuadState acc, yt, yu;
-    dynamics(k, ds, y, SP01, SP23, d);                          // k1
+    dynamics<SYM_TAU>(k, ds, y, SP01, SP23, d);                 // k1
     rk_axpy(acc, y, dt6, 0.5f * dt6, y, d);
     rk_axpy(yt, y, hdt, 0.5f * hdt, y, d);
-    dynamics(k, ds, yt, SP01, SP23, d);                         // k2
+    dynamics<SYM_TAU>(k, ds, yt, SP01, SP23, d);                // k2
     rk_axpy(acc, acc, dt3, 0.5f * dt3, yt, d);
     rk_axpy(yu, y, hdt, 0.5f * hdt, yt, d);
-    dynamics(k, ds, yu, SP01, SP23, d);                         // k3
+    dynamics<SYM_TAU>(k, ds, yu, SP01, SP23, d);                // k3
     rk_axpy(acc, acc, dt3, 0.5f * dt3, yu, d);
     rk_axpy(yt, y, dt, 0.5f * dt, yu, d);
-    dynamics(k, ds, yt, SP01, SP23, d);                         // k4
+    dynamics<SYM_TAU>(k, ds, yt, SP01, SP23, d);                // k4
     rk_axpy(y, acc, dt6, 0.5f * dt6, yt, d);
     // quaternion back to unit length: 1/|q| from its series around |q|^2 = 1 (fmas only: rounds the same
     // on both sides; e clamped so that a non-unit quaternion handed in is pulled back, not blown up)

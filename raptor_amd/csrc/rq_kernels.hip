@@ -17,6 +17,9 @@
 //   k_soa_to_rows /      the NumPy-array side of a call at >= 1024 envs          HBM (+ PCIe copy)
 //   k_rows_to_soa        (row-major [n][dim] <-> field-major [dim][ld], LDS tile)
 // Below 1024 envs k_observe / k_actor_step / k_step exchange host rows through a pinned mailbox (Mailbox).
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
 #include "rq_device_math.hpp"
 
 namespace rq {
@@ -322,7 +325,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     Stats s = load_stats(st, i);
     const Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool term;
-    const float r = step_inplace(c, k, ds, y, a, AC01, AC23, term);
+    const float r = step_inplace<false>(c, k, ds, y, a, AC01, AC23, term);
     const bool ended = stats_update(c.episode_step_limit, r, term, s);
     st.last_reward[i] = r;
     st.last_terminated[i] = term ? 1 : 0;
@@ -436,6 +439,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     }
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool frozen = AUTORESET ? false : was_frozen;
+    // wave-uniform: no env of this wave distinguishes rotor spin-up from spin-down (see dynamics<SYM_TAU>)
+    const bool sym_tau = __builtin_amdgcn_ballot_w64(k.itr != k.itf) == 0 && !(squash & 2u);
 
     for (uint32_t t = 0; t < n_steps; ++t) {
         const uint64_t live = AUTORESET ? ~0ull : __builtin_amdgcn_ballot_w64(!frozen);
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
 #pragma unroll
             for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
         actor.step(o, hn, a);
-        if (squash) squash_action(a);        // wave-uniform (kernel argument)
+        if (squash & 1u) squash_action(a);   // wave-uniform (kernel argument)
         if (RECORD) {   // one coalesced 256-byte store per field per wave
             // buffer stores: resource = this step's block of the trajectory (base moved on the SALU), scalar
             // offset = field row, vector offset = the lane's env; no per-lane 64-bit address arithmetic and
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         QuadState yn = y;
         f32x2 A01, A23;
         bool term;
-        const float r = step_inplace(c, k, ds, yn, a, A01, A23, term);
+        const float r = sym_tau ? step_inplace<true>(c, k, ds, yn, a, A01, A23, term)
+                                : step_inplace<false>(c, k, ds, yn, a, A01, A23, term);
         bool ended = false;
         uint8_t done_code = 4;          // frozen: computed on a scratch copy, not committed
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
@@ -677,12 +683,16 @@ hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj) {
+                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj,
+                                hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
+    // hipExtLaunchKernelGGL: the two events take the kernel's own begin / end timestamps (not the stream's
+    // position when a record command is processed), which is what rq_device_last_rollout_ms reports
 #define RQ_LAUNCH_FUSED(NZ, AR, RC, ACT) \
-    k_rollout_fused<NZ, AR, RC, ACT><<<g, kFusedBlock, 0, s>>>(b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, squash)
+    hipExtLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, ACT>), dim3(g), dim3(kFusedBlock), 0, s, ev_begin, ev_end, 0, \
+                          b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, squash)
 #define RQ_LAUNCH_FUSED_RC(NZ, AR, ACT) \
     do { if (rec) RQ_LAUNCH_FUSED(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED(NZ, AR, false, ACT); } while (0)
 #define RQ_LAUNCH_FUSED_ACT(ACT)                                                          \
@@ -691,7 +701,8 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
         else       { if (ar) RQ_LAUNCH_FUSED_RC(false, true, ACT); else RQ_LAUNCH_FUSED_RC(false, false, ACT); } \
     } while (0)
     const bool rec = traj.obs != nullptr;
-    const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
+    static const uint32_t no_sym = getenv("RQ_NO_SYM_TAU") ? 2u : 0u;      // experiment switch
+    const uint32_t squash = (((uint32_t)precision >> 8) & 1u) | no_sym;
     precision &= 0xff;
     // Two builds of the same loop: a 512-register one (one wave per SIMD) and a 256-register "lean" one
     // (two waves per SIMD, GRU two tiles at a time).  Beyond 65 536 envs (1024 SIMDs x 64 lanes) the lean

@@ -127,7 +127,8 @@ hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj);
+                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj,
+                                hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // chained mode: copy step t (env obs/action buffers + last reward / done code) into the trajectory
 hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* act, StatsPtrs st, TrajPtrs traj);
 // ---- MFMA operand images of the policy (layout rationale: rq_device_math.hpp "actor") ----------

@@ -58,6 +58,18 @@ class Device:
         _lib.call("rq_device_timer_stop", self._h, C.byref(ms))
         return float(ms.value)
 
+    def last_rollout_ms(self):
+        """Duration (ms) of the most recent fused rollout kernel on this device: its own begin/end timestamps."""
+        ms = C.c_float()
+        _lib.call("rq_device_last_rollout_ms", self._h, C.byref(ms))
+        return float(ms.value)
+
+    def launch_floor(self, n, reps=200):
+        """Average us per launch of back-to-back near-empty kernels on an n-thread grid (diagnostic)."""
+        us = C.c_float()
+        _lib.call("rq_device_launch_floor", self._h, int(n), int(reps), C.byref(us))
+        return float(us.value)
+
     @property
     def stream(self):
         s = C.c_void_p()

@@ -45,7 +45,10 @@ for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                          int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["SGPR_Count"])))
     for key, v in agg.items():
         d = pmc[key]
-        d[counter + "_KiB_avg"] = sum(x[0] for x in v) / len(v)
+        # the MEDIAN launch: one kernel instantiation is launched with different step counts (the region's
+        # launches and a couple of warm-up ones); the median is the region's
+        d[counter + "_KiB_avg"] = sorted(x[0] for x in v)[len(v) // 2]
+        d["median_dur_us"] = sorted(x[1] for x in v)[len(v) // 2] / 1e3
         d["calls_" + which] = len(v)
         d["avg_dur_us_" + which] = sum(x[1] for x in v) / len(v) / 1e3
         d["vgpr"], d["agpr"], d["sgpr"] = v[0][2], v[0][3], v[0][4]
@@ -71,29 +74,32 @@ for fn in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
         shutil.copy(p, os.path.join(dst, f"{tag}_{fn}"))
 
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `python bench.py --no-cpu-baseline` (kernel trace); "
-            "PMC passes add `--steps 1000 --warmup 0`.\n\n## kernel-trace --stats\n\n")
+    cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python bench.py"
+    f.write(f"# rocprofv3 summary {tag}\n\nCommand (all three passes): `{cmd}`\n\n## kernel-trace --stats\n\n")
     f.write("| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
     for r in rows:
         f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {r['Percentage']} |\n")
-    # the dominant kernel, call by call: --stats averages every launch of the process, including the first
-    # ones at ramping clocks and the probes' launches; the timed region of bench.py is a known slice of them
+    # the dominant kernel, instantiation by instantiation, from the per-dispatch trace: --stats averages every
+    # launch of the process; bench.py launches the short-launch build for its timed regions when --steps < 48
+    # and the 256-register build for the 500-step launches of `steady_state` and of the probes
     trace = os.path.join(src, "trace", "bench_kernel_trace.csv")
     bench_json = os.path.join(src, "bench_trace.json")
     if os.path.exists(trace) and os.path.exists(bench_json):
         b = json.loads(open(bench_json).read().strip().splitlines()[-1])
-        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace))
-                if "k_rollout_fused<false, true, false" in r["Kernel_Name"]]
-        untimed = 1 + -(-b["config"]["untimed_steps_before_timing"] // 500)     # the 1-step launch + warm-up chunks
-        timed = -(-b["steps"] // 500)
-        region = durs[untimed:untimed + timed]
-        if region:
-            f.write(f"\nDominant kernel `k_rollout_fused`, launch by launch (us): first {untimed} launches are "
-                    f"untimed (1 step, then {untimed - 1} x 500 steps while the clocks ramp): "
-                    f"{', '.join(str(round(x)) for x in durs[:untimed])}; the {timed} launches of the timed region: "
-                    f"mean **{sum(region) / len(region):.1f}**, min {min(region):.0f}, max {max(region):.0f} "
-                    f"(bench.py's HIP events in the same run: {b['roofline']['avg_launch_ms'] * 1e3:.1f} per launch incl. the "
-                    f"per-chunk copy of the returns); later launches belong to the probes.\n")
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            if "k_rollout_fused" in r["Kernel_Name"]:
+                per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        f.write("\n## `k_rollout_fused`, per instantiation (us per launch, from the kernel trace)\n\n"
+                "| instantiation | launches | mean | median | min | max |\n|---|---|---|---|---|---|\n")
+        for name, d in sorted(per.items()):
+            ds = sorted(d)
+            f.write(f"| `{name}` | {len(d)} | {sum(d) / len(d):.2f} | {ds[len(ds) // 2]:.2f} | {ds[0]:.2f} | {ds[-1]:.2f} |\n")
+        rl, ss, tm = b.get("roofline", {}), b.get("steady_state", {}), b.get("timing", {})
+        f.write(f"\nbench.py in the same (profiled) run: timed regions of {b['steps']} steps x {tm.get('repetitions')} repetitions, "
+                f"`roofline.kernel` = `{rl.get('kernel')}`, `roofline.avg_launch_ms` = {rl.get('avg_launch_ms')} "
+                f"(HIP events, median region; includes the enqueue of the returns copy); `steady_state.kernel` = "
+                f"`{ss.get('kernel')}`, `steady_state.avg_launch_ms` = {ss.get('avg_launch_ms')}.\n")
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
     f.write("| kernel@grid | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|\n")
     for k, d in out.items():
