@@ -354,6 +354,31 @@ RQ_API int rq_rollout_record(rq_device* dev, rq_env* env, const rq_params* param
                       rq_policy* policy, rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags,
                       rq_trajectory* trajectory);
 
+/* ---- Teacher bank: the distillation step of the reference (README.md:208-216: ~1000 teacher policies, one per
+ * sampled quadrotor, queried on the states the student visited).  The teachers'
+ * architecture is not in the reference tree - this is rl-tools' plain MLP family [UPSTREAM-UNVERIFIED]:
+ *     input (first in_dim <= 22 recorded observation features) -> h1 -> h2 -> 4 actions,
+ * h1, h2 in {16, 32, 64}, one activation for both hidden layers and one for the output.  Every env is labelled
+ * by ITS teacher: envs are grouped by teacher id into 16-env tiles and each tile's three layers run as dense
+ * contractions on the matrix cores with that teacher's operands held in registers for the whole trajectory. */
+typedef enum rq_activation { RQ_ACT_IDENTITY = 0, RQ_ACT_RELU = 1, RQ_ACT_TANH = 2 } rq_activation;
+typedef struct rq_teacher_bank rq_teacher_bank;
+/* weights: n_teachers consecutive blocks [W1 (h1 x in_dim) | b1 (h1) | W2 (h2 x h1) | b2 (h2) | W3 (4 x h2) | b3 (4)],
+ * matrices row-major with one row per output (the layout of rl-tools dense layers, checkpoint.h:39-53).
+ * hidden_activation: RQ_ACT_RELU or RQ_ACT_TANH; output_activation: RQ_ACT_IDENTITY or RQ_ACT_TANH. */
+RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t n_teachers, uint32_t in_dim,
+                           uint32_t h1, uint32_t h2, int hidden_activation, int output_activation,
+                           rq_teacher_bank** out);
+RQ_API int rq_teacher_bank_destroy(rq_teacher_bank* bank);
+RQ_API int rq_teacher_bank_set_precision(rq_teacher_bank* bank, int precision);   /* rq_policy_precision */
+/* Actions of teacher teacher_id[i] (host array, one id per env) on every recorded step of env i.
+ * action_out: host [length, n_envs, 4] or NULL; overwrite != 0 replaces the trajectory's stored actions (what a
+ * DAgger-style learner regresses on); otherwise they stay in a device scratch block (rq_trajectory_device_ptrs is
+ * unaffected).  MLPs carry no state: done codes are not consulted, steps with code 4 get the teacher's action on
+ * whatever observation is stored there. */
+RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* bank, const uint32_t* teacher_id,
+                                   float* action_out, int overwrite);
+
 #ifdef __cplusplus
 }
 #endif

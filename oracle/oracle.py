@@ -226,5 +226,19 @@ def rollout_record(cfg, weights, seed, epoch0, env_offset, params, state, hidden
     return tr
 
 
+def teacher_relabel(weights, in_dim, h1, h2, act, out_act, obs, teacher_id, nthreads=0):
+    """MLP teachers (codes: 0 identity, 1 ReLU, 2 tanh): weights [n_teachers, P], obs [T, n, 22],
+    teacher_id [n] -> actions [T, n, 4]."""
+    w, wp = _f(weights)
+    o, op = _f(obs)
+    ids = np.ascontiguousarray(teacher_id, np.uint32)
+    T, n, _ = o.shape
+    out = np.empty((T, n, 4), np.float32)
+    lib().orc_teacher_relabel(wp, C.c_uint32(in_dim), C.c_uint32(h1), C.c_uint32(h2), C.c_int(act), C.c_int(out_act),
+                              op, _p(ids, C.c_uint32), C.c_uint32(T), C.c_uint32(n), _p(out, C.c_float),
+                              C.c_int(nthreads))
+    return out
+
+
 def max_threads():
     return int(lib().orc_max_threads())

@@ -582,6 +582,51 @@ ORC_EXPORT void orc_rollout(const rq_env_config* c, const float* w, uint64_t see
                        last_terminated, nthreads, 0, 0, 0, 0);
 }
 
+/* ---------------------------------------------------------------- MLP teachers --------- */
+/* The teacher family of raptor_quad.h "Teacher bank" (architecture [UPSTREAM-UNVERIFIED], see there):
+ * x[in] -> act(W1 x + b1)[h1] -> act(W2 . + b2)[h2] -> out_act(W3 . + b3)[4]; one block of parameters per
+ * teacher [W1 | b1 | W2 | b2 | W3 | b3], matrices row-major (out, in).  Dense: acc = b; acc = fma(W[o][k], x[k], acc)
+ * for k ascending, as orc_actor_step does.  activation codes: 0 identity, 1 ReLU, 2 tanh. */
+static float orc_act(int a, float x) { return a == 1 ? fmaxf(x, 0.0f) : (a == 2 ? tanhf(x) : x); }
+
+ORC_EXPORT void orc_teacher_forward(const float* w, uint32_t in, uint32_t h1, uint32_t h2, int act, int out_act,
+                                    const float* x, float* out) {
+    const float *W1 = w, *b1 = W1 + (size_t)h1 * in, *W2 = b1 + h1, *b2 = W2 + (size_t)h2 * h1;
+    const float *W3 = b2 + h2, *b3 = W3 + (size_t)4 * h2;
+    float y1[64], y2[64];
+    for (uint32_t o = 0; o < h1; ++o) {
+        float acc = b1[o];
+        for (uint32_t k = 0; k < in; ++k) acc = fmaf(W1[(size_t)o * in + k], x[k], acc);
+        y1[o] = orc_act(act, acc);
+    }
+    for (uint32_t o = 0; o < h2; ++o) {
+        float acc = b2[o];
+        for (uint32_t k = 0; k < h1; ++k) acc = fmaf(W2[(size_t)o * h1 + k], y1[k], acc);
+        y2[o] = orc_act(act, acc);
+    }
+    for (uint32_t o = 0; o < 4; ++o) {
+        float acc = b3[o];
+        for (uint32_t k = 0; k < h2; ++k) acc = fmaf(W3[(size_t)o * h2 + k], y2[k], acc);
+        out[o] = orc_act(out_act, acc);
+    }
+}
+
+/* obs [T][n][22] -> out [T][n][4] with teacher teacher_id[i] for env i */
+ORC_EXPORT void orc_teacher_relabel(const float* w, uint32_t in, uint32_t h1, uint32_t h2, int act, int out_act,
+                                    const float* obs, const uint32_t* teacher_id, uint32_t T, uint32_t n,
+                                    float* out, int nthreads) {
+    const size_t per = (size_t)h1 * in + h1 + (size_t)h2 * h1 + h2 + (size_t)4 * h2 + 4;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ++ii)
+        for (uint32_t t = 0; t < T; ++t) {
+            const size_t slot = (size_t)t * n + (size_t)ii;
+            orc_teacher_forward(w + per * teacher_id[ii], in, h1, h2, act, out_act, obs + slot * 22, out + slot * 4);
+        }
+}
+
 ORC_EXPORT int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

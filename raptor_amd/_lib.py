@@ -21,6 +21,7 @@ STATE_DIM = 27
 ROLLOUT_FUSED, ROLLOUT_CHAINED = 0, 1
 ROLLOUT_AUTORESET = 1
 POLICY_FP32, POLICY_BF16_MFMA = 0, 1
+ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
 
 
 class RaptorQuadError(RuntimeError):
@@ -154,6 +155,10 @@ _SIGNATURES = {
     "rq_trajectory_device_ptrs": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u32p],
     "rq_rollout_record": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32, _vp],
     "rq_trajectory_relabel": [_vp, _vp, _fp, C.c_int],
+    "rq_teacher_bank_create": [_vp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(_vp)],
+    "rq_teacher_bank_destroy": [_vp],
+    "rq_teacher_bank_set_precision": [_vp, C.c_int],
+    "rq_trajectory_relabel_teachers": [_vp, _vp, _vp, _fp, C.c_int],
 }
 _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 

@@ -23,7 +23,7 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"--offload-arch={ARCH}",
                 "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 DEVICE_FLAGS += os.environ.get("RQ_EXTRA_HIPCC_FLAGS", "").split()      # compiler-flag experiments only
-SOURCES = ["rq_kernels.hip", "rq_capi.cpp", "rq_pack.cpp"]
+SOURCES = ["rq_kernels.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_pack.cpp"]
 HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
 
 

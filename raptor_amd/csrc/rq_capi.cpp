@@ -132,6 +132,18 @@ struct rq_policy {
     float* act = nullptr;         // [4][ld]
 };
 
+struct rq_teacher_bank {
+    rq_device* dev = nullptr;
+    int ordinal = 0;
+    uint32_t n_teachers = 0, in_dim = 0, h1 = 0, h2 = 0;
+    int act = RQ_ACT_RELU, out_act = RQ_ACT_IDENTITY;
+    int precision = RQ_POLICY_FP32;
+    float* images_f32 = nullptr;     // [n_teachers][teacher_image_regs_f32 * 64]
+    float* images_bf16 = nullptr;    // [n_teachers][teacher_image_regs_bf16 * 64]
+    uint32_t* tiles = nullptr;       // device: tile_teacher [cap] followed by tile_env [cap][16]
+    uint32_t tile_capacity = 0;
+};
+
 namespace {
 
 // Every entry point runs on its rq_device's HIP device and leaves the calling thread's current device as it
@@ -1311,6 +1323,119 @@ RQ_API int rq_trajectory_relabel(rq_trajectory* t, rq_policy* pol, float* action
     }
     RQ_HIP(rq::launch_actor_relabel(dev->stream, env->n, env->ld, t->length, packed_of(pol), t->obs, t->done, pol->hidden,
                                     pol->ld, d_act, mode_of(pol)));
+    if (action_out) return traj_block_to_host(dev, d_act, t->length, env->n, env->ld, RQ_ACTION_DIM, action_out);
+    return RQ_OK;
+}
+
+// ---------------------------------------------------------------------------- Teacher bank
+RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t n_teachers, uint32_t in_dim, uint32_t h1,
+                           uint32_t h2, int hidden_activation, int output_activation, rq_teacher_bank** out) {
+    RQ_REQUIRE(dev && weights && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    RQ_REQUIRE(n_teachers > 0, RQ_ERR_INVALID_ARGUMENT, "n_teachers must be positive");
+    RQ_REQUIRE(in_dim >= 1 && in_dim <= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT,
+               "in_dim must be 1..22 (the recorded policy inputs)");
+    auto ok_width = [](uint32_t h) { return h == 16 || h == 32 || h == 64; };
+    RQ_REQUIRE(ok_width(h1) && ok_width(h2), RQ_ERR_INVALID_ARGUMENT, "hidden widths must be 16, 32 or 64");
+    RQ_REQUIRE(hidden_activation == RQ_ACT_RELU || hidden_activation == RQ_ACT_TANH, RQ_ERR_INVALID_ARGUMENT,
+               "hidden activation must be RQ_ACT_RELU or RQ_ACT_TANH");
+    RQ_REQUIRE(output_activation == RQ_ACT_IDENTITY || output_activation == RQ_ACT_TANH, RQ_ERR_INVALID_ARGUMENT,
+               "output activation must be RQ_ACT_IDENTITY or RQ_ACT_TANH");
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    rq_teacher_bank* b = new (std::nothrow) rq_teacher_bank();
+    RQ_REQUIRE(b, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    b->dev = dev; b->ordinal = dev->ordinal; b->n_teachers = n_teachers; b->in_dim = in_dim; b->h1 = h1; b->h2 = h2;
+    b->act = hidden_activation; b->out_act = output_activation;
+    const size_t per = rq::teacher_param_count((int)in_dim, (int)h1, (int)h2);
+    const size_t f32_floats = (size_t)rq::teacher_image_regs_f32((int)h1, (int)h2) * 64;
+    const size_t bf16_floats = (size_t)rq::teacher_image_regs_bf16((int)h1, (int)h2) * 64;
+    std::vector<float> img32(f32_floats * n_teachers), img16(bf16_floats * n_teachers);
+    for (uint32_t t = 0; t < n_teachers; ++t) {
+        rq::pack_teacher_f32(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img32.data() + f32_floats * t);
+        rq::pack_teacher_bf16(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img16.data() + bf16_floats * t);
+    }
+    hipError_t e1 = hipMalloc(&b->images_f32, img32.size() * sizeof(float));
+    hipError_t e2 = hipMalloc(&b->images_bf16, img16.size() * sizeof(float));
+    if (e1 == hipSuccess) e1 = hipMemcpy(b->images_f32, img32.data(), img32.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = hipMemcpy(b->images_bf16, img16.data(), img16.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        rq_teacher_bank_destroy(b);
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_teacher_bank_create: device allocation or upload failed");
+    }
+    *out = b;
+    return RQ_OK;
+}
+
+RQ_API int rq_teacher_bank_destroy(rq_teacher_bank* bank) {
+    if (!bank) return RQ_OK;
+    DeviceScope on_device(bank->ordinal);
+    if (bank->images_f32) (void)hipFree(bank->images_f32);
+    if (bank->images_bf16) (void)hipFree(bank->images_bf16);
+    if (bank->tiles) (void)hipFree(bank->tiles);
+    delete bank;
+    return RQ_OK;
+}
+
+RQ_API int rq_teacher_bank_set_precision(rq_teacher_bank* bank, int precision) {
+    RQ_REQUIRE(bank, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA, RQ_ERR_INVALID_ARGUMENT, "unknown precision");
+    bank->precision = precision;
+    return RQ_OK;
+}
+
+RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* bank, const uint32_t* teacher_id, float* action_out,
+                                   int overwrite) {
+    RQ_REQUIRE(t && bank && teacher_id, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    rq_env* env = t->env;
+    rq_device* dev = env->dev;
+    RQ_REQUIRE(bank->dev == dev, RQ_ERR_SHAPE_MISMATCH, "teacher bank lives on another device");
+    if (t->length == 0) return RQ_OK;
+    const uint32_t n = env->n;
+    // group the envs by teacher: a tile = up to 16 envs of ONE teacher (counting sort over the teacher ids, env
+    // order kept inside a teacher, so sorted inputs give contiguous tiles and coalesced rows)
+    std::vector<uint32_t> count(bank->n_teachers + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        RQ_REQUIRE(teacher_id[i] < bank->n_teachers, RQ_ERR_INVALID_ARGUMENT, "teacher id out of range");
+        ++count[teacher_id[i] + 1];
+    }
+    uint32_t n_tiles = 0;
+    for (uint32_t k = 0; k < bank->n_teachers; ++k) n_tiles += (count[k + 1] + 15u) / 16u;
+    std::vector<uint32_t> start(bank->n_teachers, 0);         // first tile of each teacher
+    {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < bank->n_teachers; ++k) { start[k] = acc; acc += (count[k + 1] + 15u) / 16u; }
+    }
+    std::vector<uint32_t> host((size_t)n_tiles * 17, 0xFFFFFFFFu);   // tile_teacher [n_tiles] | tile_env [n_tiles][16]
+    std::vector<uint32_t> filled(bank->n_teachers, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t k = teacher_id[i], pos = filled[k]++;
+        const uint32_t tile = start[k] + pos / 16u;
+        host[tile] = k;
+        host[(size_t)n_tiles + (size_t)tile * 16 + pos % 16u] = i;
+    }
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    if (bank->tile_capacity < n_tiles) {
+        RQ_HIP(hipStreamSynchronize(dev->stream));
+        if (bank->tiles) { RQ_HIP(hipFree(bank->tiles)); bank->tiles = nullptr; bank->tile_capacity = 0; }
+        RQ_HIP(hipMalloc(&bank->tiles, (size_t)n_tiles * 17 * sizeof(uint32_t)));
+        bank->tile_capacity = n_tiles;
+    }
+    RQ_HIP(hipMemcpyAsync(bank->tiles, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev->stream));
+    RQ_HIP(hipStreamSynchronize(dev->stream));                // `host` is pageable and about to go out of scope
+    const size_t act_bytes = (size_t)t->length * RQ_ACTION_DIM * env->ld * sizeof(float);
+    float* d_act = t->act;
+    if (!overwrite) {
+        if (dev->rows2_bytes < act_bytes) {
+            if (dev->rows2) { RQ_HIP(hipFree(dev->rows2)); dev->rows2 = nullptr; dev->rows2_bytes = 0; }
+            RQ_HIP(hipMalloc(&dev->rows2, act_bytes));
+            dev->rows2_bytes = act_bytes;
+        }
+        d_act = dev->rows2;
+    }
+    const float* images = bank->precision == RQ_POLICY_BF16_MFMA ? bank->images_bf16 : bank->images_f32;
+    RQ_HIP(rq::launch_teacher_relabel(dev->stream, n_tiles, env->ld, t->length, bank->in_dim, bank->h1, bank->h2, bank->act,
+                                      bank->out_act, bank->precision, images, bank->tiles, bank->tiles + n_tiles, t->obs,
+                                      d_act));
     if (action_out) return traj_block_to_host(dev, d_act, t->length, env->n, env->ld, RQ_ACTION_DIM, action_out);
     return RQ_OK;
 }

@@ -165,6 +165,26 @@ void pack_policy(const float* weights, float* packed);
 // the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
 void pack_policy_bf16(const float* weights, float* packed);
 
+// ---- teacher bank (rq_teacher.hip): per-teacher operand images, regs x 64 lanes, one dword per lane --------
+//   f32 : [H1/16][6] layer-1 A, [H2/16][H1/4] layer-2 A, [H2/4] layer-3 A, [H2/16][4] layer-2 bias, [4] layer-3 bias
+//   bf16: the A operands as bf16x8 (4 dwords each): [H1/16], [H2/16][ceil(H1/32)], [ceil(H2/32)]; biases fp32 as above
+constexpr int teacher_image_regs_f32(int h1, int h2) { return (h1 / 16) * 6 + (h2 / 16) * (h1 / 4) + h2 / 4 + (h2 / 16) * 4 + 4; }
+constexpr int teacher_image_regs_bf16(int h1, int h2) {
+    return 4 * (h1 / 16) + 4 * (h2 / 16) * ((h1 + 31) / 32) + 4 * ((h2 + 31) / 32) + (h2 / 16) * 4 + 4;
+}
+// one teacher's parameters, [W1 (h1 x in) | b1 | W2 (h2 x h1) | b2 | W3 (4 x h2) | b3], rows = outputs -> its image
+void pack_teacher_f32(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
+void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
+inline size_t teacher_param_count(int in_dim, int h1, int h2) {
+    return (size_t)h1 * in_dim + h1 + (size_t)h2 * h1 + h2 + (size_t)4 * h2 + 4;
+}
+// actions of every tile's teacher on the recorded observations obs [steps][22][ld] -> act [steps][4][ld];
+// tile_teacher [n_tiles], tile_env [n_tiles][16] (0xFFFFFFFF = padding), images = bank in the given precision
+hipError_t launch_teacher_relabel(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                  uint32_t h1, uint32_t h2, int act, int out_act, int precision, const float* images,
+                                  const uint32_t* tile_teacher, const uint32_t* tile_env, const float* obs,
+                                  float* actions);
+
 // layout changes at the boundary (device pointers): field-major [dim][ld] <-> row-major [n][dim|stride],
 // dim <= 32; rows_to_soa zeroes the padding lanes n..ld-1
 // slabs > 1: consecutive [dim][ld] blocks (the steps of a trajectory) -> consecutive [n][dim] blocks, one launch

@@ -88,5 +88,88 @@ void pack_policy_bf16(const float* w, float* packed) {
     }
 }
 
+// ---- teacher bank images (layout: rq_teacher.hip / rq_kernels.hpp) --------------------------------------
+namespace {
+struct TeacherView {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int in, h1, h2;
+    float k1, k2, k3;      // row scale: -2 log2 e where the layer's output goes through tanh, else 1
+};
+TeacherView view(const float* w, int in, int h1, int h2, int act, int out_act) {
+    TeacherView t;
+    t.in = in; t.h1 = h1; t.h2 = h2;
+    t.W1 = w; t.b1 = t.W1 + (size_t)h1 * in;
+    t.W2 = t.b1 + h1; t.b2 = t.W2 + (size_t)h2 * h1;
+    t.W3 = t.b2 + h2; t.b3 = t.W3 + (size_t)4 * h2;
+    const float kT = -2.8853900817779268f;
+    t.k1 = t.k2 = act == RQ_ACT_TANH ? kT : 1.0f;
+    t.k3 = out_act == RQ_ACT_TANH ? kT : 1.0f;
+    return t;
+}
+// layer-1 operand entry: input feature f of output row `row`; feature in_dim carries the bias
+float l1(const TeacherView& t, int row, int f) {
+    return t.k1 * (f < t.in ? t.W1[(size_t)row * t.in + f] : (f == t.in ? t.b1[row] : 0.0f));
+}
+}  // namespace
+
+void pack_teacher_f32(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image) {
+    const TeacherView t = view(w, in_dim, h1, h2, act, out_act);
+    const int regs = teacher_image_regs_f32(h1, h2);
+    for (int i = 0; i < regs * 64; ++i) image[i] = 0.0f;
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, i = l & 15;
+        int v = 0;
+        auto put = [&](float x) { image[(v++) * 64 + l] = x; };
+        for (int m = 0; m < h1 / 16; ++m)
+            for (int s = 0; s < 6; ++s) put(l1(t, 16 * m + i, 4 * s + q));
+        for (int m = 0; m < h2 / 16; ++m)
+            for (int k = 0; k < h1 / 4; ++k) put(t.k2 * t.W2[(size_t)(16 * m + i) * h1 + 16 * (k / 4) + 4 * q + (k % 4)]);
+        for (int k = 0; k < h2 / 4; ++k) put(i < 4 ? t.k3 * t.W3[(size_t)i * h2 + 16 * (k / 4) + 4 * q + (k % 4)] : 0.0f);
+        for (int m = 0; m < h2 / 16; ++m)
+            for (int r = 0; r < 4; ++r) put(t.k2 * t.b2[16 * m + 4 * q + r]);
+        for (int r = 0; r < 4; ++r) put(q == 0 ? t.k3 * t.b3[r] : 0.0f);
+    }
+}
+
+void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image) {
+    const TeacherView t = view(w, in_dim, h1, h2, act, out_act);
+    const int regs = teacher_image_regs_bf16(h1, h2);
+    uint32_t* pu = reinterpret_cast<uint32_t*>(image);
+    for (int i = 0; i < regs * 64; ++i) pu[i] = 0u;
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, i = l & 15;
+        int v = 0;
+        auto put8 = [&](const float (&x)[8]) {            // one bf16x8 A operand = 4 dwords, element e in half e & 1 of dword e / 2
+            for (int e = 0; e < 8; ++e) {
+                uint32_t& d = pu[(v + e / 2) * 64 + l];
+                const uint32_t h = to_bf16_rne(x[e]);
+                d = (e & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
+            }
+            v += 4;
+        };
+        for (int m = 0; m < h1 / 16; ++m) {
+            float x[8];
+            for (int e = 0; e < 8; ++e) x[e] = e < 6 ? l1(t, 16 * m + i, 4 * e + q) : 0.0f;
+            put8(x);
+        }
+        auto unit = [&](int c, int e) { return 16 * (2 * c + e / 4) + 4 * q + (e % 4); };   // k-slot e of chunk c
+        for (int m = 0; m < h2 / 16; ++m)
+            for (int c = 0; c < (h1 + 31) / 32; ++c) {
+                float x[8];
+                for (int e = 0; e < 8; ++e) x[e] = unit(c, e) < h1 && 2 * c + e / 4 < h1 / 16 ? t.k2 * t.W2[(size_t)(16 * m + i) * h1 + unit(c, e)] : 0.0f;
+                put8(x);
+            }
+        for (int c = 0; c < (h2 + 31) / 32; ++c) {
+            float x[8];
+            for (int e = 0; e < 8; ++e) x[e] = (i < 4 && 2 * c + e / 4 < h2 / 16) ? t.k3 * t.W3[(size_t)i * h2 + unit(c, e)] : 0.0f;
+            put8(x);
+        }
+        auto putf = [&](float x) { image[(v++) * 64 + l] = x; };
+        for (int m = 0; m < h2 / 16; ++m)
+            for (int r = 0; r < 4; ++r) putf(t.k2 * t.b2[16 * m + 4 * q + r]);
+        for (int r = 0; r < 4; ++r) putf(q == 0 ? t.k3 * t.b3[r] : 0.0f);
+    }
+}
+
 }  // namespace rq
 

@@ -1,0 +1,273 @@
+// rq_teacher.hip — teacher-action relabel of a recorded trajectory with a BANK of MLP teachers
+// (the distillation step of /root/reference/README.md:208-216 evaluates ~1000
+// teacher policies, one per sampled quadrotor, on the states the student visited).
+//
+// The teachers' architecture is NOT in the reference tree (no teacher checkpoint, no source): what is built
+// here is the family rl-tools' `nn_models/mlp` describes [UPSTREAM-UNVERIFIED] - input -> H1 -> H2 -> 4 with one
+// activation for the hidden layers and one for the output - with H1, H2 in {16, 32, 64}.
+//
+// Mapping.  Every env has its own teacher, so the contraction is not one GEMM: envs are grouped by teacher on
+// the host into TILES of 16 envs of ONE teacher (rq_capi.cpp), and one wave owns one tile for all T recorded
+// steps.  That makes every layer a true dense contraction W[out x in] X[in x 16] on the matrix cores with the
+// teacher's operands register-stationary (loaded once per wave, 124 VGPRs for 22-64-64-4, amortised over T
+// steps):
+//   f32 : v_mfma_f32_16x16x4_f32 - exact fp32 (one correctly rounded fma per product), 104 MFMAs per tile-step;
+//   bf16: v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32 accumulate, 14 MFMAs per tile-step.
+// Layouts (lane l = (q = l >> 4, j = l & 15), as in the student's actor, rq_device_math.hpp):
+//   * the observation is read straight into the B-operand layout - lane (q, j) loads feature 4s + q of env j
+//     of the tile for K-step s - so the trajectory's field-major rows need no transpose at all;
+//   * D = W X leaves output unit 16m + 4q + r of env j in register r of row tile m at lane (q, j); used as the
+//     next layer's B operand with K-step (m, r), k-slot q then carries feature 16m + 4q + r and the packed A
+//     images are laid out to match (pack_teacher_*): activations never change layout;
+//   * biases: layer 1's rides in the spare K slot `in_dim` (its B operand is the constant 1), the others are
+//     the C operand of each chain's first MFMA; for tanh the rows are pre-scaled by -2 log2 e so that
+//     tanh = 2 / (1 + 2^acc) - 1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rq_kernels.hpp"
+
+namespace rq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t dwordx4 __attribute__((ext_vector_type(4)));
+
+template <int ACT>
+__device__ __forceinline__ float teacher_act(float x) {
+    if (ACT == RQ_ACT_RELU) {          // one v_max_i32 on the bit pattern (see relu() in rq_device_math.hpp)
+        const int b = __builtin_bit_cast(int, x);
+        return __builtin_bit_cast(float, b > 0 ? b : 0);
+    }
+    if (ACT == RQ_ACT_TANH)            // rows pre-scaled by -2 log2 e: x = -2 log2e * pre-activation
+        return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x)), -1.0f);
+    return x;
+}
+
+// B operand of layer 1 for this lane: feature f = 4s + q of env `e` at step t; feature in_dim is the constant 1
+// that carries the bias, anything beyond is padding.  obs is the trajectory's [T][22][ld] block.
+__device__ __forceinline__ float load_input(const float* __restrict__ obs, size_t t, uint32_t ld, uint32_t e,
+                                            uint32_t f, uint32_t in_dim) {
+    const uint32_t fc = f < in_dim ? f : 0u;
+    const float v = obs[(t * RQ_POLICY_INPUT_DIM + fc) * ld + e];
+    return f < in_dim ? v : (f == in_dim ? 1.0f : 0.0f);
+}
+
+template <int H1, int H2, int ACT, int OUT_ACT>
+__global__ __launch_bounds__(64, 2) void k_teacher_relabel_f32(uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                                               const float* __restrict__ images,
+                                                               const uint32_t* __restrict__ tile_teacher,
+                                                               const uint32_t* __restrict__ tile_env,
+                                                               const float* __restrict__ obs, float* __restrict__ act) {
+    constexpr int M1 = H1 / 16, M2 = H2 / 16, K2 = H1 / 4, K3 = H2 / 4;
+    constexpr int REGS = teacher_image_regs_f32(H1, H2);
+    const uint32_t lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const uint32_t tile = blockIdx.x;
+    // blockIdx.y = which slice of the recorded steps this wave labels (load balance: see launch_teacher_relabel)
+    const uint32_t per = (steps + gridDim.y - 1) / gridDim.y;
+    const uint32_t t_begin = blockIdx.y * per, t_end = t_begin + per < steps ? t_begin + per : steps;
+    if (t_begin >= t_end) return;                       // wave-uniform
+    const float* img = images + (size_t)tile_teacher[tile] * REGS * 64 + lane;
+    float A1[M1][6], A2[M2][K2], A3[K3];
+    f32x4 B2[M2], B3;
+    int v = 0;
+#pragma unroll
+    for (int m = 0; m < M1; ++m)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) A1[m][s] = img[(v++) * 64];
+#pragma unroll
+    for (int m = 0; m < M2; ++m)
+#pragma unroll
+        for (int k = 0; k < K2; ++k) A2[m][k] = img[(v++) * 64];
+#pragma unroll
+    for (int k = 0; k < K3; ++k) A3[k] = img[(v++) * 64];
+#pragma unroll
+    for (int m = 0; m < M2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B2[m][r] = img[(v++) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) B3[r] = img[(v++) * 64];
+
+    const uint32_t e0 = tile_env[tile * 16 + j];
+    const bool valid = e0 != 0xFFFFFFFFu;
+    const uint32_t e = valid ? e0 : 0u;                 // padding lanes shadow env 0: MFMA ignores EXEC
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float X[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) X[s] = load_input(obs, t_begin, ld, e, 4 * s + q, in_dim);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        float Xn[6];
+        const uint32_t tn = t + 1 < t_end ? t + 1 : t;   // next step's operands in flight behind this step's MFMAs
+#pragma unroll
+        for (int s = 0; s < 6; ++s) Xn[s] = load_input(obs, tn, ld, e, 4 * s + q, in_dim);
+        f32x4 y1[M1], y2[M2];
+#pragma unroll
+        for (int m = 0; m < M1; ++m) y1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[m][0], X[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 6; ++s)
+#pragma unroll
+            for (int m = 0; m < M1; ++m) y1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[m][s], X[s], y1[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < M1; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1[m][r] = teacher_act<ACT>(y1[m][r]);
+#pragma unroll
+        for (int m = 0; m < M2; ++m) y2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][0], y1[0][0], B2[m], 0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < K2; ++k)
+#pragma unroll
+            for (int m = 0; m < M2; ++m)
+                y2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][k], y1[k / 4][k % 4], y2[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < M2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2[m][r] = teacher_act<ACT>(y2[m][r]);
+        f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[0], y2[0][0], B3, 0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < K3; ++k) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[k], y2[k / 4][k % 4], o, 0, 0, 0);
+        if (valid && q == 0) {                            // rows 0..3 of the 16-row output tile are the 4 actions
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[((size_t)t * RQ_ACTION_DIM + r) * ld + e0] = teacher_act<OUT_ACT>(o[r]);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) X[s] = Xn[s];
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
+    bf16x8 v;
+    v[0] = (__bf16)f0; v[1] = (__bf16)f1; v[2] = (__bf16)f2; v[3] = (__bf16)f3;
+    v[4] = (__bf16)f4; v[5] = (__bf16)f5; v[6] = (__bf16)f6; v[7] = (__bf16)f7;
+    return v;
+}
+
+template <int H1, int H2, int ACT, int OUT_ACT>
+__global__ __launch_bounds__(64, 4) void k_teacher_relabel_bf16(uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                                                const float* __restrict__ images,
+                                                                const uint32_t* __restrict__ tile_teacher,
+                                                                const uint32_t* __restrict__ tile_env,
+                                                                const float* __restrict__ obs, float* __restrict__ act) {
+    constexpr int M1 = H1 / 16, M2 = H2 / 16, C2 = (H1 + 31) / 32, C3 = (H2 + 31) / 32;
+    constexpr int REGS = teacher_image_regs_bf16(H1, H2);
+    const uint32_t lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t per = (steps + gridDim.y - 1) / gridDim.y;
+    const uint32_t t_begin = blockIdx.y * per, t_end = t_begin + per < steps ? t_begin + per : steps;
+    if (t_begin >= t_end) return;                       // wave-uniform
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(images) + (size_t)tile_teacher[tile] * REGS * 64 + lane;
+    bf16x8 A1[M1], A2[M2][C2], A3[C3];
+    f32x4 B2[M2], B3;
+    int v = 0;
+    auto load_a = [&]() {
+        const dwordx4 u = {img[(v + 0) * 64], img[(v + 1) * 64], img[(v + 2) * 64], img[(v + 3) * 64]};
+        v += 4;
+        return __builtin_bit_cast(bf16x8, u);
+    };
+#pragma unroll
+    for (int m = 0; m < M1; ++m) A1[m] = load_a();
+#pragma unroll
+    for (int m = 0; m < M2; ++m)
+#pragma unroll
+        for (int c = 0; c < C2; ++c) A2[m][c] = load_a();
+#pragma unroll
+    for (int c = 0; c < C3; ++c) A3[c] = load_a();
+#pragma unroll
+    for (int m = 0; m < M2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B2[m][r] = __builtin_bit_cast(float, img[(v++) * 64]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) B3[r] = __builtin_bit_cast(float, img[(v++) * 64]);
+
+    const uint32_t e0 = tile_env[tile * 16 + j];
+    const bool valid = e0 != 0xFFFFFFFFu;
+    const uint32_t e = valid ? e0 : 0u;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float X[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) X[s] = load_input(obs, t_begin, ld, e, 4 * s + q, in_dim);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        float Xn[6];
+        const uint32_t tn = t + 1 < t_end ? t + 1 : t;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) Xn[s] = load_input(obs, tn, ld, e, 4 * s + q, in_dim);
+        // k-slot e of lane-group q carries feature 4e + q (e < 6), as in the student's bf16 layer_0
+        const bf16x8 xb = pack8(X[0], X[1], X[2], X[3], X[4], X[5], 0.f, 0.f);
+        f32x4 y1[M1 + 1], y2[M2 + 1];                     // one spare tile of zeros pads an odd chunk
+#pragma unroll
+        for (int m = 0; m < M1; ++m) {
+            y1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[m], xb, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1[m][r] = teacher_act<ACT>(y1[m][r]);
+        }
+        y1[M1] = zero;
+        // chunk c of the next contraction: slots e < 4 carry unit 16 (2c) + 4q + e, e >= 4 unit 16 (2c + 1) + 4q + e - 4
+        bf16x8 hb[C2];
+#pragma unroll
+        for (int c = 0; c < C2; ++c) {
+            const f32x4 a = y1[2 * c], b = y1[2 * c + 1 < M1 ? 2 * c + 1 : M1];
+            hb[c] = pack8(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+        }
+#pragma unroll
+        for (int m = 0; m < M2; ++m) {
+            y2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[m][0], hb[0], B2[m], 0, 0, 0);
+#pragma unroll
+            for (int c = 1; c < C2; ++c) y2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[m][c], hb[c], y2[m], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2[m][r] = teacher_act<ACT>(y2[m][r]);
+        }
+        y2[M2] = zero;
+        f32x4 o = B3;
+#pragma unroll
+        for (int c = 0; c < C3; ++c) {
+            const f32x4 a = y2[2 * c], b = y2[2 * c + 1 < M2 ? 2 * c + 1 : M2];
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3[c], pack8(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]), o, 0, 0, 0);
+        }
+        if (valid && q == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[((size_t)t * RQ_ACTION_DIM + r) * ld + e0] = teacher_act<OUT_ACT>(o[r]);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) X[s] = Xn[s];
+    }
+}
+
+// ---------------------------------------------------------------------------- launcher ---
+template <int H1, int H2>
+static hipError_t launch_hh(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim, int act,
+                            int out_act, int precision, const float* images, const uint32_t* tile_teacher,
+                            const uint32_t* tile_env, const float* obs, float* actions) {
+    // One wave per (tile, slice of the steps).  A wave keeps its teacher's operands in registers, so slices should
+    // be long (>= 64 steps amortise the 32 KB image load); but with few tiles, or tile counts just above a multiple
+    // of what the chip holds at once (2048 waves at 2 per SIMD), whole-trajectory waves leave SIMDs idle in the
+    // last round - slices bring the wave count to >= 8 rounds.
+    uint32_t slices = (16384u + n_tiles - 1) / n_tiles;
+    if (slices > steps / 64u) slices = steps / 64u;
+    if (slices < 1u) slices = 1u;
+    const dim3 grid(n_tiles, slices);
+#define RQ_T(KERNEL, A, O) KERNEL<H1, H2, A, O><<<grid, 64, 0, s>>>(ld, steps, in_dim, images, tile_teacher, tile_env, obs, actions)
+#define RQ_T_ACT(KERNEL)                                                                                        \
+    do {                                                                                                        \
+        if (act == RQ_ACT_RELU) { if (out_act == RQ_ACT_TANH) RQ_T(KERNEL, RQ_ACT_RELU, RQ_ACT_TANH); else RQ_T(KERNEL, RQ_ACT_RELU, RQ_ACT_IDENTITY); } \
+        else                    { if (out_act == RQ_ACT_TANH) RQ_T(KERNEL, RQ_ACT_TANH, RQ_ACT_TANH); else RQ_T(KERNEL, RQ_ACT_TANH, RQ_ACT_IDENTITY); } \
+    } while (0)
+    if (precision == RQ_POLICY_BF16_MFMA) RQ_T_ACT(k_teacher_relabel_bf16);
+    else                                  RQ_T_ACT(k_teacher_relabel_f32);
+#undef RQ_T_ACT
+#undef RQ_T
+    return hipGetLastError();
+}
+
+hipError_t launch_teacher_relabel(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                  uint32_t h1, uint32_t h2, int act, int out_act, int precision, const float* images,
+                                  const uint32_t* tile_teacher, const uint32_t* tile_env, const float* obs,
+                                  float* actions) {
+    if (n_tiles == 0 || steps == 0) return hipSuccess;
+#define RQ_T_HH(A, B) \
+    if (h1 == A && h2 == B) return launch_hh<A, B>(s, n_tiles, ld, steps, in_dim, act, out_act, precision, images, tile_teacher, tile_env, obs, actions)
+    RQ_T_HH(64, 64); RQ_T_HH(64, 32); RQ_T_HH(32, 64); RQ_T_HH(32, 32); RQ_T_HH(32, 16); RQ_T_HH(16, 32); RQ_T_HH(16, 16);
+    RQ_T_HH(64, 16); RQ_T_HH(16, 64);
+#undef RQ_T_HH
+    return hipErrorInvalidValue;
+}
+
+}  // namespace rq

@@ -393,6 +393,20 @@ class VectorModule:
                           _lib.fptr(out) if fetch else None, 1 if overwrite else 0)
                 return out
 
+            def relabel_teachers(self, bank, teacher_ids, overwrite=False, fetch=True):
+                """Actions of MLP teacher ``teacher_ids[i]`` of ``bank`` (raptor_amd.teachers.TeacherBank) on every
+                recorded step of env i, in one launch on the matrix cores -> [T, N, 4] (``fetch=False``: only on
+                the device); ``overwrite=True`` replaces the stored actions with the teachers' (the regression
+                targets of the distillation step, README.md:208-216)."""
+                T, N = len(self), mod.N_ENVIRONMENTS
+                ids = np.ascontiguousarray(teacher_ids, np.uint32)
+                if ids.shape != (N,):
+                    raise ValueError("teacher_ids must hold one id per env")
+                out = np.empty((T, N, 4), np.float32) if fetch else None
+                _lib.call("rq_trajectory_relabel_teachers", self._h, bank._h, ids.ctypes.data,
+                          _lib.fptr(out) if fetch else None, 1 if overwrite else 0)
+                return out
+
         self.Trajectory = Trajectory
         self.VectorRng = VectorRng
         self.VectorEnvironment = VectorEnvironment

@@ -1,0 +1,53 @@
+"""Teacher bank: many MLP teacher policies queried on student-visited states in one launch.
+
+The distillation step of rl-tools/raptor (/root/reference/README.md:208-216) labels the states the student
+visits with the action of the teacher that was trained for that quadrotor - about 1000 MLP teachers, one per
+sampled dynamics.  ``TeacherBank`` holds such a set on the device and ``Trajectory.relabel_teachers`` evaluates
+teacher ``teacher_ids[i]`` on every recorded step of env ``i``.  The teachers'
+architecture is not in the reference tree: this is the plain MLP family input -> h1 -> h2 -> 4
+[UPSTREAM-UNVERIFIED], h1, h2 in {16, 32, 64}.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+ACTIVATIONS = {"identity": _lib.ACT_IDENTITY, "relu": _lib.ACT_RELU, "tanh": _lib.ACT_TANH}
+PRECISIONS = {"fp32": _lib.POLICY_FP32, "bf16": _lib.POLICY_BF16_MFMA}
+
+
+def parameter_count(in_dim, h1, h2):
+    """floats per teacher: W1 [h1, in_dim], b1 [h1], W2 [h2, h1], b2 [h2], W3 [4, h2], b3 [4]"""
+    return h1 * in_dim + h1 + h2 * h1 + h2 + 4 * h2 + 4
+
+
+def flatten_teacher(W1, b1, W2, b2, W3, b3):
+    """One teacher's layers (matrices [out, in], as rl-tools dense layers store them) -> its flat block."""
+    parts = [np.asarray(a, np.float32).ravel() for a in (W1, b1, W2, b2, W3, b3)]
+    return np.concatenate(parts)
+
+
+class TeacherBank:
+    def __init__(self, device, weights, in_dim=22, h1=64, h2=64, hidden_activation="relu",
+                 output_activation="identity", precision="fp32"):
+        w = np.ascontiguousarray(weights, np.float32)
+        per = parameter_count(in_dim, h1, h2)
+        if w.ndim != 2 or w.shape[1] != per:
+            raise ValueError(f"weights must be [n_teachers, {per}] for {in_dim}-{h1}-{h2}-4")
+        self.n_teachers, self.in_dim, self.h1, self.h2 = int(w.shape[0]), int(in_dim), int(h1), int(h2)
+        self.hidden_activation, self.output_activation = hidden_activation, output_activation
+        self._device = device
+        h = C.c_void_p()
+        _lib.call("rq_teacher_bank_create", device._h, _lib.fptr(w), self.n_teachers, self.in_dim, self.h1, self.h2,
+                  ACTIVATIONS[hidden_activation], ACTIVATIONS[output_activation], C.byref(h))
+        self._h = h
+        self._fin = weakref.finalize(self, _lib.load().rq_teacher_bank_destroy, h)
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.precision = precision
+        _lib.call("rq_teacher_bank_set_precision", self._h, PRECISIONS[precision])

@@ -1176,3 +1176,69 @@ def test_closed_loop_statistics_against_the_reference_training_log_on_the_gpu(de
     share, length = w.env.finished_terminated().mean(), w.env.finished_lengths().mean()
     assert abs(share - REFERENCE_LOG["share_terminated"]) < 0.008, share
     assert abs(length - REFERENCE_LOG["episode_length"]) < 4.0, length
+
+
+# ------------------------------------------------------------------------------ teacher bank -
+def _teacher_weights(rng, n_teachers, in_dim, h1, h2):
+    from raptor_amd.teachers import parameter_count
+    W = np.empty((n_teachers, parameter_count(in_dim, h1, h2)), np.float32)
+    for t in range(n_teachers):      # He-style scales per layer so that activations stay O(1) through the net
+        parts = [rng.standard_normal(h1 * in_dim) / np.sqrt(in_dim), rng.standard_normal(h1) * 0.1,
+                 rng.standard_normal(h2 * h1) / np.sqrt(h1), rng.standard_normal(h2) * 0.1,
+                 rng.standard_normal(4 * h2) / np.sqrt(h2), rng.standard_normal(4) * 0.1]
+        W[t] = np.concatenate(parts).astype(np.float32)
+    return W
+
+
+ACT_CODE = {"identity": 0, "relu": 1, "tanh": 2}
+
+
+@pytest.mark.parametrize("h1,h2,act,out_act,in_dim", [(64, 64, "relu", "identity", 22), (64, 64, "tanh", "tanh", 22),
+                                                      (32, 16, "relu", "tanh", 18), (16, 64, "tanh", "identity", 22),
+                                                      (64, 32, "relu", "identity", 13)])
+def test_teacher_bank_relabel_vs_oracle(device, oracle, h1, h2, act, out_act, in_dim):
+    """MLP teachers on a recorded trajectory: f32 MFMA path within 1e-5 of the oracle's fma chains, bf16 path
+    within 5e-2; ragged teacher groups (sizes 1..50, not multiples of the 16-env tile), interleaved ids."""
+    from raptor_amd.teachers import TeacherBank
+    rng = np.random.default_rng(h1 * 1000 + h2)
+    n, T, n_teachers = 1000, 6, 37
+    w = World(device, oracle, n, seed=31, episode_step_limit=4)
+    tr = w.vector.Trajectory(w.env, T)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T, "fused", True, trajectory=tr)
+    rec = tr.numpy()
+    W = _teacher_weights(rng, n_teachers, in_dim, h1, h2)
+    ids = rng.integers(0, n_teachers, n).astype(np.uint32)
+    ids[:100] = np.arange(100) % 5                      # interleaved
+    bank = TeacherBank(device, W, in_dim, h1, h2, act, out_act)
+    ref = oracle.teacher_relabel(W, in_dim, h1, h2, ACT_CODE[act], ACT_CODE[out_act], rec["obs"], ids, 4)
+    got = tr.relabel_teachers(bank, ids)
+    assert np.abs(got - ref).max() < 1e-5, np.abs(got - ref).max()
+    assert np.array_equal(tr.numpy()["act"], rec["act"])          # overwrite=False leaves the recording alone
+    bank.set_precision("bf16")
+    got16 = tr.relabel_teachers(bank, ids)
+    assert np.abs(got16 - ref).max() < 5e-2, np.abs(got16 - ref).max()
+    bank.set_precision("fp32")
+    tr.relabel_teachers(bank, ids, overwrite=True, fetch=False)
+    assert np.array_equal(tr.numpy()["act"], got)                 # overwrite=True: the stored actions are the labels
+    with pytest.raises(Exception):
+        tr.relabel_teachers(bank, np.full(n, n_teachers, np.uint32))      # id out of range
+
+
+def test_teacher_bank_at_full_batch(device, oracle):
+    """65 536 envs x 64 teachers: f32 path against the oracle on every env."""
+    from raptor_amd.teachers import TeacherBank
+    rng = np.random.default_rng(77)
+    n, T, n_teachers = 65536, 4, 64
+    w = World(device, oracle, n, seed=32)
+    tr = w.vector.Trajectory(w.env, T)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T, "fused", True, trajectory=tr)
+    obs = tr.numpy()["obs"]
+    W = _teacher_weights(rng, n_teachers, 22, 64, 64)
+    ids = (np.arange(n) // 1024).astype(np.uint32)               # 1024 envs per teacher, as a learner would shard them
+    rng.shuffle(ids[:4096])                                       # and a shuffled corner
+    bank = TeacherBank(device, W, 22, 64, 64, "relu", "identity")
+    ref = oracle.teacher_relabel(W, 22, 64, 64, 1, 0, obs, ids, 8)
+    got = tr.relabel_teachers(bank, ids)
+    assert np.abs(got - ref).max() < 1e-5, np.abs(got - ref).max()
+    bank.set_precision("bf16")
+    assert np.abs(tr.relabel_teachers(bank, ids) - ref).max() < 5e-2

@@ -164,3 +164,27 @@ def test_raptor_save_checkpoint_both_formats(tmp_path):
         q = Raptor.from_checkpoint(str(tmp_path / name))
         assert np.array_equal(q._weights, p._weights)
         assert np.array_equal(q.example[0], p.example[0]) and np.array_equal(q.example[1], p.example[1])
+
+
+def test_oracle_teacher_mlp_matches_numpy(oracle):
+    """The oracle's MLP teacher (the checker of the teacher-bank kernels) against a float64 numpy evaluation."""
+    rng = np.random.default_rng(5)
+    in_dim, h1, h2, n_teachers, T, n = 22, 64, 32, 5, 3, 40
+    per = h1 * in_dim + h1 + h2 * h1 + h2 + 4 * h2 + 4
+    W = (rng.standard_normal((n_teachers, per)) * 0.3).astype(np.float32)
+    obs = rng.standard_normal((T, n, 22)).astype(np.float32)
+    ids = rng.integers(0, n_teachers, n).astype(np.uint32)
+    for act, out_act, f, g in ((1, 0, lambda x: np.maximum(x, 0), lambda x: x), (2, 2, np.tanh, np.tanh)):
+        got = oracle.teacher_relabel(W, in_dim, h1, h2, act, out_act, obs, ids)
+        for i in range(n):
+            w = W[ids[i]].astype(np.float64)
+            o = 0
+            W1 = w[o:o + h1 * in_dim].reshape(h1, in_dim); o += h1 * in_dim
+            b1 = w[o:o + h1]; o += h1
+            W2 = w[o:o + h2 * h1].reshape(h2, h1); o += h2 * h1
+            b2 = w[o:o + h2]; o += h2
+            W3 = w[o:o + 4 * h2].reshape(4, h2); o += 4 * h2
+            b3 = w[o:o + 4]
+            x = obs[:, i, :in_dim].astype(np.float64)
+            ref = g(f(f(x @ W1.T + b1) @ W2.T + b2) @ W3.T + b3)
+            assert np.abs(got[:, i] - ref).max() < 2e-5
