@@ -361,12 +361,50 @@ def main():
     # the one exchange step of the path: after every episode-length chunk the last
     # finished return of every env is all-gathered - copy enqueued on the engine's stream, collective on
     # a side stream, both overlapped with the next chunk's rollout (raptor_amd.distributed.ReturnsExchange)
-    exchange = ReturnsExchange(n, n_total, f"cuda:{local_rank}", engine_stream=device.stream)
+    # It is issued by the C++ host (rq_comm_* / rq_allgather_returns: RCCL bound by libraptor_quad.so itself);
+    # torch.distributed only ships the communicator id, provides the barriers and the max over ranks.  Should the
+    # native communicator not come up on this box, the torch-side exchange (same structure) takes over and the
+    # JSON says so.
+    exchange_kind = "native RCCL (rq_allgather_returns)"
+
+    def all_ranks_ok(ok):
+        if dist is None or world == 1:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
+    from raptor_amd.distributed import NativeReturnsExchange
+    why = ""
+    try:      # phase 1 (no collective inside): can every rank bind RCCL?  rank 0's id is the one that is used
+        ident = [NativeReturnsExchange.unique_id() if world > 1 else None]
+    except Exception as exc:      # noqa: BLE001
+        ident, why = [None], str(exc)
+    native = world > 1 and all_ranks_ok(ident[0] is not None)
+    if world == 1:
+        why = "single rank"
+    if native:
+        if dist is not None and world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        try:  # phase 2: the collective communicator creation
+            exchange = NativeReturnsExchange(device, world, rank, ident[0])
+        except Exception as exc:  # noqa: BLE001
+            exchange, why = None, str(exc)
+        native = all_ranks_ok(exchange is not None)
+    if native:
+        post = lambda: exchange.post(shard.env)                                            # noqa: E731
+        finish = lambda: exchange.finish(to_host=False)                                    # noqa: E731
+    else:
+        exchange_kind = ("none: one rank, the returns are only copied out behind each rollout" if world == 1 else
+                         f"torch.distributed all_gather_into_tensor (native communicator unavailable: {why})")
+        exchange = ReturnsExchange(n, n_total, f"cuda:{local_rank}", engine_stream=device.stream)
+        post = lambda: exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))   # noqa: E731
+        finish = exchange.finish
 
     def run(plan):
         for c in plan:
             shard.rollout(c, args.mode)
-            exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))
+            post()
 
     def sync_all():
         device.synchronize()
@@ -375,7 +413,7 @@ def main():
             dist.barrier()
 
     def timed_region(plan):
-        """exactly sum(plan) steps between barrier + synchronize on both sides -> (wall s, ms of the region's LAST
+        """exactly sum(plan) steps, barrier + synchronize before, synchronize + barrier after -> (wall s, ms of the region's LAST
         rollout launch).  Fused mode: that launch's own begin/end timestamps (rq_device_last_rollout_ms, the figure
         rocprofv3 prints per dispatch); chained mode: HIP events around the whole region divided by its steps."""
         sync_all()
@@ -384,9 +422,12 @@ def main():
             device.timer_start()
         run(plan)
         launch_ms = device.timer_stop() / sum(plan) if args.mode != "fused" else None   # chained: ms per step
-        exchange.finish()
-        sync_all()
-        wall = time.perf_counter() - t0
+        finish()
+        device.synchronize()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0              # this rank's clock stops when ITS work is done: the max over
+        if dist is not None:                         # ranks is taken afterwards, so the closing barrier is not timed
+            dist.barrier()
         if launch_ms is None:
             launch_ms = device.last_rollout_ms()     # after the clock is stopped: the event query is not timed
         return wall, launch_ms
@@ -394,11 +435,11 @@ def main():
     # ---- warm-up: one-off costs first (RCCL communicator, first barrier, lazy allocations), then EXACTLY
     # --warmup untimed steps of the same rollout ----
     run([1])
-    gathered = exchange.finish()
+    finish()
     sync_all()
     if args.warmup > 0:
         run(chunks(args.warmup, EPISODE))
-        exchange.finish()
+        finish()
 
     # ---- timed regions: each exactly --steps steps; repeated, the median counts (module docstring) ----
     plan = chunks(args.steps, EPISODE)
@@ -528,7 +569,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         result["config"]["exchanges_per_timed_region"] = len(plan)
-        result["config"]["gathered_returns"] = int(gathered.numel())
+        gathered = exchange.finish()          # numpy (native) or tensor (torch): the last all-gathered returns
+        result["config"]["gathered_returns"] = int(np.prod(gathered.shape))
+        result["config"]["exchange"] = exchange_kind
+        # RCCL / the HIP runtime print banners through C stdio, which a redirected stdout only flushes at exit:
+        # push them out now so that the JSON line is the LAST line of stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(result), flush=True)
 
     if dist is not None:

@@ -379,6 +379,30 @@ RQ_API int rq_teacher_bank_set_precision(rq_teacher_bank* bank, int precision); 
 RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* bank, const uint32_t* teacher_id,
                                    float* action_out, int overwrite);
 
+
+/* ---- Multi-GPU: the path's one exchange ---------------------------------------------
+ * Envs are independent, so a batch shards over GPUs with no data-path collective: one process per GPU, rank r
+ * owns the global env ids [r n, (r + 1) n) (rq_env_create's global_env_offset keys the RNG, results do not depend
+ * on the sharding).  What is exchanged is the per-env return of the last finished episode: an RCCL all-gather
+ * over xGMI, once per episode, in the C++ host.  Rank 0 obtains an id with rq_comm_unique_id and the host ships
+ * its RQ_COMM_ID_BYTES bytes to the other ranks (MPI, a TCP store, a file - torch.distributed in bench.py); every
+ * rank then calls rq_comm_create (a collective).  librccl is bound at run time (a copy the process already
+ * mapped, e.g. PyTorch's, is shared; RQ_RCCL_LIBRARY overrides the search). */
+#define RQ_COMM_ID_BYTES 128
+typedef struct rq_comm rq_comm;
+RQ_API int rq_comm_unique_id(void* id_out, size_t bytes);
+RQ_API int rq_comm_create(rq_device* dev, uint32_t n_ranks, uint32_t rank, const void* id, size_t bytes, rq_comm** out);
+RQ_API int rq_comm_destroy(rq_comm* comm);
+RQ_API int rq_comm_info(const rq_comm* comm, uint32_t* n_ranks, uint32_t* rank);
+/* ENQUEUE the all-gather of this rank's rq_env_get_finished_returns: the copy on the env's own stream (right
+ * behind the rollout that produced the returns), the collective on a side stream behind an event, double-
+ * buffered - it overlaps the next rollout and the host does not block.  Every rank must call it the same number
+ * of times with envs of the same size. */
+RQ_API int rq_allgather_returns(rq_env* env, rq_comm* comm);
+/* Wait for the most recently enqueued all-gather: device pointer to the [n_ranks * n_envs] result in global env
+ * order (valid until the second next rq_allgather_returns), its length, and optionally a host copy. */
+RQ_API int rq_comm_gathered(rq_comm* comm, const float** dev_ptr, uint32_t* count, float* host_out);
+
 #ifdef __cplusplus
 }
 #endif

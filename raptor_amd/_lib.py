@@ -22,6 +22,7 @@ ROLLOUT_FUSED, ROLLOUT_CHAINED = 0, 1
 ROLLOUT_AUTORESET = 1
 POLICY_FP32, POLICY_BF16_MFMA = 0, 1
 ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
+COMM_ID_BYTES = 128
 
 
 class RaptorQuadError(RuntimeError):
@@ -155,6 +156,12 @@ _SIGNATURES = {
     "rq_trajectory_device_ptrs": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u32p],
     "rq_rollout_record": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32, _vp],
     "rq_trajectory_relabel": [_vp, _vp, _fp, C.c_int],
+    "rq_comm_unique_id": [_vp, C.c_size_t],
+    "rq_comm_create": [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(_vp)],
+    "rq_comm_destroy": [_vp],
+    "rq_comm_info": [_vp, _u32p, _u32p],
+    "rq_allgather_returns": [_vp, _vp],
+    "rq_comm_gathered": [_vp, C.POINTER(_vp), _u32p, _fp],
     "rq_teacher_bank_create": [_vp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(_vp)],
     "rq_teacher_bank_destroy": [_vp],
     "rq_teacher_bank_set_precision": [_vp, C.c_int],

@@ -23,8 +23,8 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"--offload-arch={ARCH}",
                 "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 DEVICE_FLAGS += os.environ.get("RQ_EXTRA_HIPCC_FLAGS", "").split()      # compiler-flag experiments only
-SOURCES = ["rq_kernels.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_pack.cpp"]
-HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
+SOURCES = ["rq_kernels.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
+HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_host.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
 
 
 def _hipcc():
@@ -59,7 +59,7 @@ def build(force=False, verbose=False):
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in results]
     if force or any(c for _, c in results) or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -18,27 +18,24 @@
 #include "../../include/raptor_quad.h"
 #include "rq_kernels.hpp"
 
-namespace {
+#include "rq_host.hpp"
+
+namespace rq {
 
 thread_local std::string g_last_error;
+thread_local int tl_scope_depth = 0, tl_scope_device = -1;     // innermost live DeviceScope of this thread
 
 int fail(int status, const std::string& msg) {
     g_last_error = msg;
     return status;
 }
 
-#define RQ_REQUIRE(cond, status, msg)                                             \
-    do {                                                                          \
-        if (!(cond)) return fail((status), std::string(__func__) + ": " + (msg)); \
-    } while (0)
+}  // namespace rq
 
-#define RQ_HIP(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(e_ == hipErrorOutOfMemory ? RQ_ERR_OUT_OF_MEMORY : RQ_ERR_HIP,            \
-                        std::string(__func__) + ": " #expr " -> " + hipGetErrorString(e_));      \
-    } while (0)
+using rq::fail;
+using rq::DeviceScope;
+
+namespace {
 
 inline uint32_t round_up64(uint32_t n) { return (n + 63u) & ~63u; }
 
@@ -145,35 +142,6 @@ struct rq_teacher_bank {
 };
 
 namespace {
-
-// Every entry point runs on its rq_device's HIP device and leaves the calling thread's current device as it
-// found it: a host that drives several GPUs from one thread (or PyTorch with another current device) must
-// not find its device switched behind its back.
-thread_local int tl_scope_depth = 0, tl_scope_device = -1;     // innermost live DeviceScope of this thread
-
-struct DeviceScope {
-    int previous = -1, target, rc = RQ_OK;
-    bool nested = false;                 // inside another scope of the same device: nothing to query or restore
-    explicit DeviceScope(const rq_device* dev) : DeviceScope(dev->ordinal) {}
-    explicit DeviceScope(int ordinal) : target(ordinal) {
-        if (tl_scope_depth > 0 && tl_scope_device == target) { nested = true; ++tl_scope_depth; return; }
-        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
-        if (previous != target) {
-            const hipError_t e = hipSetDevice(target);
-            if (e != hipSuccess) rc = fail(RQ_ERR_HIP, std::string("hipSetDevice -> ") + hipGetErrorString(e));
-        }
-        outer_depth = tl_scope_depth; outer_device = tl_scope_device;
-        tl_scope_depth = 1; tl_scope_device = target;
-    }
-    ~DeviceScope() {
-        if (nested) { --tl_scope_depth; return; }
-        tl_scope_depth = outer_depth; tl_scope_device = outer_device;
-        if (previous >= 0 && previous != target) (void)hipSetDevice(previous);
-    }
-    int outer_depth = 0, outer_device = -1;
-    DeviceScope(const DeviceScope&) = delete;
-    DeviceScope& operator=(const DeviceScope&) = delete;
-};
 
 int ensure_staging(rq_device* dev, size_t bytes) {
     if (dev->staging_bytes >= bytes) return RQ_OK;
@@ -398,11 +366,19 @@ void policy_free_buffers(rq_policy* pol) {
 
 }  // namespace
 
+namespace rq {
+int device_ordinal(const rq_device* dev) { return dev->ordinal; }
+hipStream_t device_stream(const rq_device* dev) { return dev->stream; }
+rq_device* env_device(const rq_env* env) { return env->dev; }
+uint32_t env_num_envs(const rq_env* env) { return env->n; }
+const float* env_finished_returns(const rq_env* env) { return env->st.fin_returns; }
+}  // namespace rq
+
 extern "C" {
 
 // ---------------------------------------------------------------------------- library ---
 RQ_API int rq_abi_version(void) { return RQ_ABI_VERSION; }
-RQ_API const char* rq_last_error(void) { return g_last_error.c_str(); }
+RQ_API const char* rq_last_error(void) { return rq::g_last_error.c_str(); }
 
 RQ_API const char* rq_status_string(int status) {
     switch (status) {

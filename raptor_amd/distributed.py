@@ -121,3 +121,55 @@ class ReturnsExchange:
             self.engine.synchronize()
             self.side.synchronize()
         return self.outs[(self.posts - 1) % 2]
+
+
+class NativeReturnsExchange:
+    """The same exchange through the C++ host: ``rq_comm_*`` / ``rq_allgather_returns`` (raptor_quad.h), an RCCL
+    all-gather issued by libraptor_quad.so itself on a side stream behind the engine's event, double-buffered.
+    This is what a C or C++ host of the library uses; ``bench.py`` uses it too and keeps ``torch.distributed``
+    only for the rendezvous (shipping the 128-byte id), the barriers and the max-over-ranks of the timings.
+
+        id_bytes = NativeReturnsExchange.unique_id()     # on rank 0, then broadcast to every rank
+        ex = NativeReturnsExchange(device, world, rank, id_bytes)
+        ex.post(env) ... ; returns = ex.finish()          # [world * n_envs] float32 numpy, global env order
+    """
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.call("rq_comm_unique_id", buf, _lib.COMM_ID_BYTES)
+        return bytes(buf.raw)
+
+    def __init__(self, device, world, rank, id_bytes):
+        import ctypes as C
+        import weakref
+        from . import _lib
+        if len(id_bytes) != _lib.COMM_ID_BYTES:
+            raise ValueError("the communicator id must be 128 bytes")
+        h = C.c_void_p()
+        _lib.call("rq_comm_create", device._h, int(world), int(rank), C.c_char_p(id_bytes), len(id_bytes), C.byref(h))
+        self._h, self._device, self.world, self.rank = h, device, int(world), int(rank)
+        self._fin = weakref.finalize(self, _lib.load().rq_comm_destroy, h)
+        self.posts = 0
+
+    def post(self, env):
+        from . import _lib
+        _lib.call("rq_allgather_returns", env._require("environment"), self._h)
+        self.posts += 1
+
+    def finish(self, to_host=True):
+        """Waits for the last posted all-gather.  -> numpy [world * n_envs] (``to_host=False``: (device pointer, count))."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        if self.posts == 0:
+            return None
+        ptr, count = C.c_void_p(), C.c_uint32()
+        _lib.call("rq_comm_gathered", self._h, C.byref(ptr), C.byref(count), None)
+        if not to_host:
+            return ptr.value, count.value
+        out = np.empty(count.value, np.float32)
+        _lib.call("rq_comm_gathered", self._h, None, None, _lib.fptr(out))
+        return out

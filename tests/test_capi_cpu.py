@@ -130,3 +130,24 @@ def test_cpp_wrapper_example_links(tmp_path):
     if not HAS_GPU:
         run = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
         assert run.returncode == 1 and "no HIP device" in run.stderr
+
+
+def test_comm_entry_points_validate_and_fail_loudly_without_a_gpu():
+    """The RCCL exchange of the C++ host (rq_comm_*): argument checks work anywhere; without a GPU the id cannot
+    be produced and the call says so (no fallback transport exists)."""
+    from raptor_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+    assert lib.rq_comm_unique_id(None, 128) == -1
+    assert lib.rq_comm_unique_id(buf, 64) == -1 and b"128" in lib.rq_last_error()
+    h = ctypes.c_void_p()
+    assert lib.rq_comm_create(None, 2, 0, buf, 128, ctypes.byref(h)) == -1
+    assert lib.rq_allgather_returns(None, None) == -1
+    assert lib.rq_comm_gathered(None, None, None, None) == -1
+    assert lib.rq_comm_destroy(None) == 0
+    if not HAS_GPU:
+        # RCCL absent (-2), no device behind it (-3, ROCm's build) - or an id, which some RCCL builds (the one
+        # PyTorch bundles, shared when torch is already imported) hand out before any device is touched
+        rc = lib.rq_comm_unique_id(buf, 128)
+        assert rc in (0, -2, -3)
+        assert (rc == 0 and any(buf.raw)) or (rc != 0 and len(lib.rq_last_error()) > 0)

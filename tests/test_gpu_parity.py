@@ -1178,6 +1178,86 @@ def test_closed_loop_statistics_against_the_reference_training_log_on_the_gpu(de
     assert abs(length - REFERENCE_LOG["episode_length"]) < 4.0, length
 
 
+# ------------------------------------------------------------------------------ native RCCL exchange -
+def test_native_rccl_exchange_one_rank(device, oracle):
+    """rq_comm_* / rq_allgather_returns with a 1-rank RCCL communicator created by the C++ host itself: the
+    all-gather of episode k is enqueued behind rollout k and overlaps rollout k + 1; what comes back is the
+    env's finished returns of the episode it was posted after (double buffering keeps them apart)."""
+    from raptor_amd.distributed import NativeReturnsExchange
+    w = World(device, oracle, 4096, seed=41, episode_step_limit=20)
+    ex = NativeReturnsExchange(device, 1, 0, NativeReturnsExchange.unique_id())
+    snaps = []
+    for k in range(5):
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 20, "fused", True)
+        ex.post(w.env)
+        if k % 2 == 1:          # not every episode is read back: the un-read ones must not leak into later results
+            device.synchronize()
+            snaps.append((w.env.finished_returns().copy(), ex.finish()))
+    for fin, got in snaps:
+        assert got.shape == (4096,) and np.array_equal(got, fin)
+    ptr, count = ex.finish(to_host=False)
+    assert count == 4096 and ptr
+    with pytest.raises(Exception):
+        NativeReturnsExchange(device, 2, 5, NativeReturnsExchange.unique_id())      # rank out of range
+
+
+def _native_exchange_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # rendezvous only: ships the id
+    try:
+        import raptor_amd.l2f as l2f
+        from raptor_amd.distributed import NativeReturnsExchange
+        from raptor_amd.foundation_policy import Raptor
+        n = 2048
+        dev = l2f.Device(rank)
+        v = l2f.VectorModule(n, rank * n)
+        rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+        v.initialize_rng(dev, rng, 9)
+        v.initialize_environment(dev, env)
+        cfg = env.config
+        cfg.episode_step_limit = 30
+        env.config = cfg
+        v.sample_initial_parameters(dev, env, params, rng)
+        v.sample_initial_state(dev, env, params, state, rng)
+        pol = Raptor(dev)
+        ident = [NativeReturnsExchange.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        ex = NativeReturnsExchange(dev, world, rank, ident[0])
+        v.rollout(dev, env, params, state, pol, rng, 30, "fused", True)
+        ex.post(env)
+        q.put((rank, env.finished_returns().copy(), ex.finish()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_native_rccl_exchange_across_gpus():
+    """Two processes, two GPUs, RCCL over xGMI from the C++ host: every rank ends up with the concatenation of the
+    ranks' finished returns in global env order.  Needs >= 2 GPUs (the 1-GPU box skips it)."""
+    import socket
+    import raptor_amd.l2f as l2f
+    if l2f.Device.count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    full = np.concatenate([res[0][1], res[1][1]])
+    assert np.array_equal(res[0][2], full) and np.array_equal(res[1][2], full)
+
+
 # ------------------------------------------------------------------------------ teacher bank -
 def _teacher_weights(rng, n_teachers, in_dim, h1, h2):
     from raptor_amd.teachers import parameter_count
