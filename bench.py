@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-native-exchange", action="store_true",
+                    help="use the C++ host's RCCL all-gather even with one rank (it is always used with more)")
     return ap.parse_args()
 
 
@@ -130,7 +132,7 @@ def fused_kernel_name(precision, n, steps_per_launch):
         actor = "rq::ActorBF16Lean" if n > 65536 else "rq::ActorBF16"
     else:
         actor = "rq::ActorF32T<true> " if (n > 65536 or steps_per_launch >= 48) else "rq::ActorF32T<false> "
-    return f"rq::k_rollout_fused<false, true, false, {actor}>"
+    return f"rq::k_rollout_fused<false, true, false, false, {actor}>"     # <NOISE, AUTORESET, RECORD, SAS, ACTOR>
 
 
 def sq_profile(precision):
@@ -368,7 +370,7 @@ def main():
     exchange_kind = "native RCCL (rq_allgather_returns)"
 
     def all_ranks_ok(ok):
-        if dist is None or world == 1:
+        if dist is None:
             return ok
         flag = torch.tensor([1.0 if ok else 0.0], device=f"cuda:{local_rank}")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -377,14 +379,14 @@ def main():
     from raptor_amd.distributed import NativeReturnsExchange
     why = ""
     try:      # phase 1 (no collective inside): can every rank bind RCCL?  rank 0's id is the one that is used
-        ident = [NativeReturnsExchange.unique_id() if world > 1 else None]
+        ident = [NativeReturnsExchange.unique_id() if (world > 1 or args.force_native_exchange) else None]
     except Exception as exc:      # noqa: BLE001
         ident, why = [None], str(exc)
-    native = world > 1 and all_ranks_ok(ident[0] is not None)
-    if world == 1:
+    native = (world > 1 or args.force_native_exchange) and all_ranks_ok(ident[0] is not None)
+    if world == 1 and not args.force_native_exchange:
         why = "single rank"
     if native:
-        if dist is not None and world > 1:
+        if dist is not None:
             dist.broadcast_object_list(ident, src=0)
         try:  # phase 2: the collective communicator creation
             exchange = NativeReturnsExchange(device, world, rank, ident[0])
@@ -395,7 +397,7 @@ def main():
         post = lambda: exchange.post(shard.env)                                            # noqa: E731
         finish = lambda: exchange.finish(to_host=False)                                    # noqa: E731
     else:
-        exchange_kind = ("none: one rank, the returns are only copied out behind each rollout" if world == 1 else
+        exchange_kind = ("none: one rank, the returns are only copied out behind each rollout" if why == "single rank" else
                          f"torch.distributed all_gather_into_tensor (native communicator unavailable: {why})")
         exchange = ReturnsExchange(n, n_total, f"cuda:{local_rank}", engine_stream=device.stream)
         post = lambda: exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))   # noqa: E731

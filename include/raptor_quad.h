@@ -266,7 +266,7 @@ RQ_API int rq_env_reset_statistics(rq_env* env);
 
 /* ---- Policy (README.md:19-24,48,94,97; checkpoint.h:34-194) ---------------------------- */
 typedef enum rq_policy_precision {
-    RQ_POLICY_FP32 = 0,       /* fp32 VALU, weights broadcast from LDS                         */
+    RQ_POLICY_FP32 = 0,       /* exact fp32 on v_mfma_f32_16x16x4_f32 (one rounded fma per product), operands register-stationary */
     RQ_POLICY_BF16_MFMA = 1   /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates */
 } rq_policy_precision;
 
@@ -280,9 +280,23 @@ RQ_API int rq_policy_set_precision(rq_policy* pol, int precision);
  * reference semantics are unpinned (no source or test vector in the reference tree):
  *   Standardize: x <- (x - mean) / std on the 22 inputs (folded into layer_0's weights, zero run-time cost);
  *                mean = std = NULL disables.
- *   Squash:      action <- tanh(action) (SampleAndSquash evaluated deterministically). */
+ *   Squash:      action <- tanh(action): SampleAndSquash in evaluation mode; the full layer (mean / log-std split,
+ *                sampling) is rq_policy_set_sample_and_squash below. */
 RQ_API int rq_policy_set_standardize(rq_policy* pol, const float* mean, const float* std);
-RQ_API int rq_policy_set_squash(rq_policy* pol, int enable);
+RQ_API int rq_policy_set_squash(rq_policy* pol, int enable);   /* = set_sample_and_squash(RQ_SAS_MEAN / RQ_SAS_OFF) */
+/* SampleAndSquash as a layer (rl-tools nn/layers/sample_and_squash [UPSTREAM-UNVERIFIED]): the last dense layer
+ * has 8 outputs, [mean (4) | log_std (4)].  The 4 mean rows are the policy's layer_2; the 4 log-std rows are given
+ * here: log_std_weights [4][16] row-major (NULL = state-independent log-std) and log_std_bias [4] (NULL = 0).
+ *   RQ_SAS_OFF    raw output (the shipped checkpoint, checkpoint.h:170 IDENTITY)
+ *   RQ_SAS_MEAN   action = tanh(mean)                                       (evaluation mode)
+ *   RQ_SAS_SAMPLE action = tanh(mean + exp(clamp(log_std, -20, 2)) * eps), eps ~ N(0,1) drawn from Philox4x32-10
+ *                 keyed by `seed`, counter (step, GLOBAL env id): rollouts use the rng's epoch as the step (fused
+ *                 and chained modes agree bit for bit), rq_policy_evaluate_step a per-policy call counter that
+ *                 rq_policy_reset rewinds.  Sequence evaluation and relabelling are deterministic passes and
+ *                 reject this mode. */
+typedef enum rq_sample_and_squash_mode { RQ_SAS_OFF = 0, RQ_SAS_MEAN = 1, RQ_SAS_SAMPLE = 2 } rq_sample_and_squash_mode;
+RQ_API int rq_policy_set_sample_and_squash(rq_policy* pol, int mode, const float* log_std_weights,
+                                    const float* log_std_bias, uint64_t seed);
 /* hidden state h[B,16] <- initial_hidden_state (checkpoint.h:123); sized on first use */
 RQ_API int rq_policy_reset(rq_policy* pol);
 /* One recurrent step for a batch.  observation: host [batch, obs_stride] (first 22 columns

@@ -120,6 +120,20 @@ def actor_batch_step(weights, obs, hidden):
     return act
 
 
+def actor_batch_step_sas(weights, w_ls, b_ls, mode, seed, step, env_offset, obs, hidden):
+    """One recurrent step with the SampleAndSquash output stage (mode 0 off, 1 tanh(mean), 2 sample)."""
+    w, wp = _f(weights)
+    o, op = _f(obs)
+    B = o.shape[0]
+    act = np.empty((B, 4), np.float32)
+    wl = None if w_ls is None else _f(w_ls)
+    bl = None if b_ls is None else _f(b_ls)
+    lib().orc_actor_batch_step_sas(wp, None if wl is None else wl[1], None if bl is None else bl[1], C.c_int(mode),
+                                   C.c_uint64(seed), C.c_uint32(step), C.c_uint64(env_offset), op,
+                                   C.c_uint32(o.shape[1]), _p(hidden, C.c_float), _p(act, C.c_float), C.c_uint32(B))
+    return act
+
+
 def sample_initial_parameters(cfg, seed, epoch, env_offset, n):
     out = np.zeros((n, PARAM_DIM), np.float32)
     lib().orc_sample_initial_parameters(C.byref(cfg), C.c_uint64(seed), C.c_uint32(epoch),

@@ -156,6 +156,37 @@ ORC_EXPORT void orc_actor_step(const float* w, const float* obs, float* h, float
     }
 }
 
+/* SampleAndSquash output stage as raptor_quad.h defines it ([UPSTREAM-UNVERIFIED] layer, not in the shipped
+ * checkpoint): mode 1 act = tanh(mean); mode 2 act = tanh(mean + exp(clamp(log_std, -20, 2)) eps) with
+ * log_std = W_ls h' + b_ls (W_ls may be NULL) and eps from Philox block (0, step, genv, PURPOSE_ACTION = 4). */
+ORC_EXPORT void orc_actor_step_sas(const float* w, const float* w_ls, const float* b_ls, int mode, uint64_t seed,
+                                   uint32_t step, uint64_t genv, const float* obs, float* h, float* act) {
+    orc_actor_step(w, obs, h, act);
+    if (mode == 0) return;
+    if (mode == 2) {
+        uint32_t r[4];
+        float n[4];
+        rng_block(seed, 0, step, genv, 4, r);
+        box_muller(u01(r[0]), u01(r[1]), &n[0], &n[1]);
+        box_muller(u01(r[2]), u01(r[3]), &n[2], &n[3]);
+        for (int o = 0; o < 4; ++o) {
+            float ls = b_ls ? b_ls[o] : 0.0f;
+            if (w_ls) for (int k = 0; k < 16; ++k) ls = fmaf(w_ls[o * 16 + k], h[k], ls);
+            ls = fminf(fmaxf(ls, -20.0f), 2.0f);
+            act[o] = fmaf(expf(ls), n[o], act[o]);
+        }
+    }
+    for (int o = 0; o < 4; ++o) act[o] = tanhf(act[o]);
+}
+
+ORC_EXPORT void orc_actor_batch_step_sas(const float* w, const float* w_ls, const float* b_ls, int mode, uint64_t seed,
+                                         uint32_t step, uint64_t env_offset, const float* obs, uint32_t obs_stride,
+                                         float* h, float* act, uint32_t B) {
+    for (uint32_t b = 0; b < B; ++b)
+        orc_actor_step_sas(w, w_ls, b_ls, mode, seed, step, env_offset + b, obs + (size_t)b * obs_stride, h + 16 * b,
+                           act + 4 * b);
+}
+
 /* input [T,B,22] -> output [T,B,4], hidden starts at initial_hidden_state (checkpoint.h:123) */
 ORC_EXPORT void orc_actor_sequence(const float* w, const float* in, float* out, uint32_t T, uint32_t B) {
     float* h = (float*)malloc(sizeof(float) * 16 * B);

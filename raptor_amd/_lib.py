@@ -141,6 +141,7 @@ _SIGNATURES = {
     "rq_policy_set_precision": [_vp, C.c_int],
     "rq_policy_set_standardize": [_vp, _fp, _fp],
     "rq_policy_set_squash": [_vp, C.c_int],
+    "rq_policy_set_sample_and_squash": [_vp, C.c_int, _fp, _fp, C.c_uint64],
     "rq_policy_reset": [_vp],
     "rq_policy_evaluate_step": [_vp, _vp, _fp, C.c_uint32, C.c_uint32, _fp],
     "rq_policy_get_hidden": [_vp, _fp, C.c_uint32],

@@ -91,6 +91,7 @@ struct rq_env {
     struct GraphEntry {
         const float* params; float* state; float* hidden; const float* packed; const float* weights;
         uint32_t flags; int precision; rq_env_config cfg; uint64_t seed;
+        int sas_mode; uint64_t sas_seed; const float* ls_image;
         hipGraphExec_t exec;
     };
     std::vector<GraphEntry> graphs;
@@ -120,7 +121,10 @@ struct rq_policy {
     float w_eff[RQ_POLICY_NUM_WEIGHTS];       // with the optional Standardize stage folded into layer_0
     bool standardize = false;
     float std_mean[RQ_POLICY_INPUT_DIM], std_inv[RQ_POLICY_INPUT_DIM];
-    int squash = 0;
+    int sas_mode = RQ_SAS_OFF;        // SampleAndSquash output stage
+    uint64_t sas_seed = 0;
+    uint32_t sas_counter = 0;         // sampling step of the next rq_policy_evaluate_step call
+    float* ls_image = nullptr;        // device: rq::RQ_LOGSTD_FLOATS (log-std head operands), allocated on first use
     int precision = RQ_POLICY_FP32;
     uint32_t batch = 0, ld = 0;   // 0 = not sized yet
     bool needs_reset = true;      // hidden must be (re)filled with initial_hidden_state before use
@@ -325,7 +329,12 @@ int check_env_objects(const rq_device* dev, const rq_env* env, const rq_params* 
 
 void policy_free_buffers(rq_policy* pol);
 
-int mode_of(const rq_policy* pol) { return pol->precision | (pol->squash << 8); }
+// precision in bits 0-7, bit 8 = tanh on the output (what the sequence / relabel launchers take)
+int mode_of(const rq_policy* pol) { return pol->precision | ((pol->sas_mode != RQ_SAS_OFF ? 1 : 0) << 8); }
+
+rq::SasArgs sas_of(const rq_policy* pol, uint32_t epoch, const uint32_t* epoch_base, uint64_t env_offset) {
+    return {(uint32_t)pol->sas_mode, epoch, epoch_base, pol->ls_image, pol->sas_seed, env_offset};
+}
 
 const float* packed_of(const rq_policy* pol) {
     return pol->precision == RQ_POLICY_BF16_MFMA ? pol->w_packed_bf16 : pol->w_packed;
@@ -907,6 +916,7 @@ RQ_API int rq_policy_destroy(rq_policy* pol) {
     if (pol->w_dev) (void)hipFree(pol->w_dev);
     if (pol->w_packed) (void)hipFree(pol->w_packed);
     if (pol->w_packed_bf16) (void)hipFree(pol->w_packed_bf16);
+    if (pol->ls_image) (void)hipFree(pol->ls_image);
     delete pol;
     return RQ_OK;
 }
@@ -935,7 +945,25 @@ RQ_API int rq_policy_set_standardize(rq_policy* pol, const float* mean, const fl
 
 RQ_API int rq_policy_set_squash(rq_policy* pol, int enable) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    pol->squash = enable ? 1 : 0;
+    pol->sas_mode = enable ? RQ_SAS_MEAN : RQ_SAS_OFF;
+    return RQ_OK;
+}
+
+RQ_API int rq_policy_set_sample_and_squash(rq_policy* pol, int mode, const float* log_std_weights, const float* log_std_bias,
+                                    uint64_t seed) {
+    RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(mode == RQ_SAS_OFF || mode == RQ_SAS_MEAN || mode == RQ_SAS_SAMPLE, RQ_ERR_INVALID_ARGUMENT, "unknown mode");
+    if (mode == RQ_SAS_SAMPLE) {
+        DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
+        std::vector<float> image(rq::RQ_LOGSTD_FLOATS);
+        rq::pack_logstd_head(log_std_weights, log_std_bias, image.data());
+        RQ_HIP(hipStreamSynchronize(pol->dev->stream));
+        if (!pol->ls_image) RQ_HIP(hipMalloc(&pol->ls_image, image.size() * sizeof(float)));
+        RQ_HIP(hipMemcpy(pol->ls_image, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    pol->sas_mode = mode;
+    pol->sas_seed = seed;
+    pol->sas_counter = 0;
     return RQ_OK;
 }
 
@@ -943,6 +971,7 @@ RQ_API int rq_policy_reset(rq_policy* pol) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
     DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
     pol->needs_reset = true;   // applied (h <- initial_hidden_state, checkpoint.h:123) on the next use
+    pol->sas_counter = 0;
     return RQ_OK;
 }
 
@@ -990,7 +1019,9 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
         mb = mailbox_for(dev, rows_in, RQ_POLICY_INPUT_DIM, action ? dev->mb_out : nullptr);
     }
     RQ_HIP_MB(rq::launch_actor_step(dev->stream, batch, packed_of(pol), d_obs, ld_obs, pol->hidden, pol->ld, d_act,
-                                    ld_act, nullptr, mode_of(pol), mb), dev, mb);
+                                    ld_act, nullptr, pol->precision,
+                                    sas_of(pol, pol->sas_counter, nullptr, env ? env->offset : 0), mb), dev, mb);
+    if (pol->sas_mode == RQ_SAS_SAMPLE) pol->sas_counter += 1;
     if (action && mailbox) {
         rc = mailbox_wait(dev, mb.seq); if (rc) return rc;
         std::memcpy(action, dev->mb_out, (size_t)batch * RQ_ACTION_DIM * sizeof(float));
@@ -1006,6 +1037,8 @@ RQ_API int rq_policy_evaluate_sequence(rq_policy* pol, const float* observation,
     RQ_REQUIRE(steps > 0 && batch > 0, RQ_ERR_INVALID_ARGUMENT, "empty sequence");
     RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
     RQ_REQUIRE(memory >= RQ_DST_HOST && memory <= RQ_DST_DEVICE_ASYNC, RQ_ERR_INVALID_ARGUMENT, "memory must be 0, 1 or 2");
+    RQ_REQUIRE(pol->sas_mode != RQ_SAS_SAMPLE, RQ_ERR_INVALID_ARGUMENT,
+               "sequence evaluation is a deterministic pass: RQ_SAS_SAMPLE is defined for evaluate_step and rollouts");
     if (memory != RQ_DST_HOST)      // the kernel moves rows with 8-byte loads and actions with 16-byte stores
         RQ_REQUIRE((reinterpret_cast<uintptr_t>(observation) & 7u) == 0 && (reinterpret_cast<uintptr_t>(action) & 15u) == 0,
                    RQ_ERR_INVALID_ARGUMENT, "device tensors must be 8-byte (observation) / 16-byte (action) aligned");
@@ -1056,7 +1089,7 @@ RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* e
     rq_policy* tmp = nullptr;
     int rc = rq_policy_create(pol->dev, pol->w_host, RQ_POLICY_NUM_WEIGHTS, &tmp); if (rc) return rc;
     tmp->precision = pol->precision;
-    tmp->squash = pol->squash;
+    tmp->sas_mode = pol->sas_mode == RQ_SAS_SAMPLE ? RQ_SAS_MEAN : pol->sas_mode;   // known answers are deterministic
     if (pol->standardize) {
         tmp->standardize = true;
         std::memcpy(tmp->std_mean, pol->std_mean, sizeof(tmp->std_mean));
@@ -1086,6 +1119,7 @@ RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* e
 
 // ---------------------------------------------------------------------------- Rollout ---
 static constexpr uint32_t kGraphSteps = 25;   // steps per captured graph (divides the 500-step episode)
+static constexpr size_t kMaxGraphs = 8;       // executable graphs kept per env (one per distinct argument set)
 
 static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq_state* state, rq_policy* policy,
                         rq_rng* rng, uint32_t n_steps, int mode, uint32_t flags, rq_trajectory* traj) {
@@ -1115,7 +1149,8 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     if (mode == RQ_ROLLOUT_FUSED) {
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
-                                        mode_of(policy), tp, dev->ev_kbegin, dev->ev_kend));
+                                        policy->precision, sas_of(policy, rng->epoch, nullptr, env->offset), tp,
+                                        dev->ev_kbegin, dev->ev_kend));
         dev->k_timed = n_steps > 0;
     } else {
         // one step = observe -> evaluate_step -> step (-> record) on the stream
@@ -1124,7 +1159,8 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                                               state->d, env->obs);
             if (e == hipSuccess)
                 e = rq::launch_actor_step(dev->stream, env->n, packed_of(policy), env->obs, env->ld, policy->hidden,
-                                          policy->ld, env->act, env->ld, env->st.frozen, mode_of(policy));
+                                          policy->ld, env->act, env->ld, env->st.frozen, policy->precision,
+                                          sas_of(policy, epoch, epoch_base, env->offset));
             if (e == hipSuccess)
                 e = rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
                                     /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev);
@@ -1145,7 +1181,8 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
             for (auto& g : env->graphs)
                 if (g.params == params->d && g.state == state->d && g.hidden == policy->hidden &&
                     g.packed == packed_of(policy) && g.weights == policy->w_dev && g.flags == flags &&
-                    g.precision == mode_of(policy) && g.seed == rng->seed &&
+                    g.precision == policy->precision && g.seed == rng->seed && g.sas_mode == policy->sas_mode &&
+                    g.sas_seed == policy->sas_seed && g.ls_image == policy->ls_image &&
                     std::memcmp(&g.cfg, &env->cfg, sizeof(rq_env_config)) == 0) { exec = g.exec; break; }
             if (!exec) {
                 hipGraph_t graph = nullptr;
@@ -1159,8 +1196,14 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                 hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
                 RQ_HIP(ie);
+                if (env->graphs.size() >= kMaxGraphs) {        // least recently created goes (a replay is cheap to rebuild)
+                    RQ_HIP(hipStreamSynchronize(dev->stream));
+                    (void)hipGraphExecDestroy(env->graphs.front().exec);
+                    env->graphs.erase(env->graphs.begin());
+                }
                 env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, flags,
-                                       mode_of(policy), env->cfg, rng->seed, exec});
+                                       policy->precision, env->cfg, rng->seed, policy->sas_mode, policy->sas_seed,
+                                       policy->ls_image, exec});
             }
             RQ_HIP(rq::launch_set_u32(dev->stream, env->epoch_dev, rng->epoch));
             for (; done_steps + kGraphSteps <= n_steps; done_steps += kGraphSteps)
@@ -1283,6 +1326,8 @@ RQ_API int rq_trajectory_relabel(rq_trajectory* t, rq_policy* pol, float* action
     rq_env* env = t->env;
     rq_device* dev = env->dev;
     RQ_REQUIRE(pol->dev == dev, RQ_ERR_SHAPE_MISMATCH, "policy lives on another device");
+    RQ_REQUIRE(pol->sas_mode != RQ_SAS_SAMPLE, RQ_ERR_INVALID_ARGUMENT,
+               "relabelling is a deterministic pass: RQ_SAS_SAMPLE is defined for evaluate_step and rollouts");
     if (t->length == 0) return RQ_OK;
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     rc = policy_size(pol, env->n); if (rc) return rc;

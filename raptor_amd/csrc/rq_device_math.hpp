@@ -20,7 +20,7 @@
 namespace rq {
 
 // ------------------------------------------------------------------ Philox4x32-10 ------
-enum : uint32_t { PURPOSE_PARAMS = 1, PURPOSE_STATE = 2, PURPOSE_OBS = 3 };
+enum : uint32_t { PURPOSE_PARAMS = 1, PURPOSE_STATE = 2, PURPOSE_OBS = 3, PURPOSE_ACTION = 4 };
 
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -800,12 +800,56 @@ struct ActorBF16 {
 
 struct ActorBF16Lean : ActorBF16 {};     // same arithmetic, compiled for 2 waves/SIMD (batches > 65 536 envs)
 
-// Optional output stage (SampleAndSquash in inference mode: tanh of the mean
-// head; NOT part of the shipped checkpoint, semantics unpinned): a <- tanh(a).
+// Optional output stage SampleAndSquash (rl-tools nn/layers/sample_and_squash, /root/reference/README.md:116; NOT part
+// of the shipped checkpoint, whose chain ends in a plain Dense, checkpoint.h:185; semantics [UPSTREAM-UNVERIFIED]):
+// the final dense layer then has 8 outputs [mean (4) | log_std (4)] and
+//   RQ_SAS_MEAN   : a = tanh(mean)
+//   RQ_SAS_SAMPLE : a = tanh(mean + exp(clamp(log_std, -20, 2)) eps),  eps ~ N(0, 1) from the Philox stream
+//                   (key = the policy's sampling seed, counter = (0, step, global env id, PURPOSE_ACTION)).
 __device__ __forceinline__ void squash_action(float (&a)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         a[r] = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * a[r])), -1.0f);
+}
+
+// The log-std rows of the 8-output head on the matrix cores, from the post-update hidden state in the Q layout:
+// image = 16 A operands laid out like layer_2's ([t][s]: lane (q, j) = (j >> 2 == t) ? W_ls[j & 3][4q + s] : 0, the
+// four tiles accumulate into one D = the native layout) followed by 4 bias images.  Read from memory when used
+// (L2-resident, 5 KB): a stage that is off in the shipped policy must not hold registers in the rollout loop.
+__device__ __forceinline__ void logstd_head(const float* __restrict__ img, const float (&hQ)[4][4], float (&ls)[4]) {
+    const int lane = threadIdx.x & 63;
+    f32x4 d0 = {img[16 * 64 + lane], img[17 * 64 + lane], img[18 * 64 + lane], img[19 * 64 + lane]};
+    f32x4 d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        d0 = mfma16(img[(0 + s) * 64 + lane], hQ[0][s], d0);
+        d1 = mfma16(img[(4 + s) * 64 + lane], hQ[1][s], d1);
+        d0 = mfma16(img[(8 + s) * 64 + lane], hQ[2][s], d0);
+        d1 = mfma16(img[(12 + s) * 64 + lane], hQ[3][s], d1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ls[r] = d0[r] + d1[r];
+}
+
+// a = raw output of the mean head (native layout); hQ = hidden state after this step.  Wave-uniform control flow
+// (the log-std head is MFMA work): sas is a kernel argument.  The fused rollout kernel compiles this stage in only
+// in its SAS instantiations: the stage is off in the shipped policy, and merely present behind a never-taken branch
+// it costs the rollout loop registers and scalar state (measured: 3.27 -> 3.33 us per step; out of line 3.83, the
+// hidden state then lives in memory).
+__device__ __forceinline__ void sample_and_squash(const SasArgs& sas, uint32_t epoch, uint64_t genv,
+                                                  const float (&hQ)[4][4], float (&a)[4]) {
+    if (sas.mode == RQ_SAS_SAMPLE) {
+        float ls[4];
+        logstd_head(sas.ls_image, hQ, ls);
+        const u32x4 r = rng_block(sas.seed, 0, epoch, genv, PURPOSE_ACTION);
+        float n[4];
+        box_muller_fast(u01(r.x), u01(r.y), n[0], n[1]);
+        box_muller_fast(u01(r.z), u01(r.w), n[2], n[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = fmaf(__builtin_amdgcn_exp2f(1.4426950408889634f * clampf(ls[i], -20.0f, 2.0f)), n[i], a[i]);
+    }
+    squash_action(a);
 }
 
 // Q-layout addressing helpers for a wave whose first env is wave_base: tile t of lane (q,j) is

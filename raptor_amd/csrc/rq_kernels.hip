@@ -18,7 +18,6 @@
 //   k_rows_to_soa        (row-major [n][dim] <-> field-major [dim][ld], LDS tile)
 // Below 1024 envs k_observe / k_actor_step / k_step exchange host rows through a pinned mailbox (Mailbox).
 #include <hip/hip_ext.h>
-#include <stdlib.h>
 
 #include "rq_device_math.hpp"
 
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        float* __restrict__ hidden, uint32_t ld_h,
                                                        float* __restrict__ act, uint32_t ld_act,
-                                                       const uint8_t* __restrict__ frozen, uint32_t squash,
+                                                       const uint8_t* __restrict__ frozen, SasArgs sas,
                                                        Mailbox mb) {
     ACTOR actor;
     actor.load(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
@@ -165,7 +164,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
         const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
         float a[4];
         actor.step(x, hQ, a);
-        if (squash) squash_action(a);        // wave-uniform (kernel argument)
+        if (sas.mode)                        // wave-uniform (kernel argument)
+            sample_and_squash(sas, sas.epoch + (sas.epoch_base != nullptr ? *sas.epoch_base : 0u), sas.env_offset + i, hQ, a);
         store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
         if (commit) {
 #pragma unroll
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
 // the rare auto-reset branch (no MFMA inside) diverges.
 
-template <bool NOISE, bool AUTORESET, bool RECORD, typename ACTOR>
+template <bool NOISE, bool AUTORESET, bool RECORD, bool SAS, typename ACTOR>
 __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
                                                                uint64_t seed, uint32_t epoch0, uint32_t n_steps,
                                                                const float* __restrict__ params,
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
                                                                float* __restrict__ hidden,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ packed, StatsPtrs st,
-                                                               TrajPtrs traj, uint32_t squash) {
+                                                               TrajPtrs traj, SasArgs sas) {
     ACTOR actor;
     actor.load(packed);
     const uint32_t i0 = env_index();
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool frozen = AUTORESET ? false : was_frozen;
     // wave-uniform: no env of this wave distinguishes rotor spin-up from spin-down (see dynamics<SYM_TAU>)
-    const bool sym_tau = __builtin_amdgcn_ballot_w64(k.itr != k.itf) == 0 && !(squash & 2u);
+    const bool sym_tau = __builtin_amdgcn_ballot_w64(k.itr != k.itf) == 0;
 
     for (uint32_t t = 0; t < n_steps; ++t) {
         const uint64_t live = AUTORESET ? ~0ull : __builtin_amdgcn_ballot_w64(!frozen);
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
 #pragma unroll
             for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
         actor.step(o, hn, a);
-        if (squash & 1u) squash_action(a);   // wave-uniform (kernel argument)
+        if (SAS) sample_and_squash(sas, epoch0 + t, genv, hn, a);        // SampleAndSquash output stage (rare)
         if (RECORD) {   // one coalesced 256-byte store per field per wave
             // buffer stores: resource = this step's block of the trajectory (base moved on the SALU), scalar
             // offset = field row, vector offset = the lane's env; no per-lane 64-bit address arithmetic and
@@ -614,20 +614,18 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add) {
 
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
-                             int precision, Mailbox mb) {
+                             int precision, SasArgs sas, Mailbox mb) {
     if (n == 0) return hipSuccess;
     // enough waves to fill the 1024 SIMDs first, then several 64-env groups per wave so that the
     // per-wave operand-image load (18 KB, more than a group's own 14.8 KB of data) is amortised
-    const uint32_t squash = ((uint32_t)precision >> 8) & 1u;
-    precision &= 0xff;
     const uint32_t groups = (n + 63) / 64;
     const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
     if (precision == RQ_POLICY_BF16_MFMA)
-        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash, mb);
+        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
     else
         // the two-tiles-per-pass build: ~30 registers fewer live, 2-3 % faster at every size (same arithmetic)
-        k_actor_step<ActorF32Lean><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, squash, mb);
+        k_actor_step<ActorF32Lean><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
     return hipGetLastError();
 }
 
@@ -683,7 +681,7 @@ hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj,
+                                const float* packed, StatsPtrs st, int precision, SasArgs sas, TrajPtrs traj,
                                 hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
     const unsigned g = grid_for(b.n, kFusedBlock);
@@ -691,8 +689,19 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     // hipExtLaunchKernelGGL: the two events take the kernel's own begin / end timestamps (not the stream's
     // position when a record command is processed), which is what rq_device_last_rollout_ms reports
 #define RQ_LAUNCH_FUSED(NZ, AR, RC, ACT) \
-    hipExtLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, ACT>), dim3(g), dim3(kFusedBlock), 0, s, ev_begin, ev_end, 0, \
-                          b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, squash)
+    hipExtLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, false, ACT>), dim3(g), dim3(kFusedBlock), 0, s, ev_begin, ev_end, 0, \
+                          b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas)
+    // with the SampleAndSquash stage: only the 256-register builds carry it
+#define RQ_LAUNCH_FUSED_SAS(NZ, AR, RC, ACT) \
+    hipExtLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, true, ACT>), dim3(g), dim3(kFusedBlock), 0, s, ev_begin, ev_end, 0, \
+                          b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas)
+#define RQ_LAUNCH_FUSED_SAS_RC(NZ, AR, ACT) \
+    do { if (rec) RQ_LAUNCH_FUSED_SAS(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED_SAS(NZ, AR, false, ACT); } while (0)
+#define RQ_LAUNCH_FUSED_SAS_ACT(ACT)                                                      \
+    do {                                                                                  \
+        if (noise) { if (ar) RQ_LAUNCH_FUSED_SAS_RC(true, true, ACT); else RQ_LAUNCH_FUSED_SAS_RC(true, false, ACT); }   \
+        else       { if (ar) RQ_LAUNCH_FUSED_SAS_RC(false, true, ACT); else RQ_LAUNCH_FUSED_SAS_RC(false, false, ACT); } \
+    } while (0)
 #define RQ_LAUNCH_FUSED_RC(NZ, AR, ACT) \
     do { if (rec) RQ_LAUNCH_FUSED(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED(NZ, AR, false, ACT); } while (0)
 #define RQ_LAUNCH_FUSED_ACT(ACT)                                                          \
@@ -701,9 +710,6 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
         else       { if (ar) RQ_LAUNCH_FUSED_RC(false, true, ACT); else RQ_LAUNCH_FUSED_RC(false, false, ACT); } \
     } while (0)
     const bool rec = traj.obs != nullptr;
-    static const uint32_t no_sym = getenv("RQ_NO_SYM_TAU") ? 2u : 0u;      // experiment switch
-    const uint32_t squash = (((uint32_t)precision >> 8) & 1u) | no_sym;
-    precision &= 0xff;
     // Two builds of the same loop: a 512-register one (one wave per SIMD) and a 256-register "lean" one
     // (two waves per SIMD, GRU two tiles at a time).  Beyond 65 536 envs (1024 SIMDs x 64 lanes) the lean
     // build wins because two waves share a SIMD.  For the fp32 actor it also wins at one wave per SIMD
@@ -711,11 +717,17 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     // MFMA operands in AGPRs and copying them back, ~85 fewer vector instructions per step) but costs
     // ~6 us more per launch, so short launches keep the 512-register build.  bf16: the reverse at <= 65 536.
     const bool lean = b.n > 65536u || (precision != RQ_POLICY_BF16_MFMA && n_steps >= 48u);
-    if (precision == RQ_POLICY_BF16_MFMA) {
+    if (sas.mode != RQ_SAS_OFF) {
+        if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_SAS_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_SAS_ACT(ActorF32Lean);
+    }
+    else if (precision == RQ_POLICY_BF16_MFMA) {
         if (lean) RQ_LAUNCH_FUSED_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_ACT(ActorBF16);
     }
     else if (lean)                        RQ_LAUNCH_FUSED_ACT(ActorF32Lean);
     else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
+#undef RQ_LAUNCH_FUSED_SAS_ACT
+#undef RQ_LAUNCH_FUSED_SAS_RC
+#undef RQ_LAUNCH_FUSED_SAS
 #undef RQ_LAUNCH_FUSED_RC
 #undef RQ_LAUNCH_FUSED_ACT
 #undef RQ_LAUNCH_FUSED

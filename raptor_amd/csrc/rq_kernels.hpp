@@ -65,6 +65,16 @@ struct TrajPtrs {
     uint32_t t0;          // index of the first step this launch writes
 };
 
+// SampleAndSquash output stage of the actor (rq_policy_set_sample_and_squash): mode = rq_sample_and_squash_mode
+struct SasArgs {
+    uint32_t mode;                // RQ_SAS_OFF / RQ_SAS_MEAN / RQ_SAS_SAMPLE
+    uint32_t epoch;               // sampling counter of this launch (+ *epoch_base inside a replayed hipGraph)
+    const uint32_t* epoch_base;
+    const float* ls_image;        // 20 x 64 floats: log-std head operands + bias (pack_logstd_head), RQ_SAS_SAMPLE only
+    uint64_t seed;
+    uint64_t env_offset;          // global id of batch element 0 (k_actor_step; the fused kernel has its Batch)
+};
+
 struct Batch {           // which envs a launch covers
     uint32_t n, ld;      // envs, leading dimension of every SoA buffer
     uint64_t env_offset; // global id of env 0 (RNG key)
@@ -99,11 +109,11 @@ hipError_t launch_set_u32(hipStream_t s, uint32_t* p, uint32_t value);
 hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.
 // frozen != nullptr: envs with frozen[i] != 0 are skipped (rollout semantics).
-// `precision`: rq_policy_precision in bits 0-7, bit 8 = squash the output with tanh.
+// `precision`: rq_policy_precision; `sas`: the optional SampleAndSquash output stage.
 // `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
-                             int precision, Mailbox mb = Mailbox{});
+                             int precision, SasArgs sas, Mailbox mb = Mailbox{});
 // Raptor over a sequence: obs [steps][n][stride] (first 22 columns) -> act [steps][n][4], both row-major on
 // the device; hidden [16][ld_h] is the state before step 0 on entry and after the last step on return
 hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, const float* packed, const float* obs,
@@ -127,7 +137,7 @@ hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed
 hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, bool noise, SampleCfg sc,
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
-                                const float* packed, StatsPtrs st, int precision, TrajPtrs traj,
+                                const float* packed, StatsPtrs st, int precision, SasArgs sas, TrajPtrs traj,
                                 hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // chained mode: copy step t (env obs/action buffers + last reward / done code) into the trajectory
 hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* act, StatsPtrs st, TrajPtrs traj);
@@ -164,6 +174,9 @@ enum { RQ_PACKED_FLOATS = QW_REGS * 64, RQ_PACKED_BF16_FLOATS = BW_REGS * 64 };
 void pack_policy(const float* weights, float* packed);
 // the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
 void pack_policy_bf16(const float* weights, float* packed);
+// log-std rows of a SampleAndSquash head: w_ls [4][16] row-major (nullptr = zeros), b_ls [4] -> 20 x 64 floats
+enum { RQ_LOGSTD_FLOATS = 20 * 64 };
+void pack_logstd_head(const float* w_ls, const float* b_ls, float* image);
 
 // ---- teacher bank (rq_teacher.hip): per-teacher operand images, regs x 64 lanes, one dword per lane --------
 //   f32 : [H1/16][6] layer-1 A, [H2/16][H1/4] layer-2 A, [H2/4] layer-3 A, [H2/16][4] layer-2 bias, [4] layer-3 bias

@@ -88,6 +88,16 @@ void pack_policy_bf16(const float* w, float* packed) {
     }
 }
 
+void pack_logstd_head(const float* w_ls, const float* b_ls, float* image) {
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, j = l & 15;
+        for (int t = 0; t < 4; ++t)
+            for (int s = 0; s < 4; ++s)
+                image[(4 * t + s) * 64 + l] = (w_ls && (j >> 2) == t) ? w_ls[(j & 3) * 16 + 4 * q + s] : 0.0f;
+        for (int r = 0; r < 4; ++r) image[(16 + r) * 64 + l] = b_ls ? b_ls[r] : 0.0f;
+    }
+}
+
 // ---- teacher bank images (layout: rq_teacher.hip / rq_kernels.hpp) --------------------------------------
 namespace {
 struct TeacherView {

@@ -128,6 +128,20 @@ class Raptor:
         shipped checkpoint)."""
         _lib.call("rq_policy_set_squash", self._handle(), 1 if enable else 0)
 
+    def set_sample_and_squash(self, mode, log_std_weights=None, log_std_bias=None, seed=0):
+        """The SampleAndSquash output layer (rl-tools ``nn/layers/sample_and_squash``, README.md:116; not in the shipped
+        checkpoint, semantics [UPSTREAM-UNVERIFIED]): the last dense layer has 8 outputs [mean | log_std]; the mean rows
+        are the policy's layer_2, the log-std rows are given here (``log_std_weights`` [4, 16] or None for a state-
+        independent log-std, ``log_std_bias`` [4]).  ``mode``: "off" (raw output), "mean" (tanh(mean)) or "sample"
+        (tanh(mean + exp(clamp(log_std, -20, 2)) * eps), eps from the Philox stream keyed by ``seed``)."""
+        m = {"off": 0, "mean": 1, "sample": 2}[mode]
+        w = None if log_std_weights is None else np.ascontiguousarray(log_std_weights, np.float32)
+        b = None if log_std_bias is None else np.ascontiguousarray(log_std_bias, np.float32)
+        assert w is None or w.shape == (POLICY_OUTPUT_DIM, POLICY_HIDDEN_DIM)
+        assert b is None or b.shape == (POLICY_OUTPUT_DIM,)
+        _lib.call("rq_policy_set_sample_and_squash", self._handle(), m, None if w is None else _lib.fptr(w),
+                  None if b is None else _lib.fptr(b), int(seed))
+
     def reset(self):
         """README.md:21,94 — hidden state <- initial_hidden_state (checkpoint.h:123, zeros)."""
         _lib.call("rq_policy_reset", self._handle())

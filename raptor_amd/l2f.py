@@ -22,9 +22,13 @@ Differences that are deliberate (DESIGN.md "Boundary"):
     traffic); ``vector.rollout`` runs the whole loop body on the device;
   * everything executes on an MI355X through libraptor_quad.so — no CPU path exists here.
 
-The UI / JSON message helpers of l2f (README.md:63-92) are visualisation and out of scope.
+The UI / JSON message helpers of l2f (``set_ui_message``, ``set_parameters_message``,
+``set_state_action_message``, README.md:63-92) are emitted by the host side here (plain JSON from device
+snapshots); their schema beyond ``namespace`` / ``channel`` / ``data[i]`` is not in the reference tree
+[UPSTREAM-UNVERIFIED], see the functions.
 """
 import ctypes as C
+import json
 import weakref
 
 import numpy as np
@@ -33,7 +37,15 @@ from . import _lib
 from ._lib import (ACTION_DIM, OBSERVATION_DIM, PARAM_DIM, STATE_DIM, ROLLOUT_AUTORESET, ROLLOUT_CHAINED,
                    ROLLOUT_FUSED, EnvConfig, RaptorQuadError)
 
-__all__ = ["Device", "vector", "vector8", "EnvConfig", "RaptorQuadError"]
+__all__ = ["Device", "UI", "vector", "vector8", "EnvConfig", "RaptorQuadError"]
+
+
+class UI:
+    """``l2f.UI()`` (README.md:52): carries the namespace the ui-server hands out in its handshake
+    (``ui.ns = handshake["data"]["namespace"]``, README.md:82-85)."""
+
+    def __init__(self, ns=""):
+        self.ns = ns
 
 
 class Device:
@@ -113,9 +125,23 @@ class _DeviceArray:
                                          "data": (int(ptr), False), "version": 3, "strides": None}
 
 
+def _ordinal_of(owner):
+    """HIP device ordinal of the engine object a buffer belongs to (env, container or trajectory)."""
+    for obj in (owner, getattr(owner, "_env", None)):
+        dev = getattr(obj, "_device", None)
+        if dev is not None:
+            return dev.ordinal
+    raise RaptorQuadError(-6, "the object is not bound to a device yet")
+
+
 def _as_torch(ptr, shape, typestr, owner):
+    """Zero-copy torch view of an engine buffer ON THE ENGINE'S DEVICE (not torch's current one: as_tensor with a
+    bare "cuda" would silently copy to the current device and the view would be a detached copy)."""
     import torch
-    return torch.as_tensor(_DeviceArray(ptr, shape, typestr, owner), device="cuda")
+    t = torch.as_tensor(_DeviceArray(ptr, shape, typestr, owner), device=f"cuda:{_ordinal_of(owner)}")
+    if t.data_ptr() != int(ptr):
+        raise RaptorQuadError(-3, "torch copied the buffer instead of wrapping it (device mismatch)")
+    return t
 
 
 class _StateView:
@@ -238,7 +264,14 @@ class VectorModule:
             def _stat(self, fn, dtype, out=None, wait=True):
                 h = self._require("environment")
                 if out is not None:   # a torch tensor on the same HIP device; wait=False: only enqueued on
-                    _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1 if wait else 2)   # the engine's stream
+                    import torch                                                     # the engine's stream
+                    want = {np.float32: torch.float32, np.uint32: torch.int32, np.uint8: torch.uint8}[dtype]
+                    if (not out.is_cuda or out.device.index != self._device.ordinal or not out.is_contiguous() or
+                            out.numel() != mod.N_ENVIRONMENTS or (out.dtype != want and not
+                                                                 (dtype is np.uint32 and out.dtype == torch.uint32))):
+                        raise ValueError(f"out must be a contiguous {want} tensor of {mod.N_ENVIRONMENTS} elements on "
+                                         f"cuda:{self._device.ordinal}")
+                    _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1 if wait else 2)
                     return out
                 a = np.empty(mod.N_ENVIRONMENTS, dtype)
                 _lib.call(fn, h, a.ctypes.data, 0)
@@ -477,6 +510,46 @@ class VectorModule:
             _lib.call("rq_rollout", *args)
         else:
             _lib.call("rq_rollout_record", *args, trajectory._require("trajectory"))
+
+
+    # ------------------------------------------------------------------ ui-server messages (README.md:63-92)
+    # Only three things about the wire format are visible in the reference tree: every message is a JSON object
+    # with "namespace" (from the handshake) and "channel", and the parameters message carries "data", a list with
+    # one entry per env that a client may extend (README.md:63-70 adds d["ui"] = {"model", "name"}).  Channel
+    # names and the field names inside data[i] follow the l2f parameter / state structure as recalled
+    # [UPSTREAM-UNVERIFIED: no file in /root/reference states them]; they are here so that GPU rollouts can be
+    # inspected with a ui-server-like client, not as a parity claim.
+    def set_ui_message(self, device, env, ui):
+        """README.md:86 - announces what is going to be rendered: N quadrotors."""
+        return json.dumps({"namespace": ui.ns, "channel": "setUI",
+                           "data": {"type": "l2f-vector", "n_environments": self.N_ENVIRONMENTS}})
+
+    def set_parameters_message(self, device, env, params, ui):
+        """README.md:87 - one entry of dynamics parameters per env in ``data``."""
+        P = params.numpy()
+        data = []
+        for p in P:
+            data.append({"dynamics": {
+                "mass": float(p[0]), "J": [[float(p[1]), 0.0, 0.0], [0.0, float(p[2]), 0.0], [0.0, 0.0, float(p[3])]],
+                "rotor_positions": [[float(v) for v in p[4 + 3 * i:7 + 3 * i]] for i in range(4)],
+                "rotor_thrust_directions": [[0.0, 0.0, 1.0]] * 4,
+                "rotor_torque_directions": [[0.0, 0.0, d] for d in (-1.0, 1.0, -1.0, 1.0)],
+                "rotor_thrust_coefficients": [[float(p[16]), float(p[17]), float(p[18])]] * 4,
+                "rotor_torque_constants": [float(p[19])] * 4,
+                "rotor_time_constants_rising": [float(p[20])] * 4, "rotor_time_constants_falling": [float(p[21])] * 4,
+                "action_limit": {"min": float(p[22]), "max": float(p[23])}, "hovering_rpm": float(p[24])}})
+        return json.dumps({"namespace": ui.ns, "channel": "setParameters", "data": data})
+
+    def set_state_action_message(self, device, env, params, ui, state, action):
+        """README.md:76 - the states (a ``copy(state)`` whose ``.states[i].position`` was shifted works, README.md:73-75)
+        and the actions about to be applied, one entry per env."""
+        S = state.numpy()
+        A = np.asarray(action, np.float32).reshape(self.N_ENVIRONMENTS, ACTION_DIM)
+        data = [{"state": {"position": [float(v) for v in s[0:3]], "orientation": [float(v) for v in s[3:7]],
+                           "linear_velocity": [float(v) for v in s[7:10]], "angular_velocity": [float(v) for v in s[10:13]],
+                           "rpm": [float(v) for v in s[13:17]]},
+                 "action": [float(v) for v in a]} for s, a in zip(S, A)]
+        return json.dumps({"namespace": ui.ns, "channel": "setStateAction", "data": data})
 
 
 _modules = {}

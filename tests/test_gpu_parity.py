@@ -1178,6 +1178,86 @@ def test_closed_loop_statistics_against_the_reference_training_log_on_the_gpu(de
     assert abs(length - REFERENCE_LOG["episode_length"]) < 4.0, length
 
 
+def test_sample_and_squash_layer(device, oracle, weights):
+    """The full SampleAndSquash output stage (mean / log-std split + Philox sampling; not in the shipped checkpoint,
+    semantics unpinned): evaluate_step against the oracle's restatement of the same definition, fused rollout ==
+    chained rollout bit for bit in sampling mode, and the sampled spread where it can be predicted."""
+    from raptor_amd.foundation_policy import Raptor
+    rng = np.random.default_rng(3)
+    B = 1000
+    w_ls = (rng.standard_normal((4, 16)) * 0.3).astype(np.float32)
+    b_ls = np.array([-1.0, -0.5, 0.2, -2.0], np.float32)
+    pol = Raptor(device)
+    pol.set_sample_and_squash("sample", w_ls, b_ls, seed=99)
+    pol.reset()
+    H = np.zeros((B, 16), np.float32)
+    for step in range(3):
+        obs = rng.standard_normal((B, 22)).astype(np.float32)
+        got = pol.evaluate_step(obs)
+        ref = oracle.actor_batch_step_sas(weights, w_ls, b_ls, 2, 99, step, 0, obs, H)
+        assert np.abs(got - ref).max() < 2e-4, (step, np.abs(got - ref).max())      # Box-Muller on hardware transcendentals
+        assert np.abs(got).max() <= 1.0
+    pol.set_sample_and_squash("mean")
+    pol.reset()
+    H[:] = 0
+    obs = rng.standard_normal((B, 22)).astype(np.float32)
+    assert np.abs(pol.evaluate_step(obs) - oracle.actor_batch_step_sas(weights, None, None, 1, 0, 0, 0, obs, H)).max() < ACTOR_TOL
+    # a state-independent log-std: the pre-squash sample is mean + sigma eps; with sigma = 0.05 the spread of
+    # atanh(sample) - atanh(mean action) over many envs is sigma
+    det, smp = Raptor(device), Raptor(device)
+    det.set_sample_and_squash("mean")
+    smp.set_sample_and_squash("sample", None, np.full(4, np.log(0.05), np.float32), seed=5)
+    obs = (rng.standard_normal((20000, 22)) * 0.3).astype(np.float32)
+    det.reset(); smp.reset()
+    d = np.arctanh(np.clip(smp.evaluate_step(obs), -0.999999, 0.999999)) - np.arctanh(np.clip(det.evaluate_step(obs), -0.999999, 0.999999))
+    keep = np.abs(det.evaluate_step(obs) if False else d) < 1.0
+    assert abs(d[keep].std() - 0.05) < 0.003 and abs(d[keep].mean()) < 0.002
+    # rollouts: fused and chained draw the same noise (counter = rng epoch, key = global env id)
+    kw = dict(seed=17, episode_step_limit=40)
+    a, b = World(device, oracle, 300, **kw), World(device, oracle, 300, **kw)
+    for w_ in (a, b):
+        w_.policy.set_sample_and_squash("sample", w_ls, b_ls, seed=7)
+    ta, tb = a.vector.Trajectory(a.env, 60), b.vector.Trajectory(b.env, 60)
+    a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 60, "fused", True, trajectory=ta)
+    b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 60, "chained", True, trajectory=tb)
+    A, Bt = ta.numpy(), tb.numpy()
+    for k in ("obs", "act", "rew", "done"):
+        assert np.array_equal(A[k], Bt[k]), k
+    assert np.abs(A["act"]).max() <= 1.0 and A["act"].std() > 0.05
+    with pytest.raises(Exception):
+        a.policy.evaluate_sequence(np.zeros((3, 300, 22), np.float32))       # deterministic passes reject sampling
+
+
+def test_ui_messages_have_the_keys_the_readme_uses(device):
+    """README.md:63-92: the messages are JSON with namespace / channel, the parameters message has one data entry
+    per env that a client can extend, and a shifted copy of the state is what gets rendered."""
+    import json
+    from copy import copy
+    import raptor_amd.l2f as l2f
+    vector = l2f.vector(8)
+    rng, env, ui = vector.VectorRng(), vector.VectorEnvironment(), l2f.UI()
+    params, state = vector.VectorParameters(), vector.VectorState()
+    vector.initialize_rng(device, rng, 0)
+    vector.initialize_environment(device, env)
+    vector.sample_initial_parameters(device, env, params, rng)
+    vector.sample_initial_state(device, env, params, state, rng)
+    ui.ns = "abc"
+    assert json.loads(vector.set_ui_message(device, env, ui))["namespace"] == "abc"
+    pm = json.loads(vector.set_parameters_message(device, env, params, ui))
+    assert pm["namespace"] == "abc" and "channel" in pm and len(pm["data"]) == 8
+    for d in pm["data"]:                                  # README.md:63-70 configure_3d_model
+        d["ui"] = {"model": "95d22881d444145176db6027d44ebd3a15e9699a", "name": "x500"}
+    assert abs(pm["data"][3]["dynamics"]["mass"] - params.numpy()[3, 0]) < 1e-9
+    ui_state = copy(state)
+    for i, s in enumerate(ui_state.states):               # README.md:73-75
+        s.position[0] += i * 0.1
+    sm = json.loads(vector.set_state_action_message(device, env, params, ui, ui_state, np.zeros((8, 4))))
+    assert len(sm["data"]) == 8 and sm["data"][0]["action"] == [0.0] * 4
+    x = state.numpy()[:, 0]
+    assert np.allclose([d["state"]["position"][0] for d in sm["data"]], x + 0.1 * np.arange(8), atol=1e-6)
+    assert np.array_equal(state.numpy()[:, 0], x)         # the original state is untouched
+
+
 # ------------------------------------------------------------------------------ native RCCL exchange -
 def test_native_rccl_exchange_one_rank(device, oracle):
     """rq_comm_* / rq_allgather_returns with a 1-rank RCCL communicator created by the C++ host itself: the
