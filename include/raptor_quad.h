@@ -145,7 +145,9 @@ typedef struct rq_env_config {
     float reward_scale, reward_constant, reward_termination_penalty;
     float reward_position, reward_orientation, reward_linear_velocity,
           reward_angular_velocity, reward_action;
-    /* termination: |p_i| > .., |v_i| > .., |w_i| > .. (any axis) or any non-finite state     */
+    /* termination: |p_i| > .. (default 1 m: the value at which the shipped policy reproduces the share_terminated /
+     * episode_length of the reference's own training log), |v_i| > .., |w_i| > .. (any axis)
+     * or any non-finite state */
     uint32_t termination_enabled;
     float termination_position, termination_linear_velocity, termination_angular_velocity;
 } rq_env_config;

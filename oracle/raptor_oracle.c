@@ -113,7 +113,7 @@ ORC_EXPORT void orc_default_config(rq_env_config* c) {
     c->reward_position = 1.0f; c->reward_orientation = 0.1f; c->reward_linear_velocity = 0.01f;
     c->reward_angular_velocity = 0.001f; c->reward_action = 0.01f;
     c->termination_enabled = 1;
-    c->termination_position = 3.0f;
+    c->termination_position = 1.0f;      /* see rq_env_default_config (raptor_amd/csrc/rq_capi.cpp): the reference's own log */
     c->termination_linear_velocity = 1000.0f;
     c->termination_angular_velocity = 1000.0f;
 }
