@@ -131,7 +131,7 @@ def fused_kernel_name(precision, n, steps_per_launch):
     if precision == "bf16":
         actor = "rq::ActorBF16Lean" if n > 65536 else "rq::ActorBF16"
     else:
-        actor = "rq::ActorF32T<true> " if (n > 65536 or steps_per_launch >= 48) else "rq::ActorF32T<false> "
+        actor = "rq::ActorF32T<true> " if (n > 65536 or steps_per_launch >= 28) else "rq::ActorF32T<false> "
     return f"rq::k_rollout_fused<false, true, false, false, {actor}>"     # <NOISE, AUTORESET, RECORD, SAS, ACTOR>
 
 
@@ -191,17 +191,18 @@ def kernel_probe(device, n, reps):
                      "achieved_GBps": round(gbps, 1), "peak_GBps": PEAK_HBM_GBPS,
                      "frac": round(gbps / PEAK_HBM_GBPS, 4),
                      "traffic": None if tr is None else tr["bytes_per_launch"]}
-    # What a standalone launch of this size can reach at all: back-to-back launches of a kernel that only stores
-    # one float per thread on the same grid take `floor` us each (rq_device_launch_floor, HIP events), and the
-    # bytes cannot arrive faster than the measured copy ceiling (6.29 TB/s, MI355X_MICROARCH.md) - so a launch
-    # takes >= floor + bytes / ceiling, which caps its fraction of the 8 TB/s spec well below 1 for small batches.
+    # A standalone launch at 65 536 envs is launch-latency-bound and its 20-30 MB working set sits in the 256 MiB
+    # Infinity Cache, so its fraction of the HBM peak is not a bandwidth statement.  Split it instead: back-to-back
+    # launches of a kernel that only stores one float per thread on the same grid take `near_empty_launch_us` each
+    # (rq_device_launch_floor, HIP events); the rest of the launch is the phase that moves this kernel's bytes.
     floor_us = device.launch_floor(n, 200)
     for name in ("k_observe", "k_actor_step", "k_step"):
         nb = out[name]["bytes_per_env"] * n
-        t_min = floor_us + nb / 6.29e12 * 1e6
-        out[name]["structural_bound"] = {"near_empty_launch_us": round(floor_us, 3), "copy_ceiling_GBps": 6290.0,
-                                         "min_launch_us": round(t_min, 3),
-                                         "max_frac_of_peak": round(nb / (t_min * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4)}
+        data_us = max(out[name]["us_per_launch"] - floor_us, 1e-3)
+        out[name]["launch_split"] = {"near_empty_launch_us": round(floor_us, 3), "data_phase_us": round(data_us, 3),
+                                     "data_phase_GBps": round(nb / (data_us * 1e-6) / 1e9, 1),
+                                     "working_set_MB": round(nb / 1e6, 1),
+                                     "resident_in_infinity_cache": bool(nb < 256 * 2 ** 20)}
     return out
 
 
@@ -415,24 +416,39 @@ def main():
             dist.barrier()
 
     def timed_region(plan):
-        """exactly sum(plan) steps, barrier + synchronize before, synchronize + barrier after -> (wall s, ms of the region's LAST
-        rollout launch).  Fused mode: that launch's own begin/end timestamps (rq_device_last_rollout_ms, the figure
-        rocprofv3 prints per dispatch); chained mode: HIP events around the whole region divided by its steps."""
+        """exactly sum(plan) steps, barrier + synchronize before, synchronize + barrier after -> wall seconds"""
         sync_all()
         t0 = time.perf_counter()
-        if args.mode != "fused":
-            device.timer_start()
         run(plan)
-        launch_ms = device.timer_stop() / sum(plan) if args.mode != "fused" else None   # chained: ms per step
         finish()
         device.synchronize()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0              # this rank's clock stops when ITS work is done: the max over
         if dist is not None:                         # ranks is taken afterwards, so the closing barrier is not timed
             dist.barrier()
-        if launch_ms is None:
-            launch_ms = device.last_rollout_ms()     # after the clock is stopped: the event query is not timed
-        return wall, launch_ms
+        return wall
+
+    def kernel_probe_ms(plan, repetitions):
+        """Median duration (ms) of one rollout launch of the kind `plan` ends with.  Fused mode: the regions are run
+        again with kernel-level timing on (rq_device_set_rollout_timing: the kernel's own begin / end timestamps, the
+        figure rocprofv3 prints per dispatch; it costs ~8 us of dispatch per launch, which is why the timed regions
+        above run without it).  Chained mode: HIP events around a whole region, per step."""
+        out = []
+        if args.mode == "fused":
+            device.set_rollout_timing(True)
+        for _ in range(repetitions):
+            sync_all()
+            if args.mode == "fused":
+                run(plan)
+                finish()
+                out.append(device.last_rollout_ms())
+            else:
+                device.timer_start()
+                run(plan)
+                out.append(device.timer_stop() / sum(plan))
+                finish()
+        device.set_rollout_timing(False)
+        return float(np.median(out))
 
     # ---- warm-up: one-off costs first (RCCL communicator, first barrier, lazy allocations), then EXACTLY
     # --warmup untimed steps of the same rollout ----
@@ -445,11 +461,9 @@ def main():
 
     # ---- timed regions: each exactly --steps steps; repeated, the median counts (module docstring) ----
     plan = chunks(args.steps, EPISODE)
-    walls, kernels = [], []
+    walls = []
     while True:
-        w_s, k_ms = timed_region(plan)
-        walls.append(w_s)
-        kernels.append(k_ms)
+        walls.append(timed_region(plan))
         total = sum(walls)
         if dist is not None:      # every rank must take the same decision: the slowest rank's clock decides
             t = torch.tensor([total], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -462,15 +476,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls = t.tolist()
     elapsed = float(np.median(walls))
-    launch_ms = float(np.median(kernels))         # median over the regions of one rollout launch's duration
+    launch_ms = kernel_probe_ms(plan, min(len(walls), 50))     # one rollout launch of the region's kind
 
     # ---- steady state: 10 x 500-step launches back to back (clocks are warm now), one region ----
     steady = None
     if args.mode == "fused":
         ss_plan = [EPISODE] * 10
         run(ss_plan)                              # untimed: 17 ms of load, the clocks reach their steady state
-        ss_wall, ss_launch_ms = timed_region(ss_plan)
-        ss_kernel_ms = ss_launch_ms * len(ss_plan)
+        ss_wall = timed_region(ss_plan)
+        ss_kernel_ms = kernel_probe_ms(ss_plan, 3) * len(ss_plan)
         if dist is not None:
             t = torch.tensor([ss_wall], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -486,7 +500,7 @@ def main():
                   "achieved_TFLOPs": round(ss_flops, 3), "peak_TFLOPs": PEAK_FP32_TFLOPS,
                   "frac": round(ss_flops / PEAK_FP32_TFLOPS, 4),
                   "note": "same process, after the timed regions and 10 untimed launches of the same kind; wall = barrier + synchronize on both sides, "
-                          "max over ranks; kernel = begin/end timestamps of the last of the 10 launches on rank 0"}
+                          "max over ranks; kernel = the kernel's own begin/end timestamps, last launch of such a region, on rank 0"}
 
     value = n_total * args.steps / elapsed
     result = {
@@ -548,7 +562,8 @@ def main():
                         f"{BYTES_FUSED_LAUNCH} B/env per launch of {int(steps_per_launch)} steps; the measured `traffic` adds "
                         "the operand image every wave loads and the loop-invariant registers parked in scratch before "
                         "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own begin/end "
-                        "timestamps (last launch of a region, median over the regions); short launches carry the "
+                        "timestamps, median over up to 50 further regions run with kernel-level timing on (the timed "
+                        "regions run without it: it costs ~8 us of dispatch per launch); short launches carry the "
                         "kernel's prologue and epilogue (see steady_state for 500-step launches)",
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
                 "steps_per_launch": steps_per_launch,

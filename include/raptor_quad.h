@@ -172,9 +172,11 @@ RQ_API int rq_device_synchronize(rq_device* dev);
 /* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
 RQ_API int rq_device_timer_start(rq_device* dev);
 RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
-/* Duration of the most recent FUSED rollout kernel launched on this device (rq_rollout / rq_rollout_record in
- * RQ_ROLLOUT_FUSED mode): the kernel's own begin and end timestamps (hipExtLaunchKernel events), i.e. the figure
- * rocprofv3 --kernel-trace prints for that dispatch.  Waits for that kernel to finish. */
+/* Kernel-level timing of fused rollouts, off by default: while enabled every fused rollout kernel is launched with
+ * two events that take the kernel's own begin and end timestamps (hipExtLaunchKernel; costs ~8 us of dispatch per
+ * launch, measured), and rq_device_last_rollout_ms returns the duration of the most recent one - the figure
+ * rocprofv3 --kernel-trace prints for that dispatch - after waiting for it to finish. */
+RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
 RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
 /* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
  * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves

@@ -47,7 +47,8 @@ struct rq_device {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_kbegin = nullptr, ev_kend = nullptr;   // begin / end of the most recent fused rollout kernel
-    bool k_timed = false;
+    bool k_timing = false;         // rq_device_set_rollout_timing
+    bool k_timed = false;          // a launch carried the two events
     void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
     float* rows = nullptr;         // device scratch, row-major side of the GPU layout changes (large batches)
     size_t rows_bytes = 0;
@@ -484,9 +485,17 @@ RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms) {
     return RQ_OK;
 }
 
+RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    dev->k_timing = enable != 0;
+    if (!dev->k_timing) dev->k_timed = false;
+    return RQ_OK;
+}
+
 RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
     RQ_REQUIRE(dev && kernel_ms, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    RQ_REQUIRE(dev->k_timed, RQ_ERR_NOT_INITIALIZED, "no fused rollout was launched on this device yet");
+    RQ_REQUIRE(dev->k_timed, RQ_ERR_NOT_INITIALIZED,
+               "no fused rollout was launched on this device with rq_device_set_rollout_timing enabled");
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipEventSynchronize(dev->ev_kend));
     RQ_HIP(hipEventElapsedTime(kernel_ms, dev->ev_kbegin, dev->ev_kend));
@@ -1155,8 +1164,8 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
                                         policy->precision, sas_of(policy, rng->epoch, nullptr, env->offset), tp,
-                                        dev->ev_kbegin, dev->ev_kend));
-        dev->k_timed = n_steps > 0;
+                                        dev->k_timing ? dev->ev_kbegin : nullptr, dev->k_timing ? dev->ev_kend : nullptr));
+        dev->k_timed = dev->k_timing && n_steps > 0;
     } else {
         // one step = observe -> evaluate_step -> step (-> record) on the stream
         auto enqueue_step = [&](uint32_t epoch, const uint32_t* epoch_base, uint32_t t_record) -> hipError_t {

@@ -70,8 +70,12 @@ class Device:
         _lib.call("rq_device_timer_stop", self._h, C.byref(ms))
         return float(ms.value)
 
+    def set_rollout_timing(self, enable):
+        """Kernel-level timing of fused rollouts (begin/end timestamps of the kernel itself; ~8 us per launch)."""
+        _lib.call("rq_device_set_rollout_timing", self._h, 1 if enable else 0)
+
     def last_rollout_ms(self):
-        """Duration (ms) of the most recent fused rollout kernel on this device: its own begin/end timestamps."""
+        """Duration (ms) of the most recent fused rollout kernel launched while ``set_rollout_timing(True)``."""
         ms = C.c_float()
         _lib.call("rq_device_last_rollout_ms", self._h, C.byref(ms))
         return float(ms.value)

@@ -97,9 +97,12 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
             f.write(f"| `{name}` | {len(d)} | {sum(d) / len(d):.2f} | {ds[len(ds) // 2]:.2f} | {ds[0]:.2f} | {ds[-1]:.2f} |\n")
         rl, ss, tm = b.get("roofline", {}), b.get("steady_state", {}), b.get("timing", {})
         f.write(f"\nbench.py in the same (profiled) run: timed regions of {b['steps']} steps x {tm.get('repetitions')} repetitions, "
-                f"`roofline.kernel` = `{rl.get('kernel')}`, `roofline.avg_launch_ms` = {rl.get('avg_launch_ms')} "
-                f"(HIP events, median region; includes the enqueue of the returns copy); `steady_state.kernel` = "
-                f"`{ss.get('kernel')}`, `steady_state.avg_launch_ms` = {ss.get('avg_launch_ms')}.\n")
+                f"`roofline.kernel` = `{rl.get('kernel')}`, `roofline.avg_launch_ms` = {rl.get('avg_launch_ms')}; "
+                f"`steady_state.kernel` = `{ss.get('kernel')}`, `steady_state.avg_launch_ms` = {ss.get('avg_launch_ms')}.  "
+                "bench.py takes these from the kernels' own begin/end timestamps (hipExtLaunchKernel events): in an "
+                "un-profiled run they equal the per-dispatch durations above (the same command un-profiled on the same "
+                "kind of box: DESIGN.md section 6); under rocprofv3 itself the profiler's signal handling inflates them "
+                "by ~15 us per launch, so the profiled run's own figure reads high.\n")
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
     f.write("| kernel@grid | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|\n")
     for k, d in out.items():
