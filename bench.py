@@ -397,9 +397,14 @@ def main():
     if native:
         post = lambda: exchange.post(shard.env)                                            # noqa: E731
         finish = lambda: exchange.finish(to_host=False)                                    # noqa: E731
+    elif why == "single rank":
+        # one rank: nothing to exchange - the episode returns stay where the engine keeps them (rq_env_get_finished_returns)
+        exchange_kind = "none (one rank: nothing to gather)"
+        exchange = None
+        post = lambda: None                                                                # noqa: E731
+        finish = lambda: None                                                              # noqa: E731
     else:
-        exchange_kind = ("none: one rank, the returns are only copied out behind each rollout" if why == "single rank" else
-                         f"torch.distributed all_gather_into_tensor (native communicator unavailable: {why})")
+        exchange_kind = f"torch.distributed all_gather_into_tensor (native communicator unavailable: {why})"
         exchange = ReturnsExchange(n, n_total, f"cuda:{local_rank}", engine_stream=device.stream)
         post = lambda: exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))   # noqa: E731
         finish = exchange.finish
@@ -585,8 +590,9 @@ def main():
             result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        result["config"]["exchanges_per_timed_region"] = len(plan)
-        gathered = exchange.finish()          # numpy (native) or tensor (torch): the last all-gathered returns
+        result["config"]["exchanges_per_timed_region"] = len(plan) if exchange is not None else 0
+        # numpy (native) or tensor (torch): the last all-gathered returns; one rank: the env's own
+        gathered = exchange.finish() if exchange is not None else shard.env.finished_returns()
         result["config"]["gathered_returns"] = int(np.prod(gathered.shape))
         result["config"]["exchange"] = exchange_kind
         # RCCL / the HIP runtime print banners through C stdio, which a redirected stdout only flushes at exit:

@@ -638,6 +638,11 @@ struct ActorF32T {
             }
             transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
         }
+        // MFMAs are issued in uninterrupted batches: an f32 MFMA and VALU work never co-execute, and every
+        // MFMA -> VALU -> MFMA round trip in the instruction stream costs ~5.8 ns of pipeline turnaround on top
+        // (tools/overlap.hip: one MFMA + 2 FMAs = 23.9 ns against 14.1 + 2 x 2.1); left alone the scheduler
+        // interleaves single MFMAs with the transposes and the gate arithmetic (23 batches per step instead of 5)
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 y0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0], X[0][t], zero);
@@ -645,6 +650,7 @@ struct ActorF32T {
         for (int s = 1; s < 6; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0 + s], X[s][t], y0[t]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -661,6 +667,7 @@ struct ActorF32T {
             const f32x4 cbz = {W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]};
             const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
             const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < TP; ++u) {
                 gr[u] = mfma16(W[QW_GI + 0], y0[t0 + u][0], cbr);
@@ -684,9 +691,10 @@ struct ActorF32T {
                     gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
                     gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
                 }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < TP; ++u) gru_gates_prescaled(gr[u], gz[u], gni[u], gnh[u], hQ[t0 + u]);
-            if (LEAN) __builtin_amdgcn_sched_barrier(0);   // keep the two passes apart (register footprint)
+            __builtin_amdgcn_sched_barrier(0);
         }
         // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
         const f32x4 cb2 = {W[QW_B2], W[QW_B2 + 1], W[QW_B2 + 2], W[QW_B2 + 3]};
@@ -701,6 +709,7 @@ struct ActorF32T {
             d0 = mfma16(W[QW_L2 + 8 + s], hQ[2][s], d0);
             d1 = mfma16(W[QW_L2 + 12 + s], hQ[3][s], d1);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
     }
