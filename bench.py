@@ -131,7 +131,7 @@ def fused_kernel_name(precision, n, steps_per_launch):
     if precision == "bf16":
         actor = "rq::ActorBF16Lean" if n > 65536 else "rq::ActorBF16"
     else:
-        actor = "rq::ActorF32T<true> " if (n > 65536 or steps_per_launch >= 28) else "rq::ActorF32T<false> "
+        actor = "rq::ActorF32T<true> " if n > 65536 else "rq::ActorF32T<false> "
     return f"rq::k_rollout_fused<false, true, false, false, {actor}>"     # <NOISE, AUTORESET, RECORD, SAS, ACTOR>
 
 

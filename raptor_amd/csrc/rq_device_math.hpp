@@ -656,10 +656,9 @@ struct ActorF32T {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y0[t][r] = relu(y0[t][r]);
 
-        // GRU, two tiles at a time (TILES_PER_PASS): 4 accumulators per tile are live per pass, so the
-        // LEAN variant (2 waves/SIMD, 256 registers) halves the accumulator footprint; the arithmetic and
-        // its order per tile are identical in both variants
-        constexpr int TP = LEAN ? 2 : 4;   // (measured: 1, 2 or 4 tiles per pass are within 2 % at 1 wave/SIMD)
+        // GRU, two tiles at a time: 4 accumulators per tile are live per pass (with all four tiles in flight the
+        // 512-register build parked MFMA operands in AGPRs and copied them back, ~25 v_accvgpr moves per step)
+        constexpr int TP = 2;
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TP) {
             f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];

@@ -710,13 +710,12 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
         else       { if (ar) RQ_LAUNCH_FUSED_RC(false, true, ACT); else RQ_LAUNCH_FUSED_RC(false, false, ACT); } \
     } while (0)
     const bool rec = traj.obs != nullptr;
-    // Two builds of the same loop: a 512-register one (one wave per SIMD) and a 256-register "lean" one
-    // (two waves per SIMD, GRU two tiles at a time).  Beyond 65 536 envs (1024 SIMDs x 64 lanes) the lean
-    // build wins because two waves share a SIMD.  For the fp32 actor it also wins at one wave per SIMD
-    // (measured 3.47 vs 3.76 us/step at 65 536 envs: under the tighter budget the allocator stops parking
-    // MFMA operands in AGPRs and copying them back) but costs ~7 us more per launch (its prologue parks loop
-    // invariants in scratch), so launches below 28 steps keep the 512-register build.  bf16: the reverse at <= 65 536.
-    const bool lean = b.n > 65536u || (precision != RQ_POLICY_BF16_MFMA && n_steps >= 28u);
+    // Two builds of the same loop (same arithmetic, GRU two tiles at a time): a 512-register one for one wave per
+    // SIMD - every batch up to 65 536 envs (1024 SIMDs x 64 lanes) - and a 256-register one, two waves per SIMD,
+    // beyond.  The 256-register build parks loop invariants in scratch before the loop (~7 us per launch); at one
+    // wave per SIMD both run the loop at the same speed (3.21 vs 3.23 us/step), so the small batches take the
+    // build with the cheaper prologue.
+    const bool lean = b.n > 65536u;
     if (sas.mode != RQ_SAS_OFF) {
         if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_SAS_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_SAS_ACT(ActorF32Lean);
     }
