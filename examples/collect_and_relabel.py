@@ -15,6 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raptor_amd.l2f as l2f                       # noqa: E402
 from raptor_amd.foundation_policy import Raptor, load_weights   # noqa: E402
+from raptor_amd.teachers import TeacherBank, parameter_count    # noqa: E402
 
 
 def main():
@@ -48,12 +49,22 @@ def main():
     device.synchronize()
     t2 = time.perf_counter()
 
+    # the distillation step proper (README.md:208-216): every quadrotor has ITS teacher, an MLP; here 64 random
+    # 22-64-64-4 teachers stand in for the trained ones and env i is labelled by teacher i % 64 - one launch
+    n_teachers = 64
+    bank = TeacherBank(device, (np.random.default_rng(1).standard_normal((n_teachers, parameter_count(22, 64, 64))) * 0.1)
+                       .astype(np.float32), 22, 64, 64, "relu", "tanh")
+    traj.relabel_teachers(bank, np.arange(env.N_ENVIRONMENTS) % n_teachers, overwrite=True, fetch=False)
+    device.synchronize()
+    t3 = time.perf_counter()
+
     batch = traj.tensors()                                   # torch views, field-major: obs [T, 22, ld], act [T, 4, ld]
     n = env.N_ENVIRONMENTS
     obs, target = batch["obs"][:, :, :n], batch["act"][:, :, :n]
     episodes = int((batch["done"][:, :n] != 0).sum().item())
     print(f"{n} envs x {args.steps} steps: collected in {(t1 - t0) * 1e3:.1f} ms "
-          f"({n * args.steps / (t1 - t0):.3g} transitions/s), relabelled in {(t2 - t1) * 1e3:.1f} ms; "
+          f"({n * args.steps / (t1 - t0):.3g} transitions/s), relabelled in {(t2 - t1) * 1e3:.1f} ms by a policy of the "
+          f"student's topology and in {(t3 - t2) * 1e3:.1f} ms by a bank of {n_teachers} MLP teachers; "
           f"{episodes} episode ends; learner tensors obs {tuple(obs.shape)} target {tuple(target.shape)} "
           f"on {obs.device}, mean |target| {target.abs().mean().item():.3f}")
 
