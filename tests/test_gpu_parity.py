@@ -1402,3 +1402,38 @@ def test_teacher_bank_at_full_batch(device, oracle):
     assert np.abs(got - ref).max() < 1e-5, np.abs(got - ref).max()
     bank.set_precision("bf16")
     assert np.abs(tr.relabel_teachers(bank, ids) - ref).max() < 5e-2
+
+
+def test_teacher_bank_edge_cases(device, oracle):
+    """One env, one step, one teacher; an empty trajectory; a bank whose teachers nobody uses; bad arguments."""
+    from raptor_amd.teachers import TeacherBank, parameter_count
+    rng = np.random.default_rng(8)
+    w = World(device, oracle, 1, seed=51)
+    tr = w.vector.Trajectory(w.env, 2)
+    W = _teacher_weights(rng, 3, 22, 16, 16)
+    bank = TeacherBank(device, W, 22, 16, 16, "tanh", "identity")
+    out = tr.relabel_teachers(bank, np.array([2], np.uint32))            # nothing recorded yet
+    assert out.shape == (0, 1, 4)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 1, "fused", True, trajectory=tr)
+    got = tr.relabel_teachers(bank, np.array([2], np.uint32))
+    ref = oracle.teacher_relabel(W, 22, 16, 16, 2, 0, tr.numpy()["obs"], np.array([2], np.uint32))
+    assert got.shape == (1, 1, 4) and np.abs(got - ref).max() < 1e-5
+    for bad in (dict(in_dim=23), dict(h1=48), dict(hidden_activation="identity")):
+        kw = dict(in_dim=22, h1=16, h2=16, hidden_activation="relu", output_activation="identity")
+        kw.update(bad)
+        with pytest.raises(Exception):
+            TeacherBank(device, np.zeros((1, parameter_count(kw["in_dim"], kw["h1"], kw["h2"])), np.float32), **kw)
+    with pytest.raises(ValueError):
+        TeacherBank(device, np.zeros((2, 7), np.float32))                 # wrong parameter count
+
+
+def test_native_exchange_resizes_with_the_env(device, oracle):
+    """One communicator serving envs of different sizes in turn (buffers are re-sized, results never mix)."""
+    from raptor_amd.distributed import NativeReturnsExchange
+    ex = NativeReturnsExchange(device, 1, 0, NativeReturnsExchange.unique_id())
+    for n in (100, 5000, 64):
+        w = World(device, oracle, n, seed=60 + n, episode_step_limit=10)
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 10, "fused", True)
+        ex.post(w.env)
+        got = ex.finish()
+        assert got.shape == (n,) and np.array_equal(got, w.env.finished_returns())
