@@ -92,13 +92,15 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f32(uint32_t ld, uint
     const bool valid = e0 != 0xFFFFFFFFu;
     const uint32_t e = valid ? e0 : 0u;                 // padding lanes shadow env 0: MFMA ignores EXEC
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    float X[6];
+    float X[6], X1[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) X[s] = load_input(obs, t_begin, ld, e, 4 * s + q, in_dim);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) X1[s] = load_input(obs, t_begin + 1 < t_end ? t_begin + 1 : t_begin, ld, e, 4 * s + q, in_dim);
     for (uint32_t t = t_begin; t < t_end; ++t) {
         float Xn[6];
-        const uint32_t tn = t + 1 < t_end ? t + 1 : t;   // next step's operands in flight behind this step's MFMAs
-#pragma unroll
+        const uint32_t tn = t + 2 < t_end ? t + 2 : t;   // operands two steps ahead in flight behind the MFMAs (one
+#pragma unroll                                            // step is ~1.6 us, about the latency of an HBM miss)
         for (int s = 0; s < 6; ++s) Xn[s] = load_input(obs, tn, ld, e, 4 * s + q, in_dim);
         f32x4 y1[M1], y2[M2];
 #pragma unroll
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f32(uint32_t ld, uint
             for (int r = 0; r < 4; ++r) act[((size_t)t * RQ_ACTION_DIM + r) * ld + e0] = teacher_act<OUT_ACT>(o[r]);
         }
 #pragma unroll
-        for (int s = 0; s < 6; ++s) X[s] = Xn[s];
+        for (int s = 0; s < 6; ++s) { X[s] = X1[s]; X1[s] = Xn[s]; }
     }
 }
 
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(64, 4) void k_teacher_relabel_bf16(uint32_t ld, uin
     for (int s = 0; s < 6; ++s) X[s] = load_input(obs, t_begin, ld, e, 4 * s + q, in_dim);
     for (uint32_t t = t_begin; t < t_end; ++t) {
         float Xn[6];
-        const uint32_t tn = t + 1 < t_end ? t + 1 : t;
+        const uint32_t tn = t + 1 < t_end ? t + 1 : t;   // one step ahead (two, as in the f32 kernel, measured slower here)
 #pragma unroll
         for (int s = 0; s < 6; ++s) Xn[s] = load_input(obs, tn, ld, e, 4 * s + q, in_dim);
         // k-slot e of lane-group q carries feature 4e + q (e < 6), as in the student's bf16 layer_0
