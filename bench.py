@@ -11,8 +11,8 @@ step -> assign for every environment (README.md:96-99).  Workload = BASELINE.jso
 randomised parameters, synthetic (seeded Philox) initial states, the shipped RAPTOR checkpoint
 as the policy.  Auto-reset keeps every env stepping, so every counted env-step is a real one.
 Multi-GPU is weak scaling: each rank owns 65 536 envs (global ids rank*65536 ...), no data-path
-collective, one all-gather of episode returns per 500-step episode (RCCL over xGMI), enqueued behind
-the rollout that produced them and overlapped with the next one.
+collective, one all-gather of episode returns per 500-step episode (RCCL over xGMI, issued by the C++ host:
+rq_allgather_returns), enqueued behind the rollout that completed the episode and overlapped with the next one.
 
 Timing: after exactly --warmup untimed steps, the timed region - exactly --steps steps (one fused launch
 per <= 500 of them + one exchange each), bracketed by barrier + synchronize on both sides - is REPEATED
@@ -409,10 +409,18 @@ def main():
         post = lambda: exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))   # noqa: E731
         finish = exchange.finish
 
+    # The exchange belongs to the EPISODE (500 steps of simulated time), not to a rollout call: a region shorter
+    # than an episode carries its share - one all-gather every 500 steps across regions (a 20-step region posts one
+    # in 25 regions; `timing` reports the mean region beside the median for that reason).
+    since_exchange = [0]
+
     def run(plan):
         for c in plan:
             shard.rollout(c, args.mode)
-            post()
+            since_exchange[0] += c
+            if since_exchange[0] >= EPISODE:
+                since_exchange[0] -= EPISODE
+                post()
 
     def sync_all():
         device.synchronize()
@@ -523,7 +531,8 @@ def main():
                    "device": torch.cuda.get_device_name(local_rank), "hip_runtime": torch.version.hip},
         "timing": {"repetitions": len(walls), "steps_per_region": args.steps, "statistic": "median",
                    "region_ms": {"first": round(walls[0] * 1e3, 4), "min": round(min(walls) * 1e3, 4),
-                                 "median": round(elapsed * 1e3, 4), "max": round(max(walls) * 1e3, 4)},
+                                 "median": round(elapsed * 1e3, 4), "mean": round(float(np.mean(walls)) * 1e3, 4),
+                                 "max": round(max(walls) * 1e3, 4)},
                    "untimed_steps_before_first_region": args.warmup + 1},
     }
     if steady is not None:
@@ -590,9 +599,11 @@ def main():
             result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        result["config"]["exchanges_per_timed_region"] = len(plan) if exchange is not None else 0
+        result["config"]["exchanges_per_timed_region"] = round(args.steps / EPISODE, 4) if exchange is not None else 0
         # numpy (native) or tensor (torch): the last all-gathered returns; one rank: the env's own
-        gathered = exchange.finish() if exchange is not None else shard.env.finished_returns()
+        gathered = exchange.finish() if exchange is not None else None
+        if gathered is None:
+            gathered = shard.env.finished_returns()
         result["config"]["gathered_returns"] = int(np.prod(gathered.shape))
         result["config"]["exchange"] = exchange_kind
         # RCCL / the HIP runtime print banners through C stdio, which a redirected stdout only flushes at exit:
