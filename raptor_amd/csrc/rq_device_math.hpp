@@ -781,20 +781,25 @@ struct ActorBF16 {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             y0[t] = mfma(wl0, pack_bf16x8(X[0][t], X[1][t], X[2][t], X[3][t], X[4][t], X[5][t], 0.f, 0.f), zero);
+        // gate rows pre-scaled (before the bf16 rounding) and pre-scaled biases through the C operand, as in the
+        // f32 image: the accumulators are the exp2 arguments (gru_gates_prescaled)
+        const f32x4 cbr = {B[BW_BR - BW_BR], B[BW_BR - BW_BR + 1], B[BW_BR - BW_BR + 2], B[BW_BR - BW_BR + 3]};
+        const f32x4 cbz = {B[BW_BZ - BW_BR], B[BW_BZ - BW_BR + 1], B[BW_BZ - BW_BR + 2], B[BW_BZ - BW_BR + 3]};
+        const f32x4 cbni = {B[BW_BNI - BW_BR], B[BW_BNI - BW_BR + 1], B[BW_BNI - BW_BR + 2], B[BW_BNI - BW_BR + 3]};
+        const f32x4 cbnh = {B[BW_BNH - BW_BR], B[BW_BNH - BW_BR + 1], B[BW_BNH - BW_BR + 2], B[BW_BNH - BW_BR + 3]};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bf16x8 xh = pack_bf16x8(relu(y0[t][0]), relu(y0[t][1]), relu(y0[t][2]),
                                           relu(y0[t][3]), hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3]);
-            gr[t] = mfma(wr, xh, zero);
-            gz[t] = mfma(wz, xh, zero);
-            gni[t] = mfma(wni, xh, zero);
-            gnh[t] = mfma(wnh, xh, zero);
+            gr[t] = mfma(wr, xh, cbr);
+            gz[t] = mfma(wz, xh, cbz);
+            gni[t] = mfma(wni, xh, cbni);
+            gnh[t] = mfma(wnh, xh, cbnh);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            gru_gates_q(gr[t], gz[t], gni[t], gnh[t], &B[BW_BR - BW_BR], &B[BW_BZ - BW_BR], &B[BW_BNI - BW_BR],
-                        &B[BW_BNH - BW_BR], hQ[t]);
-        f32x4 d0 = zero, d1 = zero;
+        for (int t = 0; t < 4; ++t) gru_gates_prescaled(gr[t], gz[t], gni[t], gnh[t], hQ[t]);
+        const f32x4 cb2 = {B[BW_B2 - BW_BR], B[BW_B2 - BW_BR + 1], B[BW_B2 - BW_BR + 2], B[BW_B2 - BW_BR + 3]};
+        f32x4 d0 = cb2, d1 = zero;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bf16x8 hb = pack_bf16x8(hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3], 0.f, 0.f, 0.f, 0.f);
@@ -802,7 +807,7 @@ struct ActorBF16 {
             else       d0 = mfma(a_op(BW_L2 + 4 * t), hb, d0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = (d0[r] + d1[r]) + B[BW_B2 - BW_BR + r];
+        for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
     }
 };
 

@@ -66,12 +66,15 @@ void pack_policy_bf16(const float* w, float* packed) {
         for (int e = 0; e < 8; ++e) {
             const int f = 4 * e + q;
             put(BW_L0, e, e < 6 ? (f < 22 ? w[W0 + i * 22 + f] : (f == 22 ? w[B0 + i] : 0.0f)) : 0.0f);
+            // gate rows pre-scaled BEFORE the bf16 rounding (r, z by -log2 e, n by -2 log2 e): the accumulators are
+            // the exp2 arguments of gru_gates_prescaled, as in the f32 image
+            const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
             const float wi_r = e < 4 ? w[WI + (0 + i) * 16 + 4 * q + e] : w[WH + (0 + i) * 16 + 4 * q + e - 4];
             const float wi_z = e < 4 ? w[WI + (16 + i) * 16 + 4 * q + e] : w[WH + (16 + i) * 16 + 4 * q + e - 4];
-            put(BW_R, e, wi_r);
-            put(BW_Z, e, wi_z);
-            put(BW_NI, e, e < 4 ? w[WI + (32 + i) * 16 + 4 * q + e] : 0.0f);
-            put(BW_NH, e, e < 4 ? 0.0f : w[WH + (32 + i) * 16 + 4 * q + e - 4]);
+            put(BW_R, e, kS * wi_r);
+            put(BW_Z, e, kS * wi_z);
+            put(BW_NI, e, e < 4 ? kT * w[WI + (32 + i) * 16 + 4 * q + e] : 0.0f);
+            put(BW_NH, e, e < 4 ? 0.0f : kT * w[WH + (32 + i) * 16 + 4 * q + e - 4]);
             for (int t = 0; t < 4; ++t)
                 put(BW_L2 + 4 * t, e, (e < 4 && (i >> 2) == t) ? w[W2 + (i & 3) * 16 + 4 * q + e] : 0.0f);
         }

@@ -162,7 +162,9 @@ def _actor_bf16_model(w, x, h):
     bi, bh, W2, b2 = w[1904:1952], w[1952:2000], w[2016:2080].reshape(4, 16), w[2080:2084]
     sig = lambda v: 1.0 / (1.0 + np.exp(-v))
     y0 = np.maximum(_bf16(x[:, :22]) @ _bf16(W0).T + _bf16(b0), 0).astype(np.float32)
-    gi, gh = _bf16(y0) @ _bf16(Wi).T, _bf16(h) @ _bf16(Wh).T
+    # the gate rows are pre-scaled (r, z by -log2 e, n by -2 log2 e) BEFORE they are rounded to bf16 (pack_policy_bf16)
+    k = np.concatenate([np.full(32, -1.4426950408889634, np.float32), np.full(16, -2.8853900817779268, np.float32)])[:, None]
+    gi, gh = (_bf16(y0) @ _bf16(k * Wi).T) / k.T, (_bf16(h) @ _bf16(k * Wh).T) / k.T
     r = sig(gi[:, :16] + gh[:, :16] + bi[:16] + bh[:16])
     z = sig(gi[:, 16:32] + gh[:, 16:32] + bi[16:32] + bh[16:32])
     n = np.tanh(gi[:, 32:] + bi[32:] + r * (gh[:, 32:] + bh[32:]))
