@@ -31,6 +31,12 @@
  *   the loop body README.md:95-99 x K                            rq_rollout  (fused or hipGraph-chained)
  *   boot self-test of the embedded backend              :136-139,155   rq_policy_selftest
  *   rl_tools_inference_applications_l2f_control(...)->status :163      convention: POD in/out, int status
+ *   rl-tools layers standardize / sample_and_squash     :114,116 rq_policy_set_standardize / rq_policy_set_sample_and_squash
+ *   post-training data collection                       :208     rq_rollout_record + rq_trajectory_*
+ *   distillation: ~1000 MLP teachers queried on
+ *     student-visited states                            :208-216 rq_teacher_bank_create / rq_trajectory_relabel_teachers
+ *   (the reference is single-process) env shards over
+ *     GPUs + all-gather of episode returns (RCCL)                rq_env_create(global_env_offset) / rq_comm_* / rq_allgather_returns
  *
  * Conventions
  *   - Every function returns an int status: RQ_OK (0) or a negative rq_status; the message of
