@@ -1384,7 +1384,14 @@ RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t
     const size_t per = rq::teacher_param_count((int)in_dim, (int)h1, (int)h2);
     const size_t f32_floats = (size_t)rq::teacher_image_regs_f32((int)h1, (int)h2) * 64;
     const size_t bf16_floats = (size_t)rq::teacher_image_regs_bf16((int)h1, (int)h2) * 64;
-    std::vector<float> img32(f32_floats * n_teachers), img16(bf16_floats * n_teachers);
+    std::vector<float> img32, img16;
+    try {                                   // nothing throws across the boundary
+        img32.resize(f32_floats * n_teachers);
+        img16.resize(bf16_floats * n_teachers);
+    } catch (const std::bad_alloc&) {
+        delete b;
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_teacher_bank_create: host allocation failed");
+    }
     for (uint32_t t = 0; t < n_teachers; ++t) {
         rq::pack_teacher_f32(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img32.data() + f32_floats * t);
         rq::pack_teacher_bf16(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img16.data() + bf16_floats * t);
@@ -1428,25 +1435,23 @@ RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* ban
     const uint32_t n = env->n;
     // group the envs by teacher: a tile = up to 16 envs of ONE teacher (counting sort over the teacher ids, env
     // order kept inside a teacher, so sorted inputs give contiguous tiles and coalesced rows)
-    std::vector<uint32_t> count(bank->n_teachers + 1, 0);
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n; ++i)
         RQ_REQUIRE(teacher_id[i] < bank->n_teachers, RQ_ERR_INVALID_ARGUMENT, "teacher id out of range");
-        ++count[teacher_id[i] + 1];
-    }
+    std::vector<uint32_t> host;             // tile_teacher [n_tiles] | tile_env [n_tiles][16]
     uint32_t n_tiles = 0;
-    for (uint32_t k = 0; k < bank->n_teachers; ++k) n_tiles += (count[k + 1] + 15u) / 16u;
-    std::vector<uint32_t> start(bank->n_teachers, 0);         // first tile of each teacher
-    {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < bank->n_teachers; ++k) { start[k] = acc; acc += (count[k + 1] + 15u) / 16u; }
-    }
-    std::vector<uint32_t> host((size_t)n_tiles * 17, 0xFFFFFFFFu);   // tile_teacher [n_tiles] | tile_env [n_tiles][16]
-    std::vector<uint32_t> filled(bank->n_teachers, 0);
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t k = teacher_id[i], pos = filled[k]++;
-        const uint32_t tile = start[k] + pos / 16u;
-        host[tile] = k;
-        host[(size_t)n_tiles + (size_t)tile * 16 + pos % 16u] = i;
+    try {                                   // nothing throws across the boundary
+        std::vector<uint32_t> count(bank->n_teachers, 0), start(bank->n_teachers, 0), filled(bank->n_teachers, 0);
+        for (uint32_t i = 0; i < n; ++i) ++count[teacher_id[i]];
+        for (uint32_t k = 0; k < bank->n_teachers; ++k) { start[k] = n_tiles; n_tiles += (count[k] + 15u) / 16u; }
+        host.assign((size_t)n_tiles * 17, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t k = teacher_id[i], pos = filled[k]++;
+            const uint32_t tile = start[k] + pos / 16u;
+            host[tile] = k;
+            host[(size_t)n_tiles + (size_t)tile * 16 + pos % 16u] = i;
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_trajectory_relabel_teachers: host allocation failed");
     }
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     if (bank->tile_capacity < n_tiles) {
