@@ -188,9 +188,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
 }
 
 // register budget of a kernel built around an actor type: waves per SIMD it is compiled for
-template <typename A> struct WavesPerSimd { static constexpr int value = 1; };
-template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; };
-template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; };
+template <typename A> struct WavesPerSimd { static constexpr int value = 1; static constexpr bool bf16 = false; };
+template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; static constexpr bool bf16 = false; };
+template <> struct WavesPerSimd<ActorBF16> { static constexpr int value = 1; static constexpr bool bf16 = true; };
+template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; static constexpr bool bf16 = true; };
 
 // Raptor evaluated over a whole observation SEQUENCE in one launch (rl-tools evaluates [seq, batch, feature]
 // tensors: the known-answer example of the checkpoint is one, checkpoint.h:197-215): obs [T][n][stride]
@@ -223,17 +224,24 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
             for (int k = 0; k < 22; ++k) x[k] = row[k];
         }
     };
-    float x[22];
+    // rows in flight ahead of the matrix work: one step for the f32 actor (a step is ~3 us of MFMA, longer than a
+    // cold row's latency; a second row in flight measured 3 % slower), two for the bf16 actor (1.5 us steps: +12 %)
+    constexpr bool kTwoAhead = WavesPerSimd<ACTOR>::bf16;
+    float x[22], x1[22];
     load_row(0, x);
+    if (kTwoAhead) load_row(steps > 1 ? 1 : 0, x1);
     for (uint32_t t = 0; t < steps; ++t) {
         float xn[22];
-        const bool more = t + 1 < steps;                  // wave-uniform
-        if (more) load_row(t + 1, xn);
+        const bool more = t + (kTwoAhead ? 2 : 1) < steps;                  // wave-uniform
+        if (more) load_row(t + (kTwoAhead ? 2 : 1), xn);
         float a[4];
         actor.step(x, hQ, a);
         if (squash) squash_action(a);
         if (valid) *reinterpret_cast<float4*>(act + ((size_t)t * n + i0) * 4) = make_float4(a[0], a[1], a[2], a[3]);
-        if (more) {
+        if (kTwoAhead) {
+#pragma unroll
+            for (int k = 0; k < 22; ++k) { x[k] = x1[k]; x1[k] = more ? xn[k] : x1[k]; }
+        } else if (more) {
 #pragma unroll
             for (int k = 0; k < 22; ++k) x[k] = xn[k];
         }
