@@ -49,6 +49,27 @@ int main(int argc, char** argv) {
             worst = std::fmax(worst, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
         }
         std::printf("8 quadrotors after 500 steps: max |position| = %.3f m\n", worst);
+
+        // around the loop: record 50 steps, label them with a bank of two 22-16-16-4 MLP teachers (README.md:208-216),
+        // and all-gather the episode returns through a one-rank RCCL communicator created by the library itself
+        rq::Trajectory traj(env, 50);
+        rq::rollout(device, env, params, state, policy, rng, 50, traj, RQ_ROLLOUT_FUSED, /*autoreset=*/true);
+        const std::size_t per_teacher = 16 * 22 + 16 + 16 * 16 + 16 + 4 * 16 + 4;
+        std::vector<float> tw(2 * per_teacher);
+        for (std::size_t i = 0; i < tw.size(); ++i) tw[i] = 0.05f * float(int(i % 13) - 6);
+        rq::TeacherBank bank(device, tw.data(), 2, 22, 16, 16, RQ_ACT_TANH, RQ_ACT_TANH);
+        std::vector<std::uint32_t> teacher(N);
+        for (std::uint32_t e = 0; e < N; ++e) teacher[e] = e % 2;
+        std::vector<float> labels(std::size_t(traj.length()) * N * 4);
+        rq::relabel_teachers(traj, bank, teacher.data(), labels.data());
+        float amax = 0;
+        for (float v : labels) amax = std::fmax(amax, std::fabs(v));
+        rq::Communicator comm(device, 1, 0, rq::Communicator::unique_id());
+        comm.allgather_returns(env);
+        const std::vector<float> gathered = comm.gathered();
+        std::printf("recorded %u steps, teacher labels max |a| = %.3f (tanh output), gathered %zu returns\n",
+                    traj.length(), amax, gathered.size());
+        if (!(amax <= 1.0f) || gathered.size() != N) return 2;
     } catch (const rq::Error& e) {
         std::fprintf(stderr, "raptor_quad error %d: %s\n", e.status, e.what());
         return 1;

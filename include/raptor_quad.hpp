@@ -94,6 +94,44 @@ struct Raptor : detail::Handle<rq_policy, rq_policy_destroy> {
         check(rq_policy_evaluate_sequence(h, observation, steps, batch, obs_stride, action, RQ_DST_HOST));
     }
     void set_precision(rq_policy_precision p) { check(rq_policy_set_precision(h, p)); }
+    // optional layers named by rl-tools (README.md:114,116), identity in the shipped checkpoint
+    void set_standardize(const float* mean, const float* std) { check(rq_policy_set_standardize(h, mean, std)); }
+    void set_sample_and_squash(rq_sample_and_squash_mode mode, const float* log_std_weights = nullptr,
+                               const float* log_std_bias = nullptr, std::uint64_t seed = 0) {
+        check(rq_policy_set_sample_and_squash(h, mode, log_std_weights, log_std_bias, seed));
+    }
+};
+
+// rollout recording buffer: what a learner's data collection consumes (README.md:208)
+struct Trajectory : detail::Handle<rq_trajectory, rq_trajectory_destroy> {
+    Trajectory(Environment& e, std::uint32_t capacity_steps) { check(rq_trajectory_create(e.h, capacity_steps, &h)); }
+    std::uint32_t length() const { std::uint32_t n = 0; check(rq_trajectory_length(h, &n, nullptr)); return n; }
+    void reset() { check(rq_trajectory_reset(h)); }
+};
+
+// a bank of MLP teachers (README.md:208-216): input (in_dim <= 22) -> h1 -> h2 -> 4
+struct TeacherBank : detail::Handle<rq_teacher_bank, rq_teacher_bank_destroy> {
+    TeacherBank(Device& d, const float* weights, std::uint32_t n_teachers, std::uint32_t in_dim, std::uint32_t h1,
+                std::uint32_t h2, rq_activation hidden = RQ_ACT_RELU, rq_activation output = RQ_ACT_IDENTITY) {
+        check(rq_teacher_bank_create(d.h, weights, n_teachers, in_dim, h1, h2, hidden, output, &h));
+    }
+    void set_precision(rq_policy_precision p) { check(rq_teacher_bank_set_precision(h, p)); }
+};
+
+// one rank of the multi-GPU job: RCCL all-gather of episode returns issued by the library itself
+struct Communicator : detail::Handle<rq_comm, rq_comm_destroy> {
+    static std::vector<char> unique_id() { std::vector<char> id(RQ_COMM_ID_BYTES); check(rq_comm_unique_id(id.data(), id.size())); return id; }
+    Communicator(Device& d, std::uint32_t n_ranks, std::uint32_t rank, const std::vector<char>& id) {
+        check(rq_comm_create(d.h, n_ranks, rank, id.data(), id.size(), &h));
+    }
+    void allgather_returns(Environment& env) { check(rq_allgather_returns(env.h, h)); }      // enqueued, overlaps the next rollout
+    std::vector<float> gathered() {
+        std::uint32_t count = 0;
+        check(rq_comm_gathered(h, nullptr, &count, nullptr));
+        std::vector<float> v(count);
+        check(rq_comm_gathered(h, nullptr, nullptr, v.data()));
+        return v;
+    }
 };
 
 // ---- the l2f vector:: free functions, reference argument order ------------------------------------
@@ -118,6 +156,17 @@ inline float step(Device& d, Environment& env, Parameters& p, State& s, const fl
 inline void rollout(Device& d, Environment& env, Parameters& p, State& s, Raptor& policy, Rng& rng,
                     std::uint32_t n_steps, rq_rollout_mode mode = RQ_ROLLOUT_FUSED, bool autoreset = false) {
     check(rq_rollout(d.h, env.h, p.h, s.h, policy.h, rng.h, n_steps, mode, autoreset ? std::uint32_t(RQ_ROLLOUT_AUTORESET) : 0u));
+}
+// the same, appending every transition to a trajectory buffer
+inline void rollout(Device& d, Environment& env, Parameters& p, State& s, Raptor& policy, Rng& rng,
+                    std::uint32_t n_steps, Trajectory& traj, rq_rollout_mode mode = RQ_ROLLOUT_FUSED, bool autoreset = false) {
+    check(rq_rollout_record(d.h, env.h, p.h, s.h, policy.h, rng.h, n_steps, mode,
+                            autoreset ? std::uint32_t(RQ_ROLLOUT_AUTORESET) : 0u, traj.h));
+}
+// teacher teacher_id[i] labels every recorded step of env i; action_out: host [length, N, 4] or nullptr
+inline void relabel_teachers(Trajectory& traj, TeacherBank& bank, const std::uint32_t* teacher_id, float* action_out,
+                             bool overwrite = false) {
+    check(rq_trajectory_relabel_teachers(traj.h, bank.h, teacher_id, action_out, overwrite ? 1 : 0));
 }
 
 }  // namespace raptor_quad

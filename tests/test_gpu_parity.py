@@ -904,8 +904,9 @@ def test_cpp_wrapper_example_runs_on_the_gpu(tmp_path):
                     os.path.join(ROOT, "examples", "readme_loop.cpp"), "-L" + pkg, "-lraptor_quad",
                     "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
     r = subprocess.run([exe, os.path.join(pkg, "data", "raptor_policy.bin")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    assert r.returncode == 0, r.stderr + r.stdout
     assert float(r.stdout.split("=")[1].split()[0]) < 1.0
+    assert "recorded 50 steps" in r.stdout and "gathered 8 returns" in r.stdout     # trajectory, teacher bank, RCCL
 
 
 def test_policy_from_checkpoint_header(device, weights, kat, tmp_path):
