@@ -766,21 +766,35 @@ struct ActorBF16 {
 
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        float X[6][4];
+        // observation -> B operands of layer_0.  The operand is bf16 anyway, so the features are rounded and packed
+        // in pairs BEFORE the layout change: dword d of a tile's operand holds k-slots 2d, 2d+1 = features 8d + q and
+        // 8d + 4 + q at lane-group q, i.e. in the native layout P[d][c] = (o[8d + c], o[8d + 4 + c]), and the 4 x 4
+        // lane-group transpose runs on 12 packed dwords instead of 24 floats (12 permlane swaps instead of 24, and
+        // no copies of the state registers the swaps would otherwise destroy); feature 22 is the constant 1 that
+        // carries the bias, 23 is padding.  Same rounding, same bits as packing after the transpose.
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        float P[3][4];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
+        for (int d = 0; d < 3; ++d) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int f = 4 * s + c;
-                X[s][c] = f < 22 ? o[f < 22 ? f : 21] : (f == 22 ? 1.0f : 0.0f);
+                const int f0 = 8 * d + c, f1 = 8 * d + 4 + c;
+                const float lo = o[f0 < 22 ? f0 : 21];                       // f0 <= 19 always
+                const float hi = f1 < 22 ? o[f1 < 22 ? f1 : 21] : (f1 == 22 ? 1.0f : 0.0f);
+                bf16x2 v;
+                v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+                P[d][c] = __builtin_bit_cast(float, v);
             }
-            transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
+            transpose4(P[d][0], P[d][1], P[d][2], P[d][3]);
         }
         const bf16x8 wl0 = a_op(BW_L0), wr = a_op(BW_R), wz = a_op(BW_Z), wni = a_op(BW_NI), wnh = a_op(BW_NH);
         f32x4 y0[4], gr[4], gz[4], gni[4], gnh[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            y0[t] = mfma(wl0, pack_bf16x8(X[0][t], X[1][t], X[2][t], X[3][t], X[4][t], X[5][t], 0.f, 0.f), zero);
+        for (int t = 0; t < 4; ++t) {
+            const dwordx4 xb = {__builtin_bit_cast(uint32_t, P[0][t]), __builtin_bit_cast(uint32_t, P[1][t]),
+                                __builtin_bit_cast(uint32_t, P[2][t]), 0u};
+            y0[t] = mfma(wl0, __builtin_bit_cast(bf16x8, xb), zero);
+        }
         // gate rows pre-scaled (before the bf16 rounding) and pre-scaled biases through the C operand, as in the
         // f32 image: the accumulators are the exp2 arguments (gru_gates_prescaled)
         const f32x4 cbr = {B[BW_BR - BW_BR], B[BW_BR - BW_BR + 1], B[BW_BR - BW_BR + 2], B[BW_BR - BW_BR + 3]};
