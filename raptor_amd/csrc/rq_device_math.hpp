@@ -625,6 +625,13 @@ struct ActorF32T {
     __device__ __forceinline__ float h0(int r) const { return W[QW_H0 + r]; }
 
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
+        step<0>(o, hQ, a, [] {});
+    }
+    // `early_stores`: N_STORES vector-memory stores that only need the observation (the trajectory recorder's).
+    // They are emitted into the first GRU pass and interleaved with its MFMAs - a store issues while the matrix
+    // pipe executes, whereas a burst of 26 stores after the actor holds the wave for ~0.4 us (measured).
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         // observation -> B operands of layer_0: X[s][t] at lane (q,j) = o[4s+q] of env (t,j);
         // input 22 is the constant 1 that carries the bias, input 23 is padding
@@ -667,6 +674,7 @@ struct ActorF32T {
             const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
             const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
             __builtin_amdgcn_sched_barrier(0);
+            if (t0 == 0) early_stores();
 #pragma unroll
             for (int u = 0; u < TP; ++u) {
                 gr[u] = mfma16(W[QW_GI + 0], y0[t0 + u][0], cbr);
@@ -690,6 +698,13 @@ struct ActorF32T {
                     gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
                     gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
                 }
+            if (t0 == 0 && N_STORES > 0) {        // this region's order: 2 MFMAs, 1 store, 2 MFMAs, 1 store, ...
+#pragma unroll
+                for (int k = 0; k < N_STORES; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // VMEM write
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < TP; ++u) gru_gates_prescaled(gr[u], gz[u], gni[u], gnh[u], hQ[t0 + u]);
@@ -764,6 +779,11 @@ struct ActorBF16 {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
+        early_stores();           // the bf16 MFMAs co-execute with everything else: no placement needed
+        step(o, hQ, a);
+    }
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         // observation -> B operands of layer_0.  The operand is bf16 anyway, so the features are rounded and packed

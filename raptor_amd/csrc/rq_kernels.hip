@@ -460,23 +460,29 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
-        actor.step(o, hn, a);
-        if (SAS) sample_and_squash(sas, epoch0 + t, genv, hn, a);        // SampleAndSquash output stage (rare)
-        if (RECORD) {   // one coalesced 256-byte store per field per wave
-            // buffer stores: resource = this step's block of the trajectory (base moved on the SALU), scalar
-            // offset = field row, vector offset = the lane's env; no per-lane 64-bit address arithmetic and
-            // no per-lane pointers kept alive across the loop.  Lanes past the batch are sent out of range
-            // (the hardware drops out-of-range buffer stores).  Issued here, before the env step: the 22
-            // observation registers die at once instead of living through the RK4 (which pushed loop-carried
-            // counters into scratch, one exposed reload per step), and the stores drain behind the dynamics.
+        // Trajectory stores (RECORD): one coalesced 256-byte store per field per wave; buffer stores: resource = this
+        // step's block of the trajectory (base moved on the SALU), scalar offset = field row, vector offset = the
+        // lane's env - no per-lane 64-bit address arithmetic, no per-lane pointers kept alive across the loop; lanes
+        // past the batch are sent out of range (the hardware drops out-of-range buffer stores).  The 22 observation
+        // stores are handed to the actor, which places them between the MFMAs of its first GRU pass; the action
+        // follows the actor, reward and done code the env step.
+        const uint32_t row = (uint32_t)ld * 4u;                     // bytes per field row (ld < 2^30)
+        const uint32_t lane_off = valid ? i * 4u : 0xFFFFFFFFu;
+        if (RECORD) {
             const size_t tt = traj.t0 + t;
-            const uint32_t row = (uint32_t)ld * 4u;                 // bytes per field row (ld < 2^30)
-            const uint32_t lane_off = valid ? i * 4u : 0xFFFFFFFFu;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(traj.obs + tt * 22 * ld, 0, 22u * row, 0x00020000);
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(traj.act + tt * 4 * ld, 0, 4u * row, 0x00020000);
+            actor.template step<22>(o, hn, a, [&] {
 #pragma unroll
-            for (int j = 0; j < 22; ++j)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, 0);
+                for (int j = 0; j < 22; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, 0);
+            });
+        } else {
+            actor.step(o, hn, a);
+        }
+        if (SAS) sample_and_squash(sas, epoch0 + t, genv, hn, a);        // SampleAndSquash output stage (rare)
+        if (RECORD) {
+            const size_t tt = traj.t0 + t;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(traj.act + tt * 4 * ld, 0, 4u * row, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a[j]), ra, lane_off, (uint32_t)j * row, 0);
@@ -518,7 +524,6 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         }
         if (RECORD) {   // reward and done code of this transition (the observation and action went out above)
             const size_t tt = traj.t0 + t;
-            const uint32_t row = (uint32_t)ld * 4u;
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(traj.rew + tt * ld, 0, row, 0x00020000);
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(traj.done + tt * ld, 0, (uint32_t)ld, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rr, valid ? i * 4u : 0xFFFFFFFFu, 0, 0);
