@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libraptor_quad.so")
+# RAPTOR_QUAD_LIB: another build of the same ABI (tools/ab_build.sh: same-box A/B timing of two revisions)
+LIB_PATH = os.environ.get("RAPTOR_QUAD_LIB") or os.path.join(_PKG, "libraptor_quad.so")
 
 POLICY_INPUT_DIM = 22
 POLICY_HIDDEN_DIM = 16

@@ -614,11 +614,34 @@ __device__ __forceinline__ void transpose4(float& n0, float& n1, float& n2, floa
 template <bool LEAN>
 struct ActorF32T {
     static constexpr int kPackedRegs = QW_REGS;
+    // The observation changes layout (one env per lane -> layer_0's B operands) through LDS: lane L writes its 22
+    // features to row L, lane (q,j) reads feature 4s+q of row 16t+j.  Row stride 25 floats: both the column writes
+    // (stride 25 over 64 lanes) and the operand reads (16 rows x 4 consecutive floats) touch 64 distinct banks but
+    // one.  LDS instructions issue while the matrix pipe executes, so the whole exchange sits inside the GRU's
+    // recurrent MFMAs (which do not need the observation); as lane swaps (24 v_permlane + 15 copies, VALU work
+    // that an f32 MFMA never overlaps) it cost ~150 ns per step.
+    static constexpr int kLdsRow = 25;
+    static constexpr int kLdsFloats = 64 * kLdsRow;
+    typedef __attribute__((address_space(3))) float LdsFloat;
     float W[QW_REGS];
+    LdsFloat* wr;            // this lane's row of the wave's kLdsFloats of LDS
+    LdsFloat* rd[4];         // lane (q,j): row 16t + j, column q, one pointer per tile t (kept in registers: the
+                             // offsets of a two-address LDS read reach 255 floats, a tile is 400 apart)
 
-    // every lane loads its slice of the packed image; all 64 lanes must be active
+    // every lane loads its slice of the packed image; all 64 lanes must be active.  WAVES = waves per workgroup.
+    template <int WAVES>
     __device__ __forceinline__ void load(const float* __restrict__ packed) {
+        __shared__ float lds[WAVES * kLdsFloats];
         const int lane = threadIdx.x & 63;
+        LdsFloat* stage = (LdsFloat*)lds + (threadIdx.x >> 6) * kLdsFloats;
+        wr = stage + lane * kLdsRow;
+        wr[22] = 1.0f;        // input 22 is the constant 1 that carries layer_0's bias,
+        wr[23] = 0.0f;        // input 23 is padding: written once
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            rd[t] = stage + (16 * t + (lane & 15)) * kLdsRow + (lane >> 4);
+            asm volatile("" : "+v"(rd[t]));       // not to be recomputed inside the MFMA batches
+        }
 #pragma unroll
         for (int v = 0; v < QW_REGS; ++v) W[v] = packed[v * 64 + lane];
     }
@@ -630,26 +653,59 @@ struct ActorF32T {
     // `early_stores`: N_STORES vector-memory stores that only need the observation (the trajectory recorder's).
     // They are emitted into the first GRU pass and interleaved with its MFMAs - a store issues while the matrix
     // pipe executes, whereas a burst of 26 stores after the actor holds the wave for ~0.4 us (measured).
+    //
+    // MFMAs are issued in uninterrupted batches: an f32 MFMA and VALU work never co-execute, and every
+    // MFMA -> VALU -> MFMA round trip in the instruction stream costs ~5.8 ns of pipeline turnaround on top
+    // (tools/overlap.hip: one MFMA + 2 FMAs = 23.9 ns against 14.1 + 2 x 2.1); left alone the scheduler
+    // interleaves single MFMAs with the gate arithmetic (23 batches per step instead of 6).
+    // Summation order of the r/z gate accumulators: bias, W_h h (k = 0..15), W_i y0 (k = 0..15).
     template <int N_STORES, class HOOK>
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        // observation -> B operands of layer_0: X[s][t] at lane (q,j) = o[4s+q] of env (t,j);
-        // input 22 is the constant 1 that carries the bias, input 23 is padding
-        float X[6][4];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int f = 4 * s + c;
-                X[s][c] = f < 22 ? o[f < 22 ? f : 21] : (f == 22 ? 1.0f : 0.0f);
-            }
-            transpose4(X[s][0], X[s][1], X[s][2], X[s][3]);
-        }
-        // MFMAs are issued in uninterrupted batches: an f32 MFMA and VALU work never co-execute, and every
-        // MFMA -> VALU -> MFMA round trip in the instruction stream costs ~5.8 ns of pipeline turnaround on top
-        // (tools/overlap.hip: one MFMA + 2 FMAs = 23.9 ns against 14.1 + 2 x 2.1); left alone the scheduler
-        // interleaves single MFMAs with the transposes and the gate arithmetic (23 batches per step instead of 5)
+        constexpr int TP = 2;     // GRU tiles per pass: 4 accumulators per tile are live (with all four tiles in
+                                  // flight the 512-register build parked MFMA operands in AGPRs, ~25 moves per step)
+        const f32x4 cbr = {W[QW_BR], W[QW_BR + 1], W[QW_BR + 2], W[QW_BR + 3]};
+        const f32x4 cbz = {W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]};
+        const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
+        const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
+        f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];
+        float X[6][4];            // X[s][t] at lane (q,j) = o[4s+q] of env (t,j)
+
+        // ---- batch 1: recurrent half of GRU pass 0, with the observation's trip through LDS in its shadow ----
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 22; ++f) wr[f] = o[f];
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            gr[u] = mfma16(W[QW_GH + 0], hQ[u][0], cbr);
+            gz[u] = mfma16(W[QW_GH + 4], hQ[u][0], cbz);
+            gnh[u] = mfma16(W[QW_GH + 8], hQ[u][0], cbnh);
+        }
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                gr[u] = mfma16(W[QW_GH + 0 + s], hQ[u][s], gr[u]);
+                gz[u] = mfma16(W[QW_GH + 4 + s], hQ[u][s], gz[u]);
+                gnh[u] = mfma16(W[QW_GH + 8 + s], hQ[u][s], gnh[u]);
+            }
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) X[s][t] = rd[t][4 * s];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                                 // 8 MFMAs carry the writes,
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {                                // 12 the reads, 4 cover the last read's latency
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- batch 2: layer_0 ----
         f32x4 y0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y0[t] = mfma16(W[QW_L0], X[0][t], zero);
@@ -663,45 +719,41 @@ struct ActorF32T {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y0[t][r] = relu(y0[t][r]);
 
-        // GRU, two tiles at a time: 4 accumulators per tile are live per pass (with all four tiles in flight the
-        // 512-register build parked MFMA operands in AGPRs and copied them back, ~25 v_accvgpr moves per step)
-        constexpr int TP = 2;
+        // ---- batches 3, 4: input half of pass 0; all of pass 1 ----
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TP) {
-            f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];
-            const f32x4 cbr = {W[QW_BR], W[QW_BR + 1], W[QW_BR + 2], W[QW_BR + 3]};
-            const f32x4 cbz = {W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]};
-            const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
-            const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
             __builtin_amdgcn_sched_barrier(0);
             if (t0 == 0) early_stores();
-#pragma unroll
-            for (int u = 0; u < TP; ++u) {
-                gr[u] = mfma16(W[QW_GI + 0], y0[t0 + u][0], cbr);
-                gz[u] = mfma16(W[QW_GI + 4], y0[t0 + u][0], cbz);
-                gni[u] = mfma16(W[QW_GI + 8], y0[t0 + u][0], cbni);
-                gnh[u] = mfma16(W[QW_GH + 8], hQ[t0 + u][0], cbnh);
-            }
-#pragma unroll
-            for (int s = 1; s < 4; ++s)
+            if (t0 != 0) {
 #pragma unroll
                 for (int u = 0; u < TP; ++u) {
-                    gr[u] = mfma16(W[QW_GI + 0 + s], y0[t0 + u][s], gr[u]);
-                    gz[u] = mfma16(W[QW_GI + 4 + s], y0[t0 + u][s], gz[u]);
-                    gni[u] = mfma16(W[QW_GI + 8 + s], y0[t0 + u][s], gni[u]);
-                    gnh[u] = mfma16(W[QW_GH + 8 + s], hQ[t0 + u][s], gnh[u]);
+                    gr[u] = mfma16(W[QW_GH + 0], hQ[t0 + u][0], cbr);
+                    gz[u] = mfma16(W[QW_GH + 4], hQ[t0 + u][0], cbz);
+                    gnh[u] = mfma16(W[QW_GH + 8], hQ[t0 + u][0], cbnh);
                 }
+#pragma unroll
+                for (int s = 1; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
+                        gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
+                        gnh[u] = mfma16(W[QW_GH + 8 + s], hQ[t0 + u][s], gnh[u]);
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < TP; ++u) gni[u] = mfma16(W[QW_GI + 8], y0[t0 + u][0], cbni);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int u = 0; u < TP; ++u) {
-                    gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
-                    gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
+                    gr[u] = mfma16(W[QW_GI + 0 + s], y0[t0 + u][s], gr[u]);
+                    gz[u] = mfma16(W[QW_GI + 4 + s], y0[t0 + u][s], gz[u]);
+                    if (s > 0) gni[u] = mfma16(W[QW_GI + 8 + s], y0[t0 + u][s], gni[u]);
                 }
-            if (t0 == 0 && N_STORES > 0) {        // this region's order: 2 MFMAs, 1 store, 2 MFMAs, 1 store, ...
+            if (t0 == 0 && N_STORES > 0) {        // this region's order: 1 MFMA, 1 store, 1 MFMA, 1 store, ...
 #pragma unroll
                 for (int k = 0; k < N_STORES; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
                     __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // VMEM write
                 }
             }
@@ -710,7 +762,7 @@ struct ActorF32T {
             for (int u = 0; u < TP; ++u) gru_gates_prescaled(gr[u], gz[u], gni[u], gnh[u], hQ[t0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // layer_2: the four tiles land in disjoint row blocks of one D = the native layout
+        // ---- batch 5: layer_2, the four tiles land in disjoint row blocks of one D = the native layout ----
         const f32x4 cb2 = {W[QW_B2], W[QW_B2 + 1], W[QW_B2 + 2], W[QW_B2 + 3]};
         f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], cb2);
         f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
@@ -762,6 +814,7 @@ struct ActorBF16 {
     uint32_t A[BW_BR];
     float B[BW_REGS - BW_BR];
 
+    template <int WAVES>
     __device__ __forceinline__ void load(const float* __restrict__ packed) {
         const int lane = threadIdx.x & 63;
         const uint32_t* pu = reinterpret_cast<const uint32_t*>(packed);

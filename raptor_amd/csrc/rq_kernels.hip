@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
                                                        const uint8_t* __restrict__ frozen, SasArgs sas,
                                                        Mailbox mb) {
     ACTOR actor;
-    actor.load(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
+    actor.template load<kBlock / 64>(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t first = wave * groups_per_wave * 64;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
         uint32_t n, uint32_t steps, const float* __restrict__ packed, const float* __restrict__ obs, uint32_t stride,
         float* __restrict__ hidden, uint32_t ld_h, float* __restrict__ act, uint32_t squash) {
     ACTOR actor;
-    actor.load(packed);
+    actor.template load<kFusedBlock / 64>(packed);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_base = blockIdx.x * kFusedBlock;
     const uint32_t i0 = wave_base + lane;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
         const uint8_t* __restrict__ done, float* __restrict__ hidden, uint32_t ld_h, float* __restrict__ act,
         uint32_t squash) {
     ACTOR actor;
-    actor.load(packed);
+    actor.template load<kFusedBlock / 64>(packed);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_base = blockIdx.x * kFusedBlock;
     const uint32_t i0 = wave_base + lane;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
                                                                const float* __restrict__ packed, StatsPtrs st,
                                                                TrajPtrs traj, SasArgs sas) {
     ACTOR actor;
-    actor.load(packed);
+    actor.template load<kFusedBlock / 64>(packed);
     const uint32_t i0 = env_index();
     const uint32_t wave_base = i0 & ~63u;
     const uint32_t i = i0 < b.n ? i0 : b.n - 1;
