@@ -134,8 +134,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t first = wave * groups_per_wave * 64;
-    // inputs of a 64-env group: 22 observation features of the lane's env + the Q-layout hidden state
-    auto load_group = [&](uint32_t wave_base, float (&x)[22], float (&hQ)[4][4]) {
+    // inputs of a 64-env group: 22 observation features of the lane's env, the Q-layout hidden state, the frozen flag
+    auto load_group = [&](uint32_t wave_base, float (&x)[22], float (&hQ)[4][4], uint32_t& fz) {
         const uint32_t i0 = wave_base + lane;
         const uint32_t i = i0 < n ? i0 : n - 1;
         if (mb.rows_in != nullptr) {         // wave-uniform (kernel argument)
@@ -146,21 +146,27 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
             for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
         }
         load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+        fz = frozen != nullptr ? (uint32_t)frozen[i] : 0u;
     };
+    if (first >= n) { mailbox_signal(mb); return; }          // wave-uniform
+    const uint32_t n_groups = min(groups_per_wave, (n - first + 63u) / 64u);
     float x[22], hQ[4][4];
-    if (first < n) load_group(first, x, hQ);                 // wave-uniform
+    uint32_t fz;
+    load_group(first, x, hQ, fz);
 #pragma unroll 1
-    for (uint32_t g = 0; g < groups_per_wave; ++g) {
+    for (uint32_t g = 0; g < n_groups; ++g) {
         const uint32_t wave_base = first + g * 64;
-        if (wave_base >= n) break;                       // wave-uniform
-        // software pipeline: the next group's loads are in flight while this group's MFMAs run (the waves
-        // of a launch move in lock-step, so without it the memory and the matrix phases alternate)
+        // software pipeline: the next group's loads are in flight while this group's MFMAs run (the waves of a launch
+        // move in lock-step, so without it the memory and the matrix phases alternate).  Vector-memory operations
+        // complete in order and the compiler's wait for this group's inputs counts what was issued behind them on
+        // EVERY path: the prefetch is therefore unconditional (the last group re-reads itself) and brings the frozen
+        // flag along - a load consumed right here would wait for everything issued before it, the prefetch included.
         float xn[22], hn[4][4];
-        const bool more = g + 1 < groups_per_wave && wave_base + 64 < n;
-        if (more) load_group(wave_base + 64, xn, hn);
+        uint32_t fzn;
+        load_group(g + 1 < n_groups ? wave_base + 64 : wave_base, xn, hn, fzn);
         const uint32_t i0 = wave_base + lane;
         const uint32_t i = i0 < n ? i0 : n - 1;
-        const bool commit = (i0 < n) && !(frozen != nullptr && frozen[i]);
+        const bool commit = (i0 < n) && fz == 0;
         const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
         float a[4];
         actor.step(x, hQ, a);
@@ -175,14 +181,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
                 for (int k = 0; k < 4; ++k) mb.rows_out[(size_t)i * 4 + k] = a[k];
             }
         }
-        if (more) {
 #pragma unroll
-            for (int k = 0; k < 22; ++k) x[k] = xn[k];
+        for (int k = 0; k < 22; ++k) x[k] = xn[k];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hQ[t][r] = hn[t][r];
-        }
+            for (int r = 0; r < 4; ++r) hQ[t][r] = hn[t][r];
+        fz = fzn;
     }
     mailbox_signal(mb);
 }
