@@ -434,8 +434,7 @@ def main():
         t0 = time.perf_counter()
         run(plan)
         finish()
-        device.synchronize()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()     # hipDeviceSynchronize: every stream of the device, the library's own included
         wall = time.perf_counter() - t0              # this rank's clock stops when ITS work is done: the max over
         if dist is not None:                         # ranks is taken afterwards, so the closing barrier is not timed
             dist.barrier()

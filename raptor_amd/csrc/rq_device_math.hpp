@@ -793,7 +793,8 @@ typedef ActorF32T<true> ActorF32Lean;    // 256-register budget (2 waves/SIMD); 
 //   GRU     : slots e < 4 carry y0[4q+e], e >= 4 carry h[4q+e-4]: r and z gates are ONE MFMA each
 //             ([W_i | W_h] against [y0 ; h]), the n gate needs gi_n and gh_n apart: two MFMAs whose A
 //             has the other half zeroed;
-//   layer_2 : slots e < 4 carry h[4q+e]; the four tiles accumulate into one D (native layout).
+//   layer_2 : slots e >= 4 carry h[4q+e-4] (the gate operand's tuple again, A zero in slots e < 4); the four tiles
+//             accumulate into one D (native layout).
 // 4 + 16 + 4 = 24 MFMAs per wave-step instead of 136.  Operands are rounded to bf16 (RNE) by
 // v_cvt_pk_bf16_f32; products are exact in fp32 and accumulation is fp32.
 // image indices: enum BW_* in rq_kernels.hpp
@@ -874,10 +875,26 @@ struct ActorBF16 {
         const f32x4 cbz = {B[BW_BZ - BW_BR], B[BW_BZ - BW_BR + 1], B[BW_BZ - BW_BR + 2], B[BW_BZ - BW_BR + 3]};
         const f32x4 cbni = {B[BW_BNI - BW_BR], B[BW_BNI - BW_BR + 1], B[BW_BNI - BW_BR + 2], B[BW_BNI - BW_BR + 3]};
         const f32x4 cbnh = {B[BW_BNH - BW_BR], B[BW_BNH - BW_BR + 1], B[BW_BNH - BW_BR + 2], B[BW_BNH - BW_BR + 3]};
+        // B operand of the gates: k-slots 0..3 = relu(y0), 4..7 = h, as four dwords.  ReLU after the rounding, on the
+        // packed pairs: the sign survives the rounding, so max(int16, 0) per half (v_pk_max_i16) is the same value
+        // (negative -> +0) in 8 instructions instead of 16.  layer_2 reuses the SAME tuple with the h half replaced by
+        // the new hidden state - its A operands are zero in k-slots 0..3 (rq_pack.cpp), so the y0 half needs no zeroing.
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float lo, float hi) {            // one v_cvt_pk_bf16_f32 (RNE)
+            const f32x2 in = {lo, hi};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(in, bf16x2));
+        };
+        auto relu_pk = [](uint32_t u) {
+            const s16x2 z = {0, 0};
+            return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), z));
+        };
+        uint32_t yp[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8 xh = pack_bf16x8(relu(y0[t][0]), relu(y0[t][1]), relu(y0[t][2]),
-                                          relu(y0[t][3]), hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3]);
+            yp[t][0] = relu_pk(pk(y0[t][0], y0[t][1]));
+            yp[t][1] = relu_pk(pk(y0[t][2], y0[t][3]));
+            const dwordx4 u = {yp[t][0], yp[t][1], pk(hQ[t][0], hQ[t][1]), pk(hQ[t][2], hQ[t][3])};
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, u);
             gr[t] = mfma(wr, xh, cbr);
             gz[t] = mfma(wz, xh, cbz);
             gni[t] = mfma(wni, xh, cbni);
@@ -889,7 +906,8 @@ struct ActorBF16 {
         f32x4 d0 = cb2, d1 = zero;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8 hb = pack_bf16x8(hQ[t][0], hQ[t][1], hQ[t][2], hQ[t][3], 0.f, 0.f, 0.f, 0.f);
+            const dwordx4 u = {yp[t][0], yp[t][1], pk(hQ[t][0], hQ[t][1]), pk(hQ[t][2], hQ[t][3])};
+            const bf16x8 hb = __builtin_bit_cast(bf16x8, u);
             if (t & 1) d1 = mfma(a_op(BW_L2 + 4 * t), hb, d1);
             else       d0 = mfma(a_op(BW_L2 + 4 * t), hb, d0);
         }

@@ -76,7 +76,7 @@ void pack_policy_bf16(const float* w, float* packed) {
             put(BW_NI, e, e < 4 ? kT * w[WI + (32 + i) * 16 + 4 * q + e] : 0.0f);
             put(BW_NH, e, e < 4 ? 0.0f : kT * w[WH + (32 + i) * 16 + 4 * q + e - 4]);
             for (int t = 0; t < 4; ++t)
-                put(BW_L2 + 4 * t, e, (e < 4 && (i >> 2) == t) ? w[W2 + (i & 3) * 16 + 4 * q + e] : 0.0f);
+                put(BW_L2 + 4 * t, e, (e >= 4 && (i >> 2) == t) ? w[W2 + (i & 3) * 16 + 4 * q + e - 4] : 0.0f);
         }
         const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
         auto img = [&](int v) -> float& { return packed[v * 64 + l]; };
