@@ -1440,3 +1440,104 @@ def test_native_exchange_resizes_with_the_env(device, oracle):
         ex.post(w.env)
         got = ex.finish()
         assert got.shape == (n,) and np.array_equal(got, w.env.finished_returns())
+
+
+def test_closed_form_physics_at_full_size(device):
+    """Size-independent properties of the env step that no restatement is needed for, on 262 144 domain-randomised
+    envs on the GPU (BASELINE config 3's batch): with the rotors' thrust switched off the body is in free fall and
+    torque-free, so after K steps
+      * v = v0 - g K dt z, p = p0 + v0 K dt - g (K dt)^2 / 2 z      (RK4 is exact for a quadratic),
+      * the world-frame angular momentum R(q) J w and the rotational energy w.Jw/2 are conserved (J is not
+        isotropic: the body precesses, only a correct quaternion / Euler integration keeps both),
+      * |q| = 1,
+      * each rotor speed follows the first-order lag towards its set-point with RK4's own amplification factor
+        rho(x) = 1 - x + x^2/2 - x^3/6 + x^4/24, x = dt / T, per step.
+    These are checks of k_step against closed forms, not against oracle/."""
+    import torch
+    import raptor_amd.l2f as l2f
+    n, K = 262144, 200
+    v = l2f.VectorModule(n, 0)
+    rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+    v.initialize_rng(device, rng, 123)
+    v.initialize_environment(device, env)
+    cfg = env.config
+    cfg.termination_enabled = 0
+    cfg.disturbance_force_std = 0.0
+    cfg.disturbance_torque_std = 0.0
+    cfg.init_max_angular_velocity = 6.0
+    cfg.episode_step_limit = 10 * K
+    env.config = cfg
+    v.sample_initial_parameters(device, env, params, rng)
+    v.sample_initial_state(device, env, params, state, rng)
+    device.synchronize()
+    P, S = params.tensor(), state.tensor()
+    P[16:19] = 0.0                                            # T = c0 + c1 r + c2 r^2 = 0: no force, no torque
+    g_ = torch.Generator(device="cuda").manual_seed(7)
+    act = torch.rand(4, P.shape[1], device="cuda", generator=g_) * 2.4 - 1.2       # some outside [-1, 1]: clipped
+    env.action_tensor().copy_(act)
+    torch.cuda.synchronize()
+    s0 = S[:, :n].double().clone()
+    p64 = P[:, :n].double()
+    for _ in range(K):
+        v.step(device, env, params, state, None, state, rng)
+    device.synchronize()
+    s1 = S[:, :n].double()
+    dt, g = float(cfg.dt), float(cfg.gravity)
+    T = K * dt
+
+    def rot(q):                                               # body -> world, q = (w, x, y, z)
+        w, x, y, z = q
+        return torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)]),
+                            torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)]),
+                            torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)])])
+
+    # free fall
+    v_expect = s0[7:10].clone(); v_expect[2] -= g * T
+    p_expect = s0[0:3] + s0[7:10] * T; p_expect[2] -= 0.5 * g * T * T
+    dv = (s1[7:10] - v_expect).abs().max().item()
+    dp = (s1[0:3] - p_expect).abs().max().item()
+    # torque-free rotation
+    J = p64[1:4]
+    L0 = torch.einsum("ijn,jn->in", rot(s0[3:7]), J * s0[10:13])
+    L1 = torch.einsum("ijn,jn->in", rot(s1[3:7]), J * s1[10:13])
+    dL = ((L1 - L0).norm(dim=0) / L0.norm(dim=0).clamp_min(1e-12)).max().item()
+    E0, E1 = (J * s0[10:13] ** 2).sum(0), (J * s1[10:13] ** 2).sum(0)
+    dE = ((E1 - E0).abs() / E0.clamp_min(1e-30)).max().item()
+    dq = (s1[3:7].norm(dim=0) - 1).abs().max().item()
+    moved = (s1[10:13] - s0[10:13]).abs().max().item()        # the precession is real: w itself changes
+    # rotors
+    sp = p64[22] + (act[:, :n].double().clamp(-1, 1) + 1) * 0.5 * (p64[23] - p64[22])
+    tau = torch.where(sp > s0[13:17], p64[20].expand(4, n), p64[21].expand(4, n))
+    x = dt / tau
+    rho = 1 - x + x ** 2 / 2 - x ** 3 / 6 + x ** 4 / 24
+    r_expect = sp + (s0[13:17] - sp) * rho ** K
+    dr = ((s1[13:17] - r_expect).abs() / p64[23]).max().item()
+    print(f"\n[closed forms, {n} envs x {K} steps] max |dv| {dv:.2e} m/s, |dp| {dp:.2e} m, angular momentum {dL:.2e} rel, "
+          f"rotational energy {dE:.2e} rel, | |q| - 1 | {dq:.2e}, rotor speed {dr:.2e} of rpm_max; w moved by {moved:.2f} rad/s")
+    assert dv < 5e-4 and dp < 2e-3, (dv, dp)
+    assert dL < 1e-4 and dE < 1e-4, (dL, dE)
+    assert dq < 5e-6, dq
+    assert moved > 0.5
+    assert dr < 2e-5, dr
+    assert torch.equal(S[17:21, :n], act[:, :n].clamp(-1, 1))           # ActionHistory(1) = the clipped action
+    # the same body under the FUSED rollout kernel (hand-packed env step, policy in the loop: with the thrust off its
+    # actions only move the rotors): same start, same closed forms
+    from raptor_amd.foundation_policy import Raptor
+    S[:, :n] = s0.float()
+    torch.cuda.synchronize()
+    policy = Raptor(device)
+    policy.reset()
+    v.rollout(device, env, params, state, policy, rng, K, "fused", autoreset=False)
+    device.synchronize()
+    s2 = S[:, :n].double()
+    dv2 = (s2[7:10] - v_expect).abs().max().item()
+    dp2 = (s2[0:3] - p_expect).abs().max().item()
+    L2 = torch.einsum("ijn,jn->in", rot(s2[3:7]), J * s2[10:13])
+    dL2 = ((L2 - L0).norm(dim=0) / L0.norm(dim=0).clamp_min(1e-12)).max().item()
+    dE2 = (((J * s2[10:13] ** 2).sum(0) - E0).abs() / E0.clamp_min(1e-30)).max().item()
+    dq2 = (s2[3:7].norm(dim=0) - 1).abs().max().item()
+    print(f"[closed forms, fused rollout] max |dv| {dv2:.2e} m/s, |dp| {dp2:.2e} m, angular momentum {dL2:.2e} rel, "
+          f"rotational energy {dE2:.2e} rel, | |q| - 1 | {dq2:.2e}")
+    assert dv2 < 5e-4 and dp2 < 2e-3 and dL2 < 1e-4 and dE2 < 1e-4 and dq2 < 5e-6, (dv2, dp2, dL2, dE2, dq2)
+    # k_step and the fused kernel run the same arithmetic: position, attitude, velocities agree bit for bit
+    assert torch.equal(S[0:13, :n].double(), s1[0:13])
