@@ -1541,3 +1541,55 @@ def test_closed_form_physics_at_full_size(device):
     assert dv2 < 5e-4 and dp2 < 2e-3 and dL2 < 1e-4 and dE2 < 1e-4 and dq2 < 5e-6, (dv2, dp2, dL2, dE2, dq2)
     # k_step and the fused kernel run the same arithmetic: position, attitude, velocities agree bit for bit
     assert torch.equal(S[0:13, :n].double(), s1[0:13])
+
+
+def test_hover_equilibrium_and_torque_sign_conventions(device):
+    """The conventions /root/reference/README.md:23-27 states (FLU body frame, motor order front-right, back-right,
+    back-left, front-left, actions in [-1, 1]) checked on the GPU env step without any restatement: a level body at
+    its hover rotor speed with the hover action stays put; more thrust on the right pair (y < 0) lifts the right side
+    (rotation about -x), on the back pair pitches the nose down (+y), on the back-right / front-left pair (the +z
+    reaction torques) yaws left (+z)."""
+    import torch
+    import raptor_amd.l2f as l2f
+    n = 4096
+    v = l2f.VectorModule(n, 0)
+    rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+    v.initialize_rng(device, rng, 5)
+    v.initialize_environment(device, env)
+    cfg = env.config
+    cfg.termination_enabled = 0
+    cfg.disturbance_force_std = 0.0
+    cfg.disturbance_torque_std = 0.0
+    env.config = cfg
+    v.sample_initial_parameters(device, env, params, rng)          # domain-randomised: every env its own body
+    v.sample_initial_state(device, env, params, state, rng)
+    device.synchronize()
+    P, S, A = params.tensor(), state.tensor(), env.action_tensor()
+    level = torch.zeros(27, n, device="cuda")
+    level[3] = 1.0                                                   # q = identity
+    level[13:17] = P[24, :n]                                         # hover rotor speed
+    hover = P[25, :n]
+
+    def run(action, steps):
+        S[:, :n] = level
+        A[:, :n] = action
+        torch.cuda.synchronize()
+        for _ in range(steps):
+            v.step(device, env, params, state, None, state, rng)
+        device.synchronize()
+        return S[:, :n].double()
+
+    s = run(hover.expand(4, n), 100)                                 # 1 s of hover
+    drift, speed, spin = s[0:3].abs().max().item(), s[7:10].abs().max().item(), s[10:13].abs().max().item()
+    print(f"\n[hover, {n} randomised bodies, 100 steps] |p| {drift:.2e} m, |v| {speed:.2e} m/s, |w| {spin:.2e} rad/s")
+    assert drift < 2e-4 and speed < 5e-4 and spin < 1e-4
+    up = 0.2
+    for name, rotors, axis, sign in (("roll", (0, 1), 10, -1.0), ("pitch", (1, 2), 11, 1.0), ("yaw", (1, 3), 12, 1.0)):
+        a = hover.expand(4, n).clone()
+        for r in range(4):
+            a[r] += up if r in rotors else -up
+        s = run(a, 5)
+        turn = sign * s[axis]
+        others = [k for k in (10, 11, 12) if k != axis]
+        assert (turn > 0).all(), name                               # the named axis turns the stated way
+        assert s[others[0]].abs().max() < 1e-3 * turn.min() and s[others[1]].abs().max() < 1e-3 * turn.min(), name
