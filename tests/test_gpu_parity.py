@@ -1593,3 +1593,39 @@ def test_hover_equilibrium_and_torque_sign_conventions(device):
         others = [k for k in (10, 11, 12) if k != axis]
         assert (turn > 0).all(), name                               # the named axis turns the stated way
         assert s[others[0]].abs().max() < 1e-3 * turn.min() and s[others[1]].abs().max() < 1e-3 * turn.min(), name
+
+
+def test_env_spec_fixture_on_the_gpu(device):
+    """The committed spec-freeze fixture (tests/golden/env_spec.npz: parameters, states, actions of a recorded
+    closed loop; DESIGN.md section 2 says what it is and is not) through the HIP kernels: every recorded transition
+    (state_k, action_k) -> (state_k+1, reward, terminated) and every observation, bit for bit; the actor's actions
+    within its tolerance.  No oracle code runs in this test."""
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "env_spec.npz"))
+    n, steps, seed, offset = (int(x) for x in g["meta"])
+    v = l2f.VectorModule(n, offset)
+    rng, env, params, state, nxt = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState(), v.VectorState()
+    v.initialize_rng(device, rng, seed)
+    v.initialize_environment(device, env)
+    assert bytes(env.config) == g["config_bytes"].tobytes()            # the default MDP is part of the specification
+    v.sample_initial_parameters(device, env, params, rng)
+    assert np.array_equal(params.numpy(), g["params"])
+    v.sample_initial_state(device, env, params, state, rng)
+    assert np.allclose(state.numpy(), g["state0"], rtol=0, atol=2e-6)  # sinf/cosf of the initial attitude
+    policy = Raptor(device)
+    policy.reset()
+    prev = g["state0"]
+    worst = 0.0
+    for k in range(steps):
+        state.set(prev)
+        obs = np.zeros((n, 26), np.float32)
+        v.observe(device, env, params, state, obs, rng)
+        assert np.array_equal(obs, g["obs"][k]), k
+        act = policy.evaluate_step(obs[:, :22])
+        worst = max(worst, float(np.abs(act - g["act"][k]).max()))
+        v.step(device, env, params, state, g["act"][k], nxt, rng)
+        assert np.array_equal(nxt.numpy(), g["state"][k]), k
+        assert np.array_equal(env.rewards(), g["reward"][k]) and np.array_equal(env.terminated(), g["terminated"][k]), k
+        prev = g["state"][k]
+    assert worst < 1e-5, worst

@@ -1,6 +1,7 @@
 """Properties of the oracle's environment restatement (its l2f parity is unpinned — see
 oracle/raptor_oracle.c header; these tests pin the spec's own invariants and the conventions
 the reference states in README.md:23-27)."""
+import os
 import numpy as np
 import pytest
 
@@ -367,3 +368,21 @@ def test_threads_do_not_change_results(oracle, weights):
         oracle.rollout(cfg, weights, 0, 0, 0, P, S, H, 100, 1, st, nthreads=nt)
         res.append((S.copy(), st.returns.copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_env_spec_fixture():
+    """tests/golden/env_spec.npz (made by tests/golden/make_env_golden.py) freezes what this repository's env
+    specification computes for a 16-env, 40-step closed loop with the shipped policy: the oracle must still reproduce
+    it bit for bit - a change of the specification has to come with a regenerated fixture, it cannot slip in."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_env_golden", os.path.join(here, "golden", "make_env_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = np.load(os.path.join(here, "golden", "env_spec.npz"))
+    got = mod.generate()
+    assert sorted(want.files) == sorted(got)
+    for k in want.files:
+        assert np.array_equal(want[k], got[k], equal_nan=True), k
+    # sanity of the recorded loop itself: the policy holds every one of the 16 randomised bodies
+    assert want["terminated"].sum() == 0 and np.abs(want["state"][-1][:, :3]).max() < 1.0
