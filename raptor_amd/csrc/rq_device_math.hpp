@@ -512,17 +512,18 @@ enum { OFF_W0 = 0, OFF_B0 = 352, OFF_WI = 368, OFF_WH = 1136, OFF_BI = 1904, OFF
 // s: k-slot q then carries input feature 4q+s and the A operand (weights, one VGPR per
 // (16-row tile, K-step)) is laid out to match: lane (q, j) holds W[row j][4q + s].  So hidden
 // state, layer_0 output and all gate values live in the Q layout for the whole rollout, the
-// policy parameters are register-stationary (QW_REGS VGPRs: no LDS, no scalar loads) and only
-// two layout changes exist:
-//   observation (native) -> B operands: six 4x4 lane-group transposes (v_permlane32_swap +
-//     v_permlane16_swap, 4 instructions each);
+// policy parameters are register-stationary (QW_REGS VGPRs: no weight traffic through LDS, no scalar
+// loads) and only two layout changes exist:
+//   observation (native) -> B operands: through a 64 x 25-float LDS tile per wave, written and read
+//     while the GRU's recurrent MFMAs execute (ActorF32T::step; the bf16 actor, whose MFMAs co-execute
+//     with the VALU, keeps the lane-group transposes: v_permlane32_swap + v_permlane16_swap);
 //   action: free — tile t's W2 is placed in A rows 4t..4t+3, the four tiles accumulate into
 //     one D whose lane (q, j) then holds the 4 actions of env (q, j): the native layout.
 //
 // Per wave and step: 24 + 96 + 16 = 136 MFMAs (4352 matrix cycles for 64 envs).
 // Summation order inside a dot product is (s = 0..3 outer, q = 0..3 inner), i.e. input
-// features 0,4,8,12,1,5,...; r and z gates chain W_i y0 and W_h h into one accumulator and the
-// biases are added last.  These are fp32 re-associations of the oracle's k-ascending chains
+// features 0,4,8,12,1,5,...; r and z gates chain the bias (the C operand of the first MFMA), W_h h
+// and W_i y0 into one accumulator, in that order.  These are fp32 re-associations of the oracle's k-ascending chains
 // (differences ~1e-7, covered by the actor tolerance).
 //
 // Packed weight image: enum QW_* in rq_kernels.hpp (shared with the host-side packer rq_pack.cpp).
