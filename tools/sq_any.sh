@@ -1,14 +1,15 @@
 #!/bin/bash
 # Run ON THE GPU BOX:  bash tools/sq_any.sh <tag> <kernel substring> -- <command...>
 # SQ issue/wait counters of the dispatches of one kernel under any command -> gpurun_out/sq_<tag>.json
+# (SQ_A / SQ_B in the environment replace the two counter sets, 8 SQ slots per pass)
 set -u
 TAG=$1; KERN=$2; shift 3
 R=$PWD
 OUT=$R/gpurun_out/sqany_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-A="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"
-B="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"
+A=${SQ_A:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"}
+B=${SQ_B:-"SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"}
 (cd $R && timeout 600 rocprofv3 --pmc $A --kernel-trace --output-format csv -d $OUT/a -o p -- "$@" > $OUT/a.log 2>&1); echo "pass A rc=$?"
 (cd $R && timeout 600 rocprofv3 --pmc $B --kernel-trace --output-format csv -d $OUT/b -o p -- "$@" > $OUT/b.log 2>&1); echo "pass B rc=$?"
 cd $R
