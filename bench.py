@@ -73,8 +73,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5000)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--mode", default="fused", choices=["fused", "chained"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="actor operand precision: fp32 = BASELINE config 2 (headline), bf16 = config 5")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f16x2"],
+                    help="actor operand precision: fp32 = BASELINE config 2 (headline), bf16 = config 5, "
+                         "f16x2 = split-f16 operands (fp32-grade results on the co-executing matrix pipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -128,7 +129,9 @@ def pmc_traffic(kernel, grid):
 
 def fused_kernel_name(precision, n, steps_per_launch):
     """The instantiation launch_rollout_fused picks (raptor_amd/csrc/rq_kernels.hip), as rocprofv3 prints it."""
-    if precision == "bf16":
+    if precision == "f16x2":
+        actor = "rq::ActorF16X2"
+    elif precision == "bf16":
         actor = "rq::ActorBF16Lean" if n > 65536 else "rq::ActorBF16"
     else:
         actor = "rq::ActorF32T<true> " if n > 65536 else "rq::ActorF32T<false> "
@@ -520,7 +523,9 @@ def main():
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 6),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16 actor operands (fp32 accumulate) + f32 dynamics",
+        "dtype": {"fp32": "f32", "bf16": "bf16 actor operands (fp32 accumulate) + f32 dynamics",
+                  "f16x2": "actor operands as two f16 pieces each (22 significand bits, fp32 accumulate) + f32 dynamics"
+                  }[args.precision],
         "data": "synthetic",
         "config": {"workload": f"{n} parallel quadrotors per GPU, fp32 RK4 dynamics + {args.precision} GRU actor "
                                f"(RAPTOR checkpoint), domain-randomised params, auto-reset, {args.mode} rollout",
@@ -540,13 +545,13 @@ def main():
     if rank == 0:
         launches = len(plan) if args.mode == "fused" else 3 * args.steps
         avg_launch_s = launch_ms * 1e-3                  # one rollout launch (median over the timed regions)
-        if args.mode == "fused" and args.precision == "bf16":
+        if args.mode == "fused" and args.precision in ("bf16", "f16x2"):
             # config 5: the contractions run on the bf16 XDL pipe (24 MFMAs per wave-step, a few % of its
             # peak); what bounds the kernel is the fp32 VALU work that remains (gates + env)
             steps_per_launch = args.steps / len(plan)
             valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
             mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
-            kname = fused_kernel_name("bf16", n, steps_per_launch)
+            kname = fused_kernel_name(args.precision, n, steps_per_launch)
             tr = pmc_traffic(kname, n)
             result["roofline"] = {
                 "kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
@@ -554,10 +559,12 @@ def main():
                 "traffic": None if tr is None else tr["bytes_per_launch"],
                 "traffic_source": tr,
                 "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
-                        f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the bf16 MFMA pipe at "
-                        f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak",
+                        f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the 16-bit MFMA pipe at "
+                        f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak"
+                        + (" (x3 issued: hi.hi, hi.lo, lo.hi products)" if args.precision == "f16x2" else ""),
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                "steps_per_launch": steps_per_launch, "sq_counters": sq_profile("bf16")}
+                "steps_per_launch": steps_per_launch,
+                "sq_counters": sq_profile("bf16") if args.precision == "bf16" else None}
         elif args.mode == "fused":
             steps_per_launch = args.steps / len(plan)
             flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch

@@ -277,7 +277,11 @@ RQ_API int rq_env_reset_statistics(rq_env* env);
 /* ---- Policy (README.md:19-24,48,94,97; checkpoint.h:34-194) ---------------------------- */
 typedef enum rq_policy_precision {
     RQ_POLICY_FP32 = 0,       /* exact fp32 on v_mfma_f32_16x16x4_f32 (one rounded fma per product), operands register-stationary */
-    RQ_POLICY_BF16_MFMA = 1   /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates */
+    RQ_POLICY_BF16_MFMA = 1,  /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates */
+    RQ_POLICY_F16X2_MFMA = 2  /* every operand as two f16 pieces (hi + lo / 2048, 22 significand bits) on
+                                 v_mfma_f32_16x16x32_f16, exact products, fp32 accumulate and gates: known-answer error
+                                 ~1e-6 like fp32, on the matrix pipe that overlaps with the vector ALU.  Not fp32
+                                 arithmetic: RQ_POLICY_FP32 stays the default and the benchmarked configuration */
 } rq_policy_precision;
 
 /* weights: RQ_POLICY_NUM_WEIGHTS float32 in the order documented at RQ_POLICY_NUM_WEIGHTS
@@ -285,6 +289,12 @@ typedef enum rq_policy_precision {
 RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weights, rq_policy** out);
 RQ_API int rq_policy_destroy(rq_policy* pol);
 RQ_API int rq_policy_set_precision(rq_policy* pol, int precision);
+/* Host only (no GPU involved): the per-lane register image the actor kernels of `precision` keep their operands in,
+ * `*floats` = its size in 4-byte words (64 lanes x registers; layout: raptor_amd/csrc/rq_kernels.hpp QW_ / BW_ / FW_).
+ * `image` may be NULL to query the size.  A diagnostic: it lets the packing (pre-scaled gate rows, bf16 rounding,
+ * the f16 hi / lo split) be checked without a device. */
+RQ_API int rq_policy_pack_image(const float* weights, size_t n_weights, int precision, float* image, size_t capacity,
+                                size_t* floats);
 /* Optional stages named by rl-tools' layer list (README.md:114,116) that the SHIPPED checkpoint does not
  * contain (checkpoint.h:185 chains layer_0, layer_1, layer_2 only) — identity unless enabled; their
  * reference semantics are unpinned (no source or test vector in the reference tree):

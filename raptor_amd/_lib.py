@@ -21,7 +21,7 @@ STATE_DIM = 27
 
 ROLLOUT_FUSED, ROLLOUT_CHAINED = 0, 1
 ROLLOUT_AUTORESET = 1
-POLICY_FP32, POLICY_BF16_MFMA = 0, 1
+POLICY_FP32, POLICY_BF16_MFMA, POLICY_F16X2_MFMA = 0, 1, 2
 ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
 COMM_ID_BYTES = 128
 
@@ -141,6 +141,7 @@ _SIGNATURES = {
     "rq_policy_create": [_vp, _fp, C.c_size_t, C.POINTER(_vp)],
     "rq_policy_destroy": [_vp],
     "rq_policy_set_precision": [_vp, C.c_int],
+    "rq_policy_pack_image": [_fp, C.c_size_t, C.c_int, _fp, C.c_size_t, C.POINTER(C.c_size_t)],
     "rq_policy_set_standardize": [_vp, _fp, _fp],
     "rq_policy_set_squash": [_vp, C.c_int],
     "rq_policy_set_sample_and_squash": [_vp, C.c_int, _fp, _fp, C.c_uint64],

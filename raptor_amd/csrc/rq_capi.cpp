@@ -118,6 +118,7 @@ struct rq_policy {
     float* w_dev = nullptr;       // raw parameters (checkpoint order)
     float* w_packed = nullptr;    // f32 MFMA operand image, rq::RQ_PACKED_FLOATS floats
     float* w_packed_bf16 = nullptr;   // bf16 MFMA operand image, rq::RQ_PACKED_BF16_FLOATS floats
+    float* w_packed_f16x2 = nullptr;  // split-f16 MFMA operand image, rq::RQ_PACKED_F16X2_FLOATS floats
     float w_host[RQ_POLICY_NUM_WEIGHTS];      // as loaded (checkpoint order)
     float w_eff[RQ_POLICY_NUM_WEIGHTS];       // with the optional Standardize stage folded into layer_0
     bool standardize = false;
@@ -338,7 +339,8 @@ rq::SasArgs sas_of(const rq_policy* pol, uint32_t epoch, const uint32_t* epoch_b
 }
 
 const float* packed_of(const rq_policy* pol) {
-    return pol->precision == RQ_POLICY_BF16_MFMA ? pol->w_packed_bf16 : pol->w_packed;
+    return pol->precision == RQ_POLICY_BF16_MFMA ? pol->w_packed_bf16
+         : pol->precision == RQ_POLICY_F16X2_MFMA ? pol->w_packed_f16x2 : pol->w_packed;
 }
 
 // Size the per-batch buffers on first use (Raptor sizes its hidden state on the first
@@ -888,14 +890,16 @@ static int policy_upload(rq_policy* p) {
             p->w_eff[352 + o] = p->w_host[352 + o] - shift;
         }
     }
-    std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS);
+    std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS), packed_split(rq::RQ_PACKED_F16X2_FLOATS);
     rq::pack_policy(p->w_eff, packed.data());
     rq::pack_policy_bf16(p->w_eff, packed16.data());
+    rq::pack_policy_f16x2(p->w_eff, packed_split.data());
     DeviceScope on_device(p->dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipStreamSynchronize(p->dev->stream));
     RQ_HIP(hipMemcpy(p->w_dev, p->w_eff, sizeof(p->w_eff), hipMemcpyHostToDevice));
     RQ_HIP(hipMemcpy(p->w_packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     RQ_HIP(hipMemcpy(p->w_packed_bf16, packed16.data(), packed16.size() * sizeof(float), hipMemcpyHostToDevice));
+    RQ_HIP(hipMemcpy(p->w_packed_f16x2, packed_split.data(), packed_split.size() * sizeof(float), hipMemcpyHostToDevice));
     return RQ_OK;
 }
 
@@ -913,8 +917,11 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
     if (e != hipSuccess) { delete p; return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed"); }
     e = hipMalloc(&p->w_packed, (size_t)rq::RQ_PACKED_FLOATS * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&p->w_packed_bf16, (size_t)rq::RQ_PACKED_BF16_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p->w_packed_f16x2, (size_t)rq::RQ_PACKED_F16X2_FLOATS * sizeof(float));
     if (e != hipSuccess) {
-        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed); delete p;
+        (void)hipFree(p->w_dev); if (p->w_packed) (void)hipFree(p->w_packed);
+        if (p->w_packed_bf16) (void)hipFree(p->w_packed_bf16);
+        delete p;
         return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_create: device allocation failed");
     }
     rc = policy_upload(p);
@@ -930,15 +937,33 @@ RQ_API int rq_policy_destroy(rq_policy* pol) {
     if (pol->w_dev) (void)hipFree(pol->w_dev);
     if (pol->w_packed) (void)hipFree(pol->w_packed);
     if (pol->w_packed_bf16) (void)hipFree(pol->w_packed_bf16);
+    if (pol->w_packed_f16x2) (void)hipFree(pol->w_packed_f16x2);
     if (pol->ls_image) (void)hipFree(pol->ls_image);
     delete pol;
     return RQ_OK;
 }
 
+RQ_API int rq_policy_pack_image(const float* weights, size_t n_weights, int precision, float* image, size_t capacity,
+                                size_t* floats) {
+    RQ_REQUIRE(weights && floats, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(n_weights == RQ_POLICY_NUM_WEIGHTS, RQ_ERR_INVALID_ARGUMENT, "expected 2084 weights");
+    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA || precision == RQ_POLICY_F16X2_MFMA,
+               RQ_ERR_INVALID_ARGUMENT, "unknown precision");
+    const size_t need = precision == RQ_POLICY_FP32 ? (size_t)rq::RQ_PACKED_FLOATS
+                      : precision == RQ_POLICY_BF16_MFMA ? (size_t)rq::RQ_PACKED_BF16_FLOATS : (size_t)rq::RQ_PACKED_F16X2_FLOATS;
+    *floats = need;
+    if (!image) return RQ_OK;
+    RQ_REQUIRE(capacity >= need, RQ_ERR_INVALID_ARGUMENT, "image buffer too small");
+    if (precision == RQ_POLICY_FP32) rq::pack_policy(weights, image);
+    else if (precision == RQ_POLICY_BF16_MFMA) rq::pack_policy_bf16(weights, image);
+    else rq::pack_policy_f16x2(weights, image);
+    return RQ_OK;
+}
+
 RQ_API int rq_policy_set_precision(rq_policy* pol, int precision) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA, RQ_ERR_INVALID_ARGUMENT,
-               "unknown precision");
+    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA || precision == RQ_POLICY_F16X2_MFMA,
+               RQ_ERR_INVALID_ARGUMENT, "unknown precision");
     pol->precision = precision;
     return RQ_OK;
 }

@@ -919,6 +919,177 @@ struct ActorBF16 {
 
 struct ActorBF16Lean : ActorBF16 {};     // same arithmetic, compiled for 2 waves/SIMD (batches > 65 536 envs)
 
+// ---- split-f16 operands on v_mfma_f32_16x16x32_f16: fp32-grade contractions on the co-executing matrix pipe ----
+// The exact-f32 MFMA shares the FMA hardware with the VALU (the two never overlap): that is
+// the ceiling of the fp32 build.  The f16 MFMA does overlap with VALU work, and an fp32 number splits into two
+// f16 pieces v = hi + lo / 2048 with hi = f16(v), lo = f16((v - hi) * 2048) (the residual is exact in fp32 and
+// the scale keeps it out of the f16 subnormals): 22 of the 24 significand bits.  With weights split on the host
+// and activations here,
+//     sum_k w x  ~=  sum w_hi x_hi  +  (sum w_hi x_lo + sum w_lo x_hi) / 2048        (f16 products are exact in
+// the fp32 accumulator; the dropped lo x lo term is 2^-22 relative) - three MFMAs per contraction instead of one,
+// same operand layout and k-slot assignment as the bf16 actor (FW_* images = BW_* twice, hi then lo).
+// Known-answer error 1e-6 (the fp32 bar is 1e-5, the bf16 actor sits at 2e-2); not the default: BASELINE config 2
+// is fp32 arithmetic and that is what RQ_POLICY_FP32 computes.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ActorF16X2 {
+    static constexpr int kPackedRegs = FW_REGS;
+    static constexpr float kSplit = 2048.0f, kJoin = 1.0f / 2048.0f;
+    uint32_t A[FW_BR];
+    float B[FW_REGS - FW_BR];
+
+    template <int WAVES>
+    __device__ __forceinline__ void load(const float* __restrict__ packed) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t* pu = reinterpret_cast<const uint32_t*>(packed);
+#pragma unroll
+        for (int v = 0; v < FW_BR; ++v) A[v] = pu[v * 64 + lane];
+#pragma unroll
+        for (int v = 0; v < FW_REGS - FW_BR; ++v) B[v] = packed[(FW_BR + v) * 64 + lane];
+    }
+    __device__ __forceinline__ float h0(int r) const { return B[FW_H0 - FW_BR + r]; }
+    __device__ __forceinline__ f16x8 a_op(int base) const {
+        const dwordx4 u = {A[base], A[base + 1], A[base + 2], A[base + 3]};
+        return __builtin_bit_cast(f16x8, u);
+    }
+    __device__ __forceinline__ f32x4 bias(int base) const {
+        return f32x4{B[base - FW_BR], B[base - FW_BR + 1], B[base - FW_BR + 2], B[base - FW_BR + 3]};
+    }
+    static __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    // (v0, v1) -> packed hi pieces, packed lo pieces: v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add, v_pk_mul, v_cvt_pk
+    static __device__ __forceinline__ void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+        const f32x2 v = {v0, v1};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * splat(kSplit);
+        hi = __builtin_bit_cast(uint32_t, h);
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+    }
+    static __device__ __forceinline__ f16x8 tuple(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+        const dwordx4 u = {d0, d1, d2, d3};
+        return __builtin_bit_cast(f16x8, u);
+    }
+    // hi-accumulator + lo-accumulator / 2048
+    static __device__ __forceinline__ f32x4 join(const f32x4& hi, const f32x4& lo) {
+        const f32x2 a = pk_fma(f32x2{lo[0], lo[1]}, splat(kJoin), f32x2{hi[0], hi[1]});
+        const f32x2 b = pk_fma(f32x2{lo[2], lo[3]}, splat(kJoin), f32x2{hi[2], hi[3]});
+        return f32x4{a[0], a[1], b[0], b[1]};
+    }
+    // one contraction: A image pair at `base` (hi) / `base_lo`, B tuples (hi, lo), C = bias or zero
+    __device__ __forceinline__ f32x4 dot(int base, int base_lo, f16x8 xh, f16x8 xl, f32x4 c) const {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 hi = mfma(a_op(base), xh, c);
+        f32x4 lo = mfma(a_op(base), xl, zero);
+        lo = mfma(a_op(base_lo), xh, lo);
+        return join(hi, lo);
+    }
+
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
+        early_stores();           // the f16 MFMAs co-execute with everything else: no placement needed
+        step(o, hQ, a);
+    }
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // observation: split in the native layout, pairs (o[8d + c], o[8d + 4 + c]) as in the bf16 actor (feature 22 is
+        // the constant 1 that carries the bias, 23 padding), then the lane-group transposes on hi and lo dwords
+        float PH[3][4], PL[3][4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int f0 = 8 * d + c, f1 = 8 * d + 4 + c;
+                const float v0 = o[f0 < 22 ? f0 : 21];
+                const float v1 = f1 < 22 ? o[f1 < 22 ? f1 : 21] : (f1 == 22 ? 1.0f : 0.0f);
+                uint32_t hi, lo;
+                split2(v0, v1, hi, lo);
+                PH[d][c] = __builtin_bit_cast(float, hi);
+                PL[d][c] = __builtin_bit_cast(float, lo);
+            }
+            transpose4(PH[d][0], PH[d][1], PH[d][2], PH[d][3]);
+            transpose4(PL[d][0], PL[d][1], PL[d][2], PL[d][3]);
+        }
+        uint32_t hh[4][2], hl[4][2];          // the hidden state's pieces: k-slots 4..7 of the gate operand
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            split2(hQ[t][0], hQ[t][1], hh[t][0], hl[t][0]);
+            split2(hQ[t][2], hQ[t][3], hh[t][1], hl[t][1]);
+        }
+        // Stage-major order: the MFMAs of all four tiles of a layer are independent of one another and of the vector
+        // work of the tiles before them - issued together they pipeline on the matrix cores while the VALU joins,
+        // splits and evaluates gates (tile by tile the compiler chained them through one accumulator with s_nops).
+        uint32_t yh[4][2], yl[4][2];
+        {
+            f32x4 H[4], L[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f16x8 xh = tuple(__builtin_bit_cast(uint32_t, PH[0][t]), __builtin_bit_cast(uint32_t, PH[1][t]),
+                                       __builtin_bit_cast(uint32_t, PH[2][t]), 0u);
+                const f16x8 xl = tuple(__builtin_bit_cast(uint32_t, PL[0][t]), __builtin_bit_cast(uint32_t, PL[1][t]),
+                                       __builtin_bit_cast(uint32_t, PL[2][t]), 0u);
+                H[t] = mfma(a_op(FW_L0H), xh, zero);
+                L[t] = mfma(a_op(FW_L0H), xl, zero);
+                L[t] = mfma(a_op(FW_L0L), xh, L[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 y0 = join(H[t], L[t]);
+                split2(relu(y0[0]), relu(y0[1]), yh[t][0], yl[t][0]);
+                split2(relu(y0[2]), relu(y0[3]), yh[t][1], yl[t][1]);
+            }
+        }
+        // gates: accumulators = exp2 arguments (rows pre-scaled on the host before the split, biases through C)
+        {
+            const f32x4 cb[4] = {bias(FW_BR), bias(FW_BZ), bias(FW_BNI), bias(FW_BNH)};
+            constexpr int TP = 2;             // tiles per pass: 16 accumulators live (all four at once spilled to AGPRs)
+#pragma unroll
+            for (int t0 = 0; t0 < 4; t0 += TP) {
+                f32x4 H[TP][4], L[TP][4];
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    const int t = t0 + u;
+                    const f16x8 xh = tuple(yh[t][0], yh[t][1], hh[t][0], hh[t][1]);
+                    const f16x8 xl = tuple(yl[t][0], yl[t][1], hl[t][0], hl[t][1]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) H[u][g] = mfma(a_op(FW_RH + 8 * g), xh, cb[g]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) L[u][g] = mfma(a_op(FW_RH + 8 * g), xl, zero);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) L[u][g] = mfma(a_op(FW_RL + 8 * g), xh, L[u][g]);
+                }
+#pragma unroll
+                for (int u = 0; u < TP; ++u)
+                    gru_gates_prescaled(join(H[u][0], L[u][0]), join(H[u][1], L[u][1]), join(H[u][2], L[u][2]),
+                                        join(H[u][3], L[u][3]), hQ[t0 + u]);
+            }
+        }
+        // layer_2: the gate operand's tuple with the new hidden state in k-slots 4..7 (A is zero in slots 0..3)
+        f32x4 dh0 = bias(FW_B2), dh1 = zero, dl0 = zero, dl1 = zero;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t nh0, nl0, nh1, nl1;
+            split2(hQ[t][0], hQ[t][1], nh0, nl0);
+            split2(hQ[t][2], hQ[t][3], nh1, nl1);
+            const f16x8 xh = tuple(yh[t][0], yh[t][1], nh0, nh1);
+            const f16x8 xl = tuple(yl[t][0], yl[t][1], nl0, nl1);
+            if (t & 1) {
+                dh1 = mfma(a_op(FW_L2H + 4 * t), xh, dh1);
+                dl1 = mfma(a_op(FW_L2H + 4 * t), xl, dl1);
+                dl1 = mfma(a_op(FW_L2L + 4 * t), xh, dl1);
+            } else {
+                dh0 = mfma(a_op(FW_L2H + 4 * t), xh, dh0);
+                dl0 = mfma(a_op(FW_L2H + 4 * t), xl, dl0);
+                dl0 = mfma(a_op(FW_L2L + 4 * t), xh, dl0);
+            }
+        }
+        const f32x4 d0 = join(dh0, dl0), d1 = join(dh1, dl1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
+    }
+};
+
 // Optional output stage SampleAndSquash (rl-tools nn/layers/sample_and_squash, /root/reference/README.md:116; NOT part
 // of the shipped checkpoint, whose chain ends in a plain Dense, checkpoint.h:185; semantics [UPSTREAM-UNVERIFIED]):
 // the final dense layer then has 8 outputs [mean (4) | log_std (4)] and

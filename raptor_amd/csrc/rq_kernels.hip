@@ -197,6 +197,8 @@ template <typename A> struct WavesPerSimd { static constexpr int value = 1; stat
 template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; static constexpr bool bf16 = false; };
 template <> struct WavesPerSimd<ActorBF16> { static constexpr int value = 1; static constexpr bool bf16 = true; };
 template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; static constexpr bool bf16 = true; };
+// the split-f16 actor: its MFMAs co-execute with the VALU like the bf16 ones; one build, the 512-register budget
+template <> struct WavesPerSimd<ActorF16X2> { static constexpr int value = 1; static constexpr bool bf16 = true; };
 
 // Raptor evaluated over a whole observation SEQUENCE in one launch (rl-tools evaluates [seq, batch, feature]
 // tensors: the known-answer example of the checkpoint is one, checkpoint.h:197-215): obs [T][n][stride]
@@ -639,7 +641,9 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     const uint32_t groups = (n + 63) / 64;
     const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
-    if (precision == RQ_POLICY_BF16_MFMA)
+    if (precision == RQ_POLICY_F16X2_MFMA)
+        k_actor_step<ActorF16X2><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
+    else if (precision == RQ_POLICY_BF16_MFMA)
         k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
     else
         // the two-tiles-per-pass build: ~30 registers fewer live, 2-3 % faster at every size (same arithmetic)
@@ -655,7 +659,8 @@ hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, cons
     const unsigned g = grid_for(n, kFusedBlock);
     const bool lean = n > 65536u;          // two waves per SIMD only pay when there are that many
 #define RQ_LAUNCH_SEQ(ACT) k_actor_sequence<ACT><<<g, kFusedBlock, 0, s>>>(n, steps, packed, obs, stride, hidden, ld_h, act, squash)
-    if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_SEQ(ActorBF16Lean); else RQ_LAUNCH_SEQ(ActorBF16); }
+    if (precision == RQ_POLICY_F16X2_MFMA) RQ_LAUNCH_SEQ(ActorF16X2);
+    else if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_SEQ(ActorBF16Lean); else RQ_LAUNCH_SEQ(ActorBF16); }
     else                                  { if (lean) RQ_LAUNCH_SEQ(ActorF32Lean); else RQ_LAUNCH_SEQ(ActorF32); }
 #undef RQ_LAUNCH_SEQ
     return hipGetLastError();
@@ -670,7 +675,8 @@ hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t
     const unsigned g = grid_for(n, kFusedBlock);
     const bool lean = n > 65536u;
 #define RQ_LAUNCH_RELABEL(ACT) k_actor_relabel<ACT><<<g, kFusedBlock, 0, s>>>(n, ld, steps, packed, obs, done, hidden, ld_h, act, squash)
-    if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_RELABEL(ActorBF16Lean); else RQ_LAUNCH_RELABEL(ActorBF16); }
+    if (precision == RQ_POLICY_F16X2_MFMA) RQ_LAUNCH_RELABEL(ActorF16X2);
+    else if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_RELABEL(ActorBF16Lean); else RQ_LAUNCH_RELABEL(ActorBF16); }
     else                                  { if (lean) RQ_LAUNCH_RELABEL(ActorF32Lean); else RQ_LAUNCH_RELABEL(ActorF32); }
 #undef RQ_LAUNCH_RELABEL
     return hipGetLastError();
@@ -735,8 +741,11 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     // build with the cheaper prologue.
     const bool lean = b.n > 65536u;
     if (sas.mode != RQ_SAS_OFF) {
-        if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_SAS_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_SAS_ACT(ActorF32Lean);
+        if (precision == RQ_POLICY_F16X2_MFMA)     RQ_LAUNCH_FUSED_SAS_ACT(ActorF16X2);
+        else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_SAS_ACT(ActorBF16Lean);
+        else                                       RQ_LAUNCH_FUSED_SAS_ACT(ActorF32Lean);
     }
+    else if (precision == RQ_POLICY_F16X2_MFMA) RQ_LAUNCH_FUSED_ACT(ActorF16X2);
     else if (precision == RQ_POLICY_BF16_MFMA) {
         if (lean) RQ_LAUNCH_FUSED_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_ACT(ActorBF16);
     }

@@ -168,12 +168,23 @@ enum {
     BW_REGS = 60
 };
 
+// split-f16 actor (v_mfma_f32_16x16x32_f16, rq_device_math.hpp ActorF16X2): every A operand of the bf16 image twice,
+// the f16 of the (pre-scaled) weight and the f16 of its residual x 2048; biases fp32 as in the f32 image
+enum {
+    FW_L0H = 0, FW_L0L = 4, FW_RH = 8, FW_RL = 12, FW_ZH = 16, FW_ZL = 20, FW_NIH = 24, FW_NIL = 28, FW_NHH = 32,
+    FW_NHL = 36, FW_L2H = 40, FW_L2L = 56,                                  // f16x8 A operands, 4 dwords each (layer_2: x 4 tiles)
+    FW_BR = 72, FW_BZ = 76, FW_BNI = 80, FW_BNH = 84, FW_H0 = 88, FW_B2 = 92,   // fp32
+    FW_REGS = 96
+};
+
 // Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
 // v_mfma_f32_16x16x4_f32 instructions read as A / C operands (layout: rq_device_math.hpp "actor").
-enum { RQ_PACKED_FLOATS = QW_REGS * 64, RQ_PACKED_BF16_FLOATS = BW_REGS * 64 };
+enum { RQ_PACKED_FLOATS = QW_REGS * 64, RQ_PACKED_BF16_FLOATS = BW_REGS * 64, RQ_PACKED_F16X2_FLOATS = FW_REGS * 64 };
 void pack_policy(const float* weights, float* packed);
 // the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
 void pack_policy_bf16(const float* weights, float* packed);
+// and for the split-f16 actor: 72 dword images of f16 pairs + 24 fp32 images
+void pack_policy_f16x2(const float* weights, float* packed);
 // log-std rows of a SampleAndSquash head: w_ls [4][16] row-major (nullptr = zeros), b_ls [4] -> 20 x 64 floats
 enum { RQ_LOGSTD_FLOATS = 20 * 64 };
 void pack_logstd_head(const float* w_ls, const float* b_ls, float* image);

@@ -1,6 +1,7 @@
 // rq_pack.cpp — host-side packing of the policy parameters (checkpoint order) into the per-lane
 // operand images the actor kernels keep in registers (index enums QW_* / BW_* in rq_kernels.hpp).
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 
 #include "rq_kernels.hpp"
@@ -87,6 +88,75 @@ void pack_policy_bf16(const float* w, float* packed) {
             img(BW_BNH + r) = kT * w[BH + 32 + 4 * q + r];
             img(BW_H0 + r) = w[H0 + 4 * q + r];
             img(BW_B2 + r) = w[B2 + r];
+        }
+    }
+}
+
+// float -> IEEE binary16, round to nearest even (what v_cvt_pk_f16_f32 does on the device side of the split)
+static uint16_t to_f16_rne(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    const uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (ax > 0x7f800000u ? 0x200u : 0u));     // inf, NaN
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                  // >= 65520 rounds to infinity
+    if (ax < 0x38800000u) {                                                    // below 2^-14: f16 subnormal (or 0)
+        float a;
+        std::memcpy(&a, &ax, 4);
+        return (uint16_t)(sign | (uint32_t)std::lrintf(a * 16777216.0f));       // units of 2^-24, RNE; 1024 = 2^-14
+    }
+    uint32_t h = ((((ax >> 23) - 112u) << 10) | ((ax & 0x7fffffu) >> 13));
+    const uint32_t rem = ax & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                    // a carry walks into the exponent
+    return (uint16_t)(sign | h);
+}
+static float from_f16(uint16_t h) {
+    const uint32_t e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 0x400u), (int)e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+
+// Layout: the bf16 image's A operands twice (enum FW_*): `base` holds f16(v), `base_lo` f16((v - f16(v)) * 2048).
+void pack_policy_f16x2(const float* w, float* packed) {
+    enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, H0 = 2000, W2 = 2016, B2 = 2080 };
+    for (int i = 0; i < RQ_PACKED_F16X2_FLOATS; ++i) packed[i] = 0.0f;
+    uint32_t* pu = reinterpret_cast<uint32_t*>(packed);
+    const float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, i = l & 15;
+        auto put16 = [&](int base, int e, uint16_t h) {
+            uint32_t& d = pu[(base + e / 2) * 64 + l];
+            d = (e & 1) ? ((d & 0x0000ffffu) | ((uint32_t)h << 16)) : ((d & 0xffff0000u) | h);
+        };
+        auto put = [&](int base, int base_lo, int e, float v) {
+            const uint16_t hi = to_f16_rne(v);
+            put16(base, e, hi);
+            put16(base_lo, e, to_f16_rne((v - from_f16(hi)) * 2048.0f));
+        };
+        for (int e = 0; e < 8; ++e) {
+            const int f = 4 * e + q;
+            put(FW_L0H, FW_L0L, e, e < 6 ? (f < 22 ? w[W0 + i * 22 + f] : (f == 22 ? w[B0 + i] : 0.0f)) : 0.0f);
+            const float w_r = e < 4 ? w[WI + (0 + i) * 16 + 4 * q + e] : w[WH + (0 + i) * 16 + 4 * q + e - 4];
+            const float w_z = e < 4 ? w[WI + (16 + i) * 16 + 4 * q + e] : w[WH + (16 + i) * 16 + 4 * q + e - 4];
+            put(FW_RH, FW_RL, e, kS * w_r);
+            put(FW_ZH, FW_ZL, e, kS * w_z);
+            put(FW_NIH, FW_NIL, e, e < 4 ? kT * w[WI + (32 + i) * 16 + 4 * q + e] : 0.0f);
+            put(FW_NHH, FW_NHL, e, e < 4 ? 0.0f : kT * w[WH + (32 + i) * 16 + 4 * q + e - 4]);
+            for (int t = 0; t < 4; ++t)
+                put(FW_L2H + 4 * t, FW_L2L + 4 * t, e,
+                    (e >= 4 && (i >> 2) == t) ? w[W2 + (i & 3) * 16 + 4 * q + e - 4] : 0.0f);
+        }
+        auto img = [&](int v) -> float& { return packed[v * 64 + l]; };
+        for (int r = 0; r < 4; ++r) {
+            img(FW_BR + r) = kS * (w[BI + 4 * q + r] + w[BH + 4 * q + r]);
+            img(FW_BZ + r) = kS * (w[BI + 16 + 4 * q + r] + w[BH + 16 + 4 * q + r]);
+            img(FW_BNI + r) = kT * w[BI + 32 + 4 * q + r];
+            img(FW_BNH + r) = kT * w[BH + 32 + 4 * q + r];
+            img(FW_H0 + r) = w[H0 + 4 * q + r];
+            img(FW_B2 + r) = w[B2 + r];
         }
     }
 }

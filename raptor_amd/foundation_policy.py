@@ -42,13 +42,15 @@ def _get_default_device():
     return _default_device
 
 
-PRECISIONS = {"fp32": _lib.POLICY_FP32, "bf16": _lib.POLICY_BF16_MFMA}
+PRECISIONS = {"fp32": _lib.POLICY_FP32, "bf16": _lib.POLICY_BF16_MFMA, "f16x2": _lib.POLICY_F16X2_MFMA}
 
 
 class Raptor:
     """``precision``: "fp32" (exact-f32 MFMA, matches the reference KATs to < 1e-5) or "bf16"
     (BASELINE config 5: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates;
-    ~2e-2 max abs action deviation on the KATs)."""
+    ~2e-2 max abs action deviation on the KATs) or "f16x2" (every operand as two f16 pieces on
+    v_mfma_f32_16x16x32_f16: fp32-grade results, KATs to ~1e-6, at close to the bf16 actor's speed; not fp32
+    arithmetic, so not the default)."""
 
     def __init__(self, device=None, weights=None, precision="fp32"):
         if precision not in PRECISIONS:

@@ -151,3 +151,59 @@ def test_comm_entry_points_validate_and_fail_loudly_without_a_gpu():
         rc = lib.rq_comm_unique_id(buf, 128)
         assert rc in (0, -2, -3)
         assert (rc == 0 and any(buf.raw)) or (rc != 0 and len(lib.rq_last_error()) > 0)
+
+
+def test_split_f16_operand_image_reconstructs_the_weights():
+    """RQ_POLICY_F16X2_MFMA keeps every weight as two f16 numbers, hi = f16(w') and lo = f16((w' - hi) * 2048) with w'
+    the weight after the gate pre-scaling.  rq_policy_pack_image is host code: decode the image with numpy's float16
+    and check hi + lo / 2048 against the operands themselves, element by element (2^-21 relative), and that the f32 / bf16 images come out with their documented sizes."""
+    import ctypes as C
+    from raptor_amd import _lib
+    w = np.fromfile(os.path.join(ROOT, "raptor_amd", "data", "raptor_policy.bin"), dtype="<f4")
+    assert w.size == 2084
+
+    def image(precision):
+        need = C.c_size_t()
+        _lib.call("rq_policy_pack_image", w.ctypes.data, w.size, precision, None, 0, C.byref(need))
+        img = np.zeros(need.value, np.float32)
+        _lib.call("rq_policy_pack_image", w.ctypes.data, w.size, precision, img.ctypes.data, img.size, C.byref(need))
+        return img.reshape(-1, 64)
+
+    assert image(_lib.POLICY_FP32).shape[0] == 70 and image(_lib.POLICY_BF16_MFMA).shape[0] == 60
+    img = image(_lib.POLICY_F16X2_MFMA)
+    assert img.shape == (96, 64)
+    halves = img[:72].view(np.uint32)
+    def pieces(base):                         # 4 dwords x 64 lanes -> [lane, 8] float16 values
+        d = halves[base:base + 4]             # [4, 64]
+        lo16 = (d & 0xFFFF).astype(np.uint16).view(np.float16)
+        hi16 = (d >> 16).astype(np.uint16).view(np.float16)
+        return np.stack([lo16, hi16], axis=-1).transpose(1, 0, 2).reshape(64, 8)       # element e = 2 * dword + half
+    W0, B0, WI, WH = w[:352].reshape(16, 22), w[352:368], w[368:1136].reshape(48, 16), w[1136:1904].reshape(48, 16)
+    W2 = w[2016:2080].reshape(4, 16)
+    kS, kT = np.float32(-1.4426950408889634), np.float32(-2.8853900817779268)
+    hi, lo = pieces(0), pieces(4)             # layer_0
+    assert np.isfinite(hi.astype(np.float64)).all()
+    worst = 0.0
+    for lane in range(64):
+        q, i = lane >> 4, lane & 15
+        for e in range(8):
+            f = 4 * e + q
+            want = 0.0 if e >= 6 or f == 23 else (B0[i] if f == 22 else W0[i, f])
+            got = float(hi[lane, e]) + float(lo[lane, e]) / 2048.0
+            worst = max(worst, abs(got - float(want)) / max(abs(float(want)), 1e-30) if want != 0 else abs(got))
+    assert worst < 2.0 ** -21, worst
+    for base, rows, scale in ((8, 0, kS), (16, 16, kS)):                   # r and z gates: [W_i | W_h] rows, pre-scaled
+        hi, lo = pieces(base), pieces(base + 4)
+        for lane in range(64):
+            q, i = lane >> 4, lane & 15
+            for e in range(8):
+                want = float(np.float32(scale * (WI[rows + i, 4 * q + e] if e < 4 else WH[rows + i, 4 * q + e - 4])))
+                got = float(hi[lane, e]) + float(lo[lane, e]) / 2048.0
+                assert abs(got - want) <= 2.0 ** -21 * abs(want), (base, lane, e)
+    hi, lo = pieces(40 + 4 * 2), pieces(56 + 4 * 2)                      # layer_2, tile 2: rows 8..11, k-slots 4..7
+    for lane in range(64):
+        q, i = lane >> 4, lane & 15
+        for e in range(8):
+            want = float(W2[i & 3, 4 * q + e - 4]) if (e >= 4 and (i >> 2) == 2) else 0.0
+            got = float(hi[lane, e]) + float(lo[lane, e]) / 2048.0
+            assert abs(got - want) <= 2.0 ** -21 * abs(want) + 0.0, (lane, e)

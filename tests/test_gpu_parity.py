@@ -234,6 +234,58 @@ def test_bf16_fused_equals_chained(device, oracle):
     assert np.array_equal(a.policy.hidden_state(300), b.policy.hidden_state(300))
 
 
+def test_split_f16_actor_meets_the_fp32_bar(device, weights, kat, oracle):
+    """RQ_POLICY_F16X2_MFMA: every operand as two f16 pieces on the f16 MFMA.  It has to pass what the fp32 build
+    passes - both reference known-answer vectors to 1e-5 over 500 recurrent steps, random batches against the fp32
+    oracle - through every kernel that carries an actor (step, sequence, fused, chained, relabel)."""
+    from raptor_amd.foundation_policy import Raptor
+    x, y = kat
+    pol = Raptor(device, precision="f16x2")
+    err = pol.selftest(x, y, tolerance=ACTOR_TOL)
+    ref32 = Raptor(device).selftest(x, y, tolerance=ACTOR_TOL)
+    print(f"\n[split-f16 actor] known-answer max abs error {err:.2e} (exact-fp32 MFMA build: {ref32:.2e})")
+    assert err < ACTOR_TOL
+    # one launch over the whole [500, 2, 22] tensor
+    pol.reset()
+    seq = pol.evaluate_sequence(x)
+    assert np.abs(seq - y).max() < ACTOR_TOL
+    # random batch, ragged size, against the oracle's fp32 actor over 30 recurrent steps
+    rng = np.random.default_rng(3)
+    n = 1000
+    pol.reset()
+    H = np.zeros((n, 16), np.float32)
+    worst = 0.0
+    for _ in range(30):
+        obs = rng.normal(0, 1.5, (n, 22)).astype(np.float32)
+        a = pol.evaluate_step(obs)
+        worst = max(worst, float(np.abs(a - oracle.actor_batch_step(weights, obs, H)).max()))
+    assert worst < ACTOR_TOL, worst
+    # fused == chained bit for bit (one step function), with auto-reset and recording
+    a_ = World(device, oracle, 300, seed=8, episode_step_limit=40)
+    b_ = World(device, oracle, 300, seed=8, episode_step_limit=40)
+    a_.policy.set_precision("f16x2"); b_.policy.set_precision("f16x2")
+    ta, tb = a_.vector.Trajectory(a_.env, 100), b_.vector.Trajectory(b_.env, 100)
+    a_.vector.rollout(device, a_.env, a_.params, a_.state, a_.policy, a_.rng, 100, "fused", True, trajectory=ta)
+    b_.vector.rollout(device, b_.env, b_.params, b_.state, b_.policy, b_.rng, 100, "chained", True, trajectory=tb)
+    assert np.array_equal(a_.state.numpy(), b_.state.numpy())
+    assert np.array_equal(a_.policy.hidden_state(300), b_.policy.hidden_state(300))
+    ha, hb = ta.numpy(), tb.numpy()
+    assert all(np.array_equal(ha[k], hb[k]) for k in ("obs", "act", "rew", "done"))
+    # relabelling the recording with a policy of the same weights and precision reproduces its actions
+    teacher = Raptor(device, precision="f16x2")
+    teacher.reset()
+    assert np.array_equal(ta.relabel(teacher), ha["act"])
+    # closed loop: flying the split-f16 policy is indistinguishable from flying the fp32 one at this horizon
+    c = World(device, oracle, 4096, seed=31)
+    d = World(device, oracle, 4096, seed=31)
+    c.policy.set_precision("f16x2")
+    c.vector.rollout(device, c.env, c.params, c.state, c.policy, c.rng, 60, "fused", False)
+    d.vector.rollout(device, d.env, d.params, d.state, d.policy, d.rng, 60, "fused", False)
+    dev_ = np.abs(c.state.numpy()[:, :13] - d.state.numpy()[:, :13]).max(axis=1)
+    print(f"[split-f16 actor] 60-step closed loop vs fp32 actor: median |dstate| {np.median(dev_):.2e}, 99% {np.quantile(dev_, 0.99):.2e}")
+    assert np.median(dev_) < 1e-4
+
+
 # ------------------------------------------------------------------------------ sampling ---
 @pytest.mark.parametrize("dr", [0, 1])
 def test_sample_initial_parameters_bit_exact(device, oracle, dr):

@@ -9,6 +9,7 @@ DST=$R/gpurun_out/profiles_$TAG
 mkdir -p $DST
 python bench.py > $DST/${TAG}_bench_default.json 2> $DST/default.err; echo "default rc=$?"
 python bench.py --precision bf16 --no-cpu-baseline --no-kernel-probe > $DST/${TAG}_bench_bf16.json 2>/dev/null; echo "bf16 rc=$?"
+python bench.py --precision f16x2 --no-cpu-baseline --no-kernel-probe > $DST/${TAG}_bench_f16x2.json 2>/dev/null; echo "f16x2 rc=$?"
 python bench.py --envs-per-gpu 262144 --no-cpu-baseline --no-kernel-probe > $DST/${TAG}_bench_262144.json 2>/dev/null; echo "262144 rc=$?"
 python bench.py --envs-per-gpu 1048576 --no-cpu-baseline --no-kernel-probe > $DST/${TAG}_bench_1048576.json 2>/dev/null; echo "1048576 rc=$?"
 python bench.py --mode chained --steps 2000 --warmup 500 --no-cpu-baseline --no-kernel-probe > $DST/${TAG}_bench_chained.json 2>/dev/null; echo "chained rc=$?"
