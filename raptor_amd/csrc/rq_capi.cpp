@@ -143,6 +143,7 @@ struct rq_teacher_bank {
     int precision = RQ_POLICY_FP32;
     float* images_f32 = nullptr;     // [n_teachers][teacher_image_regs_f32 * 64]
     float* images_bf16 = nullptr;    // [n_teachers][teacher_image_regs_bf16 * 64]
+    float* images_f16x2 = nullptr;   // [n_teachers][teacher_image_regs_f16x2 * 64]
     uint32_t* tiles = nullptr;       // device: tile_teacher [cap] followed by tile_env [cap][16]
     uint32_t tile_capacity = 0;
 };
@@ -1409,10 +1410,12 @@ RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t
     const size_t per = rq::teacher_param_count((int)in_dim, (int)h1, (int)h2);
     const size_t f32_floats = (size_t)rq::teacher_image_regs_f32((int)h1, (int)h2) * 64;
     const size_t bf16_floats = (size_t)rq::teacher_image_regs_bf16((int)h1, (int)h2) * 64;
-    std::vector<float> img32, img16;
+    const size_t split_floats = (size_t)rq::teacher_image_regs_f16x2((int)h1, (int)h2) * 64;
+    std::vector<float> img32, img16, img_split;
     try {                                   // nothing throws across the boundary
         img32.resize(f32_floats * n_teachers);
         img16.resize(bf16_floats * n_teachers);
+        img_split.resize(split_floats * n_teachers);
     } catch (const std::bad_alloc&) {
         delete b;
         return fail(RQ_ERR_OUT_OF_MEMORY, "rq_teacher_bank_create: host allocation failed");
@@ -1420,12 +1423,15 @@ RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t
     for (uint32_t t = 0; t < n_teachers; ++t) {
         rq::pack_teacher_f32(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img32.data() + f32_floats * t);
         rq::pack_teacher_bf16(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img16.data() + bf16_floats * t);
+        rq::pack_teacher_f16x2(weights + per * t, (int)in_dim, (int)h1, (int)h2, b->act, b->out_act, img_split.data() + split_floats * t);
     }
     hipError_t e1 = hipMalloc(&b->images_f32, img32.size() * sizeof(float));
     hipError_t e2 = hipMalloc(&b->images_bf16, img16.size() * sizeof(float));
     if (e1 == hipSuccess) e1 = hipMemcpy(b->images_f32, img32.data(), img32.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e2 == hipSuccess) e2 = hipMemcpy(b->images_bf16, img16.data(), img16.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
+    hipError_t e3 = hipMalloc(&b->images_f16x2, img_split.size() * sizeof(float));
+    if (e3 == hipSuccess) e3 = hipMemcpy(b->images_f16x2, img_split.data(), img_split.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         rq_teacher_bank_destroy(b);
         return fail(RQ_ERR_OUT_OF_MEMORY, "rq_teacher_bank_create: device allocation or upload failed");
     }
@@ -1438,6 +1444,7 @@ RQ_API int rq_teacher_bank_destroy(rq_teacher_bank* bank) {
     DeviceScope on_device(bank->ordinal);
     if (bank->images_f32) (void)hipFree(bank->images_f32);
     if (bank->images_bf16) (void)hipFree(bank->images_bf16);
+    if (bank->images_f16x2) (void)hipFree(bank->images_f16x2);
     if (bank->tiles) (void)hipFree(bank->tiles);
     delete bank;
     return RQ_OK;
@@ -1445,7 +1452,8 @@ RQ_API int rq_teacher_bank_destroy(rq_teacher_bank* bank) {
 
 RQ_API int rq_teacher_bank_set_precision(rq_teacher_bank* bank, int precision) {
     RQ_REQUIRE(bank, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA, RQ_ERR_INVALID_ARGUMENT, "unknown precision");
+    RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA || precision == RQ_POLICY_F16X2_MFMA,
+               RQ_ERR_INVALID_ARGUMENT, "unknown precision");
     bank->precision = precision;
     return RQ_OK;
 }
@@ -1497,7 +1505,8 @@ RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* ban
         }
         d_act = dev->rows2;
     }
-    const float* images = bank->precision == RQ_POLICY_BF16_MFMA ? bank->images_bf16 : bank->images_f32;
+    const float* images = bank->precision == RQ_POLICY_BF16_MFMA ? bank->images_bf16
+                        : bank->precision == RQ_POLICY_F16X2_MFMA ? bank->images_f16x2 : bank->images_f32;
     RQ_HIP(rq::launch_teacher_relabel(dev->stream, n_tiles, env->ld, t->length, bank->in_dim, bank->h1, bank->h2, bank->act,
                                       bank->out_act, bank->precision, images, bank->tiles, bank->tiles + n_tiles, t->obs,
                                       d_act));

@@ -196,9 +196,14 @@ constexpr int teacher_image_regs_f32(int h1, int h2) { return (h1 / 16) * 6 + (h
 constexpr int teacher_image_regs_bf16(int h1, int h2) {
     return 4 * (h1 / 16) + 4 * (h2 / 16) * ((h1 + 31) / 32) + 4 * ((h2 + 31) / 32) + (h2 / 16) * 4 + 4;
 }
+// split-f16 (v_mfma_f32_16x16x32_f16): every A operand of the bf16 image twice, hi then lo (f16 of the residual x 2048)
+constexpr int teacher_image_regs_f16x2(int h1, int h2) {
+    return 2 * (4 * (h1 / 16) + 4 * (h2 / 16) * ((h1 + 31) / 32) + 4 * ((h2 + 31) / 32)) + (h2 / 16) * 4 + 4;
+}
 // one teacher's parameters, [W1 (h1 x in) | b1 | W2 (h2 x h1) | b2 | W3 (4 x h2) | b3], rows = outputs -> its image
 void pack_teacher_f32(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
 void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
+void pack_teacher_f16x2(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
 inline size_t teacher_param_count(int in_dim, int h1, int h2) {
     return (size_t)h1 * in_dim + h1 + (size_t)h2 * h1 + h2 + (size_t)4 * h2 + 4;
 }

@@ -214,21 +214,27 @@ void pack_teacher_f32(const float* w, int in_dim, int h1, int h2, int act, int o
     }
 }
 
-void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image) {
+// the 16-bit teacher images: bf16 (one operand per contraction chunk) or split f16 (hi operand, then lo operand)
+static void pack_teacher_16(const float* w, int in_dim, int h1, int h2, int act, int out_act, bool split, float* image) {
     const TeacherView t = view(w, in_dim, h1, h2, act, out_act);
-    const int regs = teacher_image_regs_bf16(h1, h2);
+    const int regs = split ? teacher_image_regs_f16x2(h1, h2) : teacher_image_regs_bf16(h1, h2);
     uint32_t* pu = reinterpret_cast<uint32_t*>(image);
     for (int i = 0; i < regs * 64; ++i) pu[i] = 0u;
     for (int l = 0; l < 64; ++l) {
         const int q = l >> 4, i = l & 15;
         int v = 0;
-        auto put8 = [&](const float (&x)[8]) {            // one bf16x8 A operand = 4 dwords, element e in half e & 1 of dword e / 2
+        auto put16 = [&](int base, int e, uint32_t h) {    // 16-bit element e of the 8-element operand at image `base`
+            uint32_t& d = pu[(base + e / 2) * 64 + l];
+            d = (e & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
+        };
+        auto put8 = [&](const float (&x)[8]) {            // one A operand = 4 dwords (split: hi operand, then lo operand)
             for (int e = 0; e < 8; ++e) {
-                uint32_t& d = pu[(v + e / 2) * 64 + l];
-                const uint32_t h = to_bf16_rne(x[e]);
-                d = (e & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
+                if (!split) { put16(v, e, to_bf16_rne(x[e])); continue; }
+                const uint16_t hi = to_f16_rne(x[e]);
+                put16(v, e, hi);
+                put16(v + 4, e, to_f16_rne((x[e] - from_f16(hi)) * 2048.0f));
             }
-            v += 4;
+            v += split ? 8 : 4;
         };
         for (int m = 0; m < h1 / 16; ++m) {
             float x[8];
@@ -252,6 +258,13 @@ void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int 
             for (int r = 0; r < 4; ++r) putf(t.k2 * t.b2[16 * m + 4 * q + r]);
         for (int r = 0; r < 4; ++r) putf(q == 0 ? t.k3 * t.b3[r] : 0.0f);
     }
+}
+
+void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image) {
+    pack_teacher_16(w, in_dim, h1, h2, act, out_act, false, image);
+}
+void pack_teacher_f16x2(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image) {
+    pack_teacher_16(w, in_dim, h1, h2, act, out_act, true, image);
 }
 
 }  // namespace rq

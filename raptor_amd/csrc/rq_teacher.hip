@@ -12,7 +12,8 @@
 // teacher's operands register-stationary (loaded once per wave, 124 VGPRs for 22-64-64-4, amortised over T
 // steps):
 //   f32 : v_mfma_f32_16x16x4_f32 - exact fp32 (one correctly rounded fma per product), 104 MFMAs per tile-step;
-//   bf16: v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32 accumulate, 14 MFMAs per tile-step.
+//   bf16: v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32 accumulate, 14 MFMAs per tile-step;
+//   f16x2: v_mfma_f32_16x16x32_f16 on operands split into two f16 pieces - fp32-grade labels, 42 MFMAs per tile-step.
 // Layouts (lane l = (q = l >> 4, j = l & 15), as in the student's actor, rq_device_math.hpp):
 //   * the observation is read straight into the B-operand layout - lane (q, j) loads feature 4s + q of env j
 //     of the tile for K-step s - so the trajectory's field-major rows need no transpose at all;
@@ -45,13 +46,35 @@ __device__ __forceinline__ float teacher_act(float x) {
 }
 
 // B operand of layer 1 for this lane: feature f = 4s + q of env `e` at step t; feature in_dim is the constant 1
-// that carries the bias, anything beyond is padding.  obs is the trajectory's [T][22][ld] block.
-__device__ __forceinline__ float load_input(const float* __restrict__ obs, size_t t, uint32_t ld, uint32_t e,
-                                            uint32_t f, uint32_t in_dim) {
-    const uint32_t fc = f < in_dim ? f : 0u;
-    const float v = obs[(t * RQ_POLICY_INPUT_DIM + fc) * ld + e];
-    return f < in_dim ? v : (f == in_dim ? 1.0f : 0.0f);
-}
+// that carries the bias, anything beyond is padding.  obs is the trajectory's [T][22][ld] block.  The lane's six
+// element offsets inside a step's block are fixed; the step's block base is wave-uniform (scalar registers), so a
+// load is one instruction with no per-step 64-bit address arithmetic on the VALU.
+struct InputPlan {
+    uint32_t off[6];       // (feature row) * ld + env, in elements (< 2^30: ld <= 2^24 rows of 22)
+    uint32_t f[6];
+    uint32_t in_dim, ld;
+    __device__ __forceinline__ InputPlan(uint32_t ld_, uint32_t e, uint32_t q, uint32_t in_dim_) : in_dim(in_dim_), ld(ld_) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            f[s] = 4 * s + q;
+            off[s] = (f[s] < in_dim ? f[s] : 0u) * ld + e;
+        }
+    }
+    // the bias constant and the padding replace what was loaded for features >= in_dim.  Kept apart from load(): the
+    // loads run one or two steps ahead and their values cross the loop's back edge raw - written as one expression
+    // the compiler sinks each load into its select and a step pays six exec-masked branches
+    __device__ __forceinline__ void finish(float (&x)[6]) const {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) x[s] = f[s] < in_dim ? x[s] : (f[s] == in_dim ? 1.0f : 0.0f);
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ obs, uint32_t t, float (&x)[6]) const {
+        const float* __restrict__ block = obs + (size_t)t * RQ_POLICY_INPUT_DIM * ld;      // wave-uniform
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            x[s] = block[off[s]];
+        }
+    }
+};
 
 template <int H1, int H2, int ACT, int OUT_ACT>
 __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f32(uint32_t ld, uint32_t steps, uint32_t in_dim,
@@ -92,23 +115,25 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f32(uint32_t ld, uint
     const bool valid = e0 != 0xFFFFFFFFu;
     const uint32_t e = valid ? e0 : 0u;                 // padding lanes shadow env 0: MFMA ignores EXEC
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const InputPlan in(ld, e, q, in_dim);
     float X[6], X1[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) X[s] = load_input(obs, t_begin, ld, e, 4 * s + q, in_dim);
-#pragma unroll
-    for (int s = 0; s < 6; ++s) X1[s] = load_input(obs, t_begin + 1 < t_end ? t_begin + 1 : t_begin, ld, e, 4 * s + q, in_dim);
+    in.load(obs, t_begin, X);
+    in.load(obs, t_begin + 1 < t_end ? t_begin + 1 : t_begin, X1);
     for (uint32_t t = t_begin; t < t_end; ++t) {
         float Xn[6];
         const uint32_t tn = t + 2 < t_end ? t + 2 : t;   // operands two steps ahead in flight behind the MFMAs (one
-#pragma unroll                                            // step is ~1.6 us, about the latency of an HBM miss)
-        for (int s = 0; s < 6; ++s) Xn[s] = load_input(obs, tn, ld, e, 4 * s + q, in_dim);
+        in.load(obs, tn, Xn);                            // step is ~1.6 us, about the latency of an HBM miss)
+        float Xc[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) Xc[s] = X[s];
+        in.finish(Xc);
         f32x4 y1[M1], y2[M2];
 #pragma unroll
-        for (int m = 0; m < M1; ++m) y1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[m][0], X[0], zero, 0, 0, 0);
+        for (int m = 0; m < M1; ++m) y1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[m][0], Xc[0], zero, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 6; ++s)
 #pragma unroll
-            for (int m = 0; m < M1; ++m) y1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[m][s], X[s], y1[m], 0, 0, 0);
+            for (int m = 0; m < M1; ++m) y1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[m][s], Xc[s], y1[m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < M1; ++m)
 #pragma unroll
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f32(uint32_t ld, uint
         for (int k = 1; k < K3; ++k) o = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[k], y2[k / 4][k % 4], o, 0, 0, 0);
         if (valid && q == 0) {                            // rows 0..3 of the 16-row output tile are the 4 actions
 #pragma unroll
-            for (int r = 0; r < 4; ++r) act[((size_t)t * RQ_ACTION_DIM + r) * ld + e0] = teacher_act<OUT_ACT>(o[r]);
+            for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[r]);
         }
 #pragma unroll
         for (int s = 0; s < 6; ++s) { X[s] = X1[s]; X1[s] = Xn[s]; }
@@ -184,15 +209,15 @@ __global__ __launch_bounds__(64, 4) void k_teacher_relabel_bf16(uint32_t ld, uin
     const bool valid = e0 != 0xFFFFFFFFu;
     const uint32_t e = valid ? e0 : 0u;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const InputPlan in(ld, e, q, in_dim);
     float X[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) X[s] = load_input(obs, t_begin, ld, e, 4 * s + q, in_dim);
+    in.load(obs, t_begin, X);
     for (uint32_t t = t_begin; t < t_end; ++t) {
         float Xn[6];
         const uint32_t tn = t + 1 < t_end ? t + 1 : t;   // one step ahead (two, as in the f32 kernel, measured slower here)
-#pragma unroll
-        for (int s = 0; s < 6; ++s) Xn[s] = load_input(obs, tn, ld, e, 4 * s + q, in_dim);
+        in.load(obs, tn, Xn);
         // k-slot e of lane-group q carries feature 4e + q (e < 6), as in the student's bf16 layer_0
+        in.finish(X);
         const bf16x8 xb = pack8(X[0], X[1], X[2], X[3], X[4], X[5], 0.f, 0.f);
         f32x4 y1[M1 + 1], y2[M2 + 1];                     // one spare tile of zeros pads an odd chunk
 #pragma unroll
@@ -226,7 +251,149 @@ __global__ __launch_bounds__(64, 4) void k_teacher_relabel_bf16(uint32_t ld, uin
         }
         if (valid && q == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) act[((size_t)t * RQ_ACTION_DIM + r) * ld + e0] = teacher_act<OUT_ACT>(o[r]);
+            for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[r]);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) X[s] = Xn[s];
+    }
+}
+
+// ---- split f16: fp32-grade labels on the matrix pipe that overlaps with the VALU (rq_device_math.hpp, ActorF16X2) ----
+// every operand = hi + lo / 2048 in f16; a contraction = hi.hi into H, hi.lo + lo.hi into L, result H + L / 2048
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {v0, v1};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 k = {2048.0f, 2048.0f};
+    const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * k;
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ f16x8 tuple16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+    const dwordx4 u = {d0, d1, d2, d3};
+    return __builtin_bit_cast(f16x8, u);
+}
+__device__ __forceinline__ f32x4 join16(const f32x4& hi, const f32x4& lo) {
+    const float k = 1.0f / 2048.0f;
+    return f32x4{fmaf(lo[0], k, hi[0]), fmaf(lo[1], k, hi[1]), fmaf(lo[2], k, hi[2]), fmaf(lo[3], k, hi[3])};
+}
+__device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int H1, int H2, int ACT, int OUT_ACT>
+__global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                                                 const float* __restrict__ images,
+                                                                 const uint32_t* __restrict__ tile_teacher,
+                                                                 const uint32_t* __restrict__ tile_env,
+                                                                 const float* __restrict__ obs, float* __restrict__ act) {
+    constexpr int M1 = H1 / 16, M2 = H2 / 16, C2 = (H1 + 31) / 32, C3 = (H2 + 31) / 32;
+    constexpr int REGS = teacher_image_regs_f16x2(H1, H2);
+    const uint32_t lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t per = (steps + gridDim.y - 1) / gridDim.y;
+    const uint32_t t_begin = blockIdx.y * per, t_end = t_begin + per < steps ? t_begin + per : steps;
+    if (t_begin >= t_end) return;                       // wave-uniform
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(images) + (size_t)tile_teacher[tile] * REGS * 64 + lane;
+    f16x8 A1h[M1], A1l[M1], A2h[M2][C2], A2l[M2][C2], A3h[C3], A3l[C3];
+    f32x4 B2[M2], B3;
+    int v = 0;
+    auto load_a = [&]() {
+        const f16x8 a = tuple16(img[(v + 0) * 64], img[(v + 1) * 64], img[(v + 2) * 64], img[(v + 3) * 64]);
+        v += 4;
+        return a;
+    };
+#pragma unroll
+    for (int m = 0; m < M1; ++m) { A1h[m] = load_a(); A1l[m] = load_a(); }
+#pragma unroll
+    for (int m = 0; m < M2; ++m)
+#pragma unroll
+        for (int c = 0; c < C2; ++c) { A2h[m][c] = load_a(); A2l[m][c] = load_a(); }
+#pragma unroll
+    for (int c = 0; c < C3; ++c) { A3h[c] = load_a(); A3l[c] = load_a(); }
+#pragma unroll
+    for (int m = 0; m < M2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B2[m][r] = __builtin_bit_cast(float, img[(v++) * 64]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) B3[r] = __builtin_bit_cast(float, img[(v++) * 64]);
+
+    const uint32_t e0 = tile_env[tile * 16 + j];
+    const bool valid = e0 != 0xFFFFFFFFu;
+    const uint32_t e = valid ? e0 : 0u;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const InputPlan in(ld, e, q, in_dim);
+    float X[6];
+    in.load(obs, t_begin, X);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        float Xn[6];
+        const uint32_t tn = t + 1 < t_end ? t + 1 : t;
+        in.load(obs, tn, Xn);
+        // k-slot e of lane-group q carries feature 4e + q (e < 6)
+        in.finish(X);
+        uint32_t xh[3], xl[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) split2(X[2 * d], X[2 * d + 1], xh[d], xl[d]);
+        const f16x8 bh = tuple16(xh[0], xh[1], xh[2], 0u), bl = tuple16(xl[0], xl[1], xl[2], 0u);
+        f32x4 H1a[M1], L1a[M1];
+#pragma unroll
+        for (int m = 0; m < M1; ++m) {
+            H1a[m] = mfma16h(A1h[m], bh, zero);
+            L1a[m] = mfma16h(A1h[m], bl, zero);
+            L1a[m] = mfma16h(A1l[m], bh, L1a[m]);
+        }
+        // activations of layer 1 -> pieces; unit 16 m + 4 q + r sits in register r of row tile m: chunk c of the next
+        // contraction takes row tiles 2c (k-slots 0..3) and 2c + 1 (k-slots 4..7)
+        uint32_t y1h[M1 + 1][2], y1l[M1 + 1][2];
+#pragma unroll
+        for (int m = 0; m < M1; ++m) {
+            const f32x4 y = join16(H1a[m], L1a[m]);
+            split2(teacher_act<ACT>(y[0]), teacher_act<ACT>(y[1]), y1h[m][0], y1l[m][0]);
+            split2(teacher_act<ACT>(y[2]), teacher_act<ACT>(y[3]), y1h[m][1], y1l[m][1]);
+        }
+        y1h[M1][0] = y1h[M1][1] = y1l[M1][0] = y1l[M1][1] = 0u;          // the zero tile that pads an odd chunk
+        f32x4 H2a[M2], L2a[M2];
+#pragma unroll
+        for (int m = 0; m < M2; ++m) { H2a[m] = B2[m]; L2a[m] = zero; }
+#pragma unroll
+        for (int c = 0; c < C2; ++c) {
+            constexpr int kPad = M1;
+            const int m0 = 2 * c, m1 = 2 * c + 1 < M1 ? 2 * c + 1 : kPad;
+            const f16x8 hb = tuple16(y1h[m0][0], y1h[m0][1], y1h[m1][0], y1h[m1][1]);
+            const f16x8 lb = tuple16(y1l[m0][0], y1l[m0][1], y1l[m1][0], y1l[m1][1]);
+#pragma unroll
+            for (int m = 0; m < M2; ++m) {
+                H2a[m] = mfma16h(A2h[m][c], hb, H2a[m]);
+                L2a[m] = mfma16h(A2h[m][c], lb, L2a[m]);
+                L2a[m] = mfma16h(A2l[m][c], hb, L2a[m]);
+            }
+        }
+        uint32_t y2h[M2 + 1][2], y2l[M2 + 1][2];
+#pragma unroll
+        for (int m = 0; m < M2; ++m) {
+            const f32x4 y = join16(H2a[m], L2a[m]);
+            split2(teacher_act<ACT>(y[0]), teacher_act<ACT>(y[1]), y2h[m][0], y2l[m][0]);
+            split2(teacher_act<ACT>(y[2]), teacher_act<ACT>(y[3]), y2h[m][1], y2l[m][1]);
+        }
+        y2h[M2][0] = y2h[M2][1] = y2l[M2][0] = y2l[M2][1] = 0u;
+        f32x4 Ho = B3, Lo = zero;
+#pragma unroll
+        for (int c = 0; c < C3; ++c) {
+            constexpr int kPad = M2;
+            const int m0 = 2 * c, m1 = 2 * c + 1 < M2 ? 2 * c + 1 : kPad;
+            const f16x8 hb = tuple16(y2h[m0][0], y2h[m0][1], y2h[m1][0], y2h[m1][1]);
+            const f16x8 lb = tuple16(y2l[m0][0], y2l[m0][1], y2l[m1][0], y2l[m1][1]);
+            Ho = mfma16h(A3h[c], hb, Ho);
+            Lo = mfma16h(A3h[c], lb, Lo);
+            Lo = mfma16h(A3l[c], hb, Lo);
+        }
+        if (valid && q == 0) {
+            const f32x4 o = join16(Ho, Lo);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[r]);
         }
 #pragma unroll
         for (int s = 0; s < 6; ++s) X[s] = Xn[s];
@@ -252,8 +419,9 @@ static hipError_t launch_hh(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32
         if (act == RQ_ACT_RELU) { if (out_act == RQ_ACT_TANH) RQ_T(KERNEL, RQ_ACT_RELU, RQ_ACT_TANH); else RQ_T(KERNEL, RQ_ACT_RELU, RQ_ACT_IDENTITY); } \
         else                    { if (out_act == RQ_ACT_TANH) RQ_T(KERNEL, RQ_ACT_TANH, RQ_ACT_TANH); else RQ_T(KERNEL, RQ_ACT_TANH, RQ_ACT_IDENTITY); } \
     } while (0)
-    if (precision == RQ_POLICY_BF16_MFMA) RQ_T_ACT(k_teacher_relabel_bf16);
-    else                                  RQ_T_ACT(k_teacher_relabel_f32);
+    if (precision == RQ_POLICY_F16X2_MFMA)     RQ_T_ACT(k_teacher_relabel_f16x2);
+    else if (precision == RQ_POLICY_BF16_MFMA) RQ_T_ACT(k_teacher_relabel_bf16);
+    else                                       RQ_T_ACT(k_teacher_relabel_f32);
 #undef RQ_T_ACT
 #undef RQ_T
     return hipGetLastError();

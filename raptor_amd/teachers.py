@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 
 ACTIVATIONS = {"identity": _lib.ACT_IDENTITY, "relu": _lib.ACT_RELU, "tanh": _lib.ACT_TANH}
-PRECISIONS = {"fp32": _lib.POLICY_FP32, "bf16": _lib.POLICY_BF16_MFMA}
+PRECISIONS = {"fp32": _lib.POLICY_FP32, "bf16": _lib.POLICY_BF16_MFMA, "f16x2": _lib.POLICY_F16X2_MFMA}
 
 
 def parameter_count(in_dim, h1, h2):

@@ -1432,6 +1432,9 @@ def test_teacher_bank_relabel_vs_oracle(device, oracle, h1, h2, act, out_act, in
     bank.set_precision("bf16")
     got16 = tr.relabel_teachers(bank, ids)
     assert np.abs(got16 - ref).max() < 5e-2, np.abs(got16 - ref).max()
+    bank.set_precision("f16x2")                                     # two f16 pieces per operand: the fp32 bar
+    got_split = tr.relabel_teachers(bank, ids)
+    assert np.abs(got_split - ref).max() < 1e-5, np.abs(got_split - ref).max()
     bank.set_precision("fp32")
     tr.relabel_teachers(bank, ids, overwrite=True, fetch=False)
     assert np.array_equal(tr.numpy()["act"], got)                 # overwrite=True: the stored actions are the labels
@@ -1457,6 +1460,10 @@ def test_teacher_bank_at_full_batch(device, oracle):
     assert np.abs(got - ref).max() < 1e-5, np.abs(got - ref).max()
     bank.set_precision("bf16")
     assert np.abs(tr.relabel_teachers(bank, ids) - ref).max() < 5e-2
+    bank.set_precision("f16x2")
+    err = np.abs(tr.relabel_teachers(bank, ids) - ref).max()
+    print(f"\n[teacher bank, 65 536 envs x 64 teachers] max |label - oracle|: f32 MFMA {np.abs(got - ref).max():.2e}, split f16 {err:.2e}")
+    assert err < 1e-5, err
 
 
 def test_teacher_bank_edge_cases(device, oracle):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the teacher-bank relabel (rq_trajectory_relabel_teachers): n_envs x T recorded steps labelled by
-n_teachers MLP teachers (22-64-64-4) in one launch, f32 and bf16 MFMA paths.
+n_teachers MLP teachers (22-64-64-4) in one launch: exact-f32, bf16 and split-f16 MFMA paths.
 
     python tools/teacher_rate.py [--envs 65536] [--steps 500] [--teachers 1000]
 """
@@ -35,7 +35,7 @@ ids = (np.arange(args.envs) * args.teachers // args.envs).astype(np.uint32)     
 flop = 2 * (22 * H + H * H + H * 4) * args.envs * args.steps
 out = {"envs": args.envs, "steps": args.steps, "teachers": args.teachers, "topology": f"22-{H}-{H}-4",
        "flop_per_label": 2 * (22 * H + H * H + H * 4)}
-for prec, peak in (("fp32", 157.3), ("bf16", 2500.0)):
+for prec, peak in (("fp32", 157.3), ("bf16", 2500.0), ("f16x2", 2500.0)):    # f16x2: useful FLOP; 3x as many are issued
     bank = TeacherBank(device, W, 22, H, H, "relu", "identity", precision=prec)
     tr.relabel_teachers(bank, ids, fetch=False)
     device.synchronize()
