@@ -230,7 +230,22 @@ def extension_probe(device, n):
     rate = n * steps / (best * 1e-3)
     out["rollout_recorded"] = {"env_steps_per_s": round(rate, 1), "us_per_step": round(best * 1e3 / steps, 3),
                                "trajectory_bytes_per_env_step": 109, "trajectory_GBps": round(rate * 109 / 1e9, 1)}
-    del traj, sh
+    del traj
+    # the other actor precisions on the same workload (the headline above stays the exact-fp32 build): launches of
+    # 500 steps, kernel + launch time from stream events
+    for prec, key in (("bf16", "rollout_bf16_actor"), ("f16x2", "rollout_split_f16_actor")):
+        sh.policy.set_precision(prec)
+        for _ in range(3):
+            sh.rollout(500, "fused")
+        best = 1e9
+        for _ in range(5):
+            device.timer_start()
+            sh.rollout(500, "fused")
+            best = min(best, device.timer_stop())
+        out[key] = {"env_steps_per_s": round(n * 500 / (best * 1e-3), 1), "us_per_step": round(best * 1e3 / 500, 3)}
+    out["rollout_split_f16_actor"]["note"] = ("operands as two f16 pieces each on v_mfma_f32_16x16x32_f16 (22 significand "
+                                             "bits, known-answer error 1.1e-6): not fp32 arithmetic, not the headline")
+    del sh
     pol = Raptor(device)
     pol.reset()
     x = torch.randn(steps, n, 22, device="cuda:%d" % torch.cuda.current_device())
