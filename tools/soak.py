@@ -20,7 +20,7 @@ cfg.disturbance_force_std, cfg.disturbance_torque_std = 0.05, 0.01
 env.config = cfg
 vector.sample_initial_parameters(device, env, params, rng)
 vector.sample_initial_state(device, env, params, state, rng)
-for prec in ("fp32", "bf16"):
+for prec in ("fp32", "bf16", "f16x2"):
     pol = Raptor(device, precision=prec); pol.reset()
     t0 = time.perf_counter()
     for k in range(100):
