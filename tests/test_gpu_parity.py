@@ -620,6 +620,25 @@ def test_device_resident_chain_equals_host_chain(device, oracle):
     assert np.array_equal(a.env.returns(), b.env.returns())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
+@pytest.mark.parametrize("n", [1, 65, 4097, 70001])
+def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle, n, precision):
+    """One env, one lane past a wave, one past a 4 096-env block, and a batch past 65 536 (where the fused kernel
+    switches to its two-waves-per-SIMD build): the fused kernel and the chain of API-granular kernels share one
+    actor step function and one env step function per precision, so they agree bit for bit - tail lanes, the LDS
+    tile of a partly filled wave and the mailbox path of the small batches included."""
+    kw = dict(seed=5, episode_step_limit=9)
+    a, b = World(device, oracle, n, **kw), World(device, oracle, n, **kw)
+    a.policy.set_precision(precision); b.policy.set_precision(precision)
+    for chunk in (7, 12):
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", True)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", True)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
+    assert np.array_equal(a.env.returns(), b.env.returns()) and np.array_equal(a.env.finished_counts(), b.env.finished_counts())
+    assert a.env.finished_counts().min() >= 1                      # episodes ended and restarted on the way
+
+
 @pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_fused_equals_chained_bit_exact(device, oracle, autoreset):
     kw = dict(seed=8, episode_step_limit=40, noise_position=0.01, noise_angular_velocity=0.05)
