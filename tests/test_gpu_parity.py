@@ -1707,3 +1707,68 @@ def test_env_spec_fixture_on_the_gpu(device):
         assert np.array_equal(env.rewards(), g["reward"][k]) and np.array_equal(env.terminated(), g["terminated"][k]), k
         prev = g["state"][k]
     assert worst < 1e-5, worst
+
+
+def test_pybind11_binding_runs_the_readme_loop(tmp_path, weights):
+    """INTEGRATION.md section 3 made concrete: examples/pybind_l2f.cpp - the pybind11 module a maintainer of l2f's C++
+    Python module would write over the C ABI - is built here and runs the reference's loop (README.md:94-99) on the
+    GPU; every array it returns equals what the ctypes binding of this repository returns for the same seed."""
+    import importlib.util
+    import subprocess
+    import sys
+    import sysconfig
+    import pybind11
+    from conftest import ROOT
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+    pkg = os.path.join(ROOT, "raptor_amd")
+    so = str(tmp_path / ("l2f_mi355x" + sysconfig.get_config_var("EXT_SUFFIX")))
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + pybind11.get_include(),
+                    "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "pybind_l2f.cpp"), "-L" + pkg, "-lraptor_quad",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", so], check=True)
+    spec = importlib.util.spec_from_file_location("l2f_mi355x", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, steps, seed = 8, 25, 11
+    # --- through the pybind11 module, written as the reference's example is
+    device = mod.Device()
+    rng, env = mod.VectorRng(), mod.VectorEnvironment(n)
+    params, state, next_state = mod.VectorParameters(), mod.VectorState(), mod.VectorState()
+    mod.initialize_rng(device, rng, seed)
+    mod.initialize_environment(device, env)
+    mod.sample_initial_parameters(device, env, params, rng)
+    mod.sample_initial_state(device, env, params, state, rng)
+    policy = mod.Raptor(device, weights)
+    policy.reset()
+    observation = np.zeros((env.N_ENVIRONMENTS, mod.OBSERVATION_DIM), dtype=np.float32)
+    got = []
+    for _ in range(steps):
+        mod.observe(device, env, params, state, observation, rng)
+        action = policy.evaluate_step(observation[:, :22])
+        dts = mod.step(device, env, params, state, action, next_state, rng)
+        state.assign(next_state)
+        got.append((observation.copy(), action.copy()))
+    assert len(dts) == n and abs(dts[-1] - 0.01) < 1e-9
+    final = mod.state_array(state, env)
+    with pytest.raises(ValueError):
+        mod.step(device, env, params, state, np.zeros((n, 3), np.float32), next_state, rng)
+    # --- the same through this repository's ctypes binding
+    d2 = l2f.Device()
+    v = l2f.vector(n)
+    rng2, env2, p2, s2, ns2 = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState(), v.VectorState()
+    v.initialize_rng(d2, rng2, seed)
+    v.initialize_environment(d2, env2)
+    v.sample_initial_parameters(d2, env2, p2, rng2)
+    v.sample_initial_state(d2, env2, p2, s2, rng2)
+    pol2 = Raptor(d2)
+    pol2.reset()
+    obs2 = np.zeros((n, 26), np.float32)
+    for k in range(steps):
+        v.observe(d2, env2, p2, s2, obs2, rng2)
+        a2 = pol2.evaluate_step(obs2[:, :22])
+        v.step(d2, env2, p2, s2, a2, ns2, rng2)
+        s2.assign(ns2)
+        assert np.array_equal(obs2, got[k][0]) and np.array_equal(a2, got[k][1]), k
+    assert np.array_equal(s2.numpy(), final)
+    assert np.abs(final[:, :3]).max() < 1.0                       # and the policy holds the eight quadrotors
