@@ -386,3 +386,21 @@ def test_env_spec_fixture():
         assert np.array_equal(want[k], got[k], equal_nan=True), k
     # sanity of the recorded loop itself: the policy holds every one of the 16 randomised bodies
     assert want["terminated"].sum() == 0 and np.abs(want["state"][-1][:, :3]).max() < 1.0
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """The restatement the HIP kernels are checked against, built with AddressSanitizer + UndefinedBehaviourSanitizer
+    and driven through every entry point with exactly sized heap buffers and odd batch sizes (oracle/sanitize_driver.c):
+    no out-of-bounds access, no leak, no undefined behaviour (the CPU restatement under
+    sanitizers)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "orc_san")
+    subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-ffp-contract=off", "-march=x86-64-v3", "-fopenmp", "-Wall", "-Wextra", "-Wno-unused-parameter", "-o", exe,
+                    os.path.join(root, "oracle", "sanitize_driver.c"), os.path.join(root, "oracle", "raptor_oracle.c"), "-lm"],
+                   check=True)
+    r = subprocess.run([exe, os.path.join(root, "raptor_amd", "data", "raptor_policy.bin")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "checksum" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
