@@ -188,3 +188,19 @@ def test_oracle_teacher_mlp_matches_numpy(oracle):
             x = obs[:, i, :in_dim].astype(np.float64)
             ref = g(f(f(x @ W1.T + b1) @ W2.T + b2) @ W3.T + b3)
             assert np.abs(got[:, i] - ref).max() < 2e-5
+
+
+def test_operand_packers_under_sanitizers(tmp_path):
+    """The host code that builds every operand image the kernels keep in registers (raptor_amd/csrc/rq_pack.cpp: the
+    f32, bf16 and split-f16 policy images, the log-std head, the three teacher images for all nine hidden-width pairs
+    and two input widths) under AddressSanitizer + UBSan with exactly sized buffers."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = str(tmp_path / "pack_san")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe, os.path.join(here, "pack_sanitize_driver.cpp"),
+                    os.path.join(root, "raptor_amd", "csrc", "rq_pack.cpp")], check=True, capture_output=True)
+    r = subprocess.run([exe, os.path.join(root, "raptor_amd", "data", "raptor_policy.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
