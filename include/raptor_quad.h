@@ -281,7 +281,8 @@ typedef enum rq_policy_precision {
     RQ_POLICY_F16X2_MFMA = 2  /* every operand as two f16 pieces (hi + lo / 2048, 22 significand bits) on
                                  v_mfma_f32_16x16x32_f16, exact products, fp32 accumulate and gates: known-answer error
                                  ~1e-6 like fp32, on the matrix pipe that overlaps with the vector ALU.  Not fp32
-                                 arithmetic: RQ_POLICY_FP32 stays the default and the benchmarked configuration */
+                                 arithmetic: RQ_POLICY_FP32 stays the default and the benchmarked configuration.
+                                 Range: an input or activation beyond the f16 range (|x| >= 65520) becomes infinite */
 } rq_policy_precision;
 
 /* weights: RQ_POLICY_NUM_WEIGHTS float32 in the order documented at RQ_POLICY_NUM_WEIGHTS
