@@ -244,7 +244,7 @@ def extension_probe(device, n):
             best = min(best, device.timer_stop())
         out[key] = {"env_steps_per_s": round(n * 500 / (best * 1e-3), 1), "us_per_step": round(best * 1e3 / 500, 3)}
     out["rollout_split_f16_actor"]["note"] = ("operands as two f16 pieces each on v_mfma_f32_16x16x32_f16 (22 significand "
-                                             "bits, known-answer error 1.1e-6): not fp32 arithmetic, not the headline")
+                                             "bits, known-answer error 1.2e-6): not fp32 arithmetic, not the headline")
     del sh
     pol = Raptor(device)
     pol.reset()

@@ -278,7 +278,7 @@ RQ_API int rq_env_reset_statistics(rq_env* env);
 typedef enum rq_policy_precision {
     RQ_POLICY_FP32 = 0,       /* exact fp32 on v_mfma_f32_16x16x4_f32 (one rounded fma per product), operands register-stationary */
     RQ_POLICY_BF16_MFMA = 1,  /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate and gates */
-    RQ_POLICY_F16X2_MFMA = 2  /* every operand as two f16 pieces (hi + lo / 2048, 22 significand bits) on
+    RQ_POLICY_F16X2_MFMA = 2  /* every operand as two f16 pieces (hi + lo, 22 significand bits or 2^-25 absolute) on
                                  v_mfma_f32_16x16x32_f16, exact products, fp32 accumulate and gates: known-answer error
                                  ~1e-6 like fp32, on the matrix pipe that overlaps with the vector ALU.  Not fp32
                                  arithmetic: RQ_POLICY_FP32 stays the default and the benchmarked configuration.

@@ -169,7 +169,7 @@ enum {
 };
 
 // split-f16 actor (v_mfma_f32_16x16x32_f16, rq_device_math.hpp ActorF16X2): every A operand of the bf16 image twice,
-// the f16 of the (pre-scaled) weight and the f16 of its residual x 2048; biases fp32 as in the f32 image
+// the f16 of the (gate-pre-scaled) weight and the f16 of its exact residual; biases fp32 as in the f32 image
 enum {
     FW_L0H = 0, FW_L0L = 4, FW_RH = 8, FW_RL = 12, FW_ZH = 16, FW_ZL = 20, FW_NIH = 24, FW_NIL = 28, FW_NHH = 32,
     FW_NHL = 36, FW_L2H = 40, FW_L2L = 56,                                  // f16x8 A operands, 4 dwords each (layer_2: x 4 tiles)
@@ -196,7 +196,7 @@ constexpr int teacher_image_regs_f32(int h1, int h2) { return (h1 / 16) * 6 + (h
 constexpr int teacher_image_regs_bf16(int h1, int h2) {
     return 4 * (h1 / 16) + 4 * (h2 / 16) * ((h1 + 31) / 32) + 4 * ((h2 + 31) / 32) + (h2 / 16) * 4 + 4;
 }
-// split-f16 (v_mfma_f32_16x16x32_f16): every A operand of the bf16 image twice, hi then lo (f16 of the residual x 2048)
+// split-f16 (v_mfma_f32_16x16x32_f16): every A operand of the bf16 image twice, hi then lo (f16 of the residual)
 constexpr int teacher_image_regs_f16x2(int h1, int h2) {
     return 2 * (4 * (h1 / 16) + 4 * (h2 / 16) * ((h1 + 31) / 32) + 4 * ((h2 + 31) / 32)) + (h2 / 16) * 4 + 4;
 }

@@ -119,7 +119,7 @@ static float from_f16(uint16_t h) {
     return (h & 0x8000u) ? -v : v;
 }
 
-// Layout: the bf16 image's A operands twice (enum FW_*): `base` holds f16(v), `base_lo` f16((v - f16(v)) * 2048).
+// Layout: the bf16 image's A operands twice (enum FW_*): `base` holds f16(v), `base_lo` f16(v - f16(v)) (the exact residual).
 void pack_policy_f16x2(const float* w, float* packed) {
     enum { W0 = 0, B0 = 352, WI = 368, WH = 1136, BI = 1904, BH = 1952, H0 = 2000, W2 = 2016, B2 = 2080 };
     for (int i = 0; i < RQ_PACKED_F16X2_FLOATS; ++i) packed[i] = 0.0f;
@@ -134,7 +134,7 @@ void pack_policy_f16x2(const float* w, float* packed) {
         auto put = [&](int base, int base_lo, int e, float v) {
             const uint16_t hi = to_f16_rne(v);
             put16(base, e, hi);
-            put16(base_lo, e, to_f16_rne((v - from_f16(hi)) * 2048.0f));
+            put16(base_lo, e, to_f16_rne(v - from_f16(hi)));
         };
         for (int e = 0; e < 8; ++e) {
             const int f = 4 * e + q;
@@ -232,7 +232,7 @@ static void pack_teacher_16(const float* w, int in_dim, int h1, int h2, int act,
                 if (!split) { put16(v, e, to_bf16_rne(x[e])); continue; }
                 const uint16_t hi = to_f16_rne(x[e]);
                 put16(v, e, hi);
-                put16(v + 4, e, to_f16_rne((x[e] - from_f16(hi)) * 2048.0f));
+                put16(v + 4, e, to_f16_rne(x[e] - from_f16(hi)));
             }
             v += split ? 8 : 4;
         };

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(64, 4) void k_teacher_relabel_bf16(uint32_t ld, uin
 }
 
 // ---- split f16: fp32-grade labels on the matrix pipe that overlaps with the VALU (rq_device_math.hpp, ActorF16X2) ----
-// every operand = hi + lo / 2048 in f16; a contraction = hi.hi into H, hi.lo + lo.hi into L, result H + L / 2048
+// every operand = hi + lo in f16 (lo = f16 of the exact residual); a contraction = hi.hi + hi.lo + lo.hi, three MFMAs
+// chained through one accumulator
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -267,18 +268,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
     const f32x2 v = {v0, v1};
     const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 k = {2048.0f, 2048.0f};
-    const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * k;
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 __device__ __forceinline__ f16x8 tuple16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
     const dwordx4 u = {d0, d1, d2, d3};
     return __builtin_bit_cast(f16x8, u);
-}
-__device__ __forceinline__ f32x4 join16(const f32x4& hi, const f32x4& lo) {
-    const float k = 1.0f / 2048.0f;
-    return f32x4{fmaf(lo[0], k, hi[0]), fmaf(lo[1], k, hi[1]), fmaf(lo[2], k, hi[2]), fmaf(lo[3], k, hi[3])};
 }
 __device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -338,26 +334,26 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, ui
 #pragma unroll
         for (int d = 0; d < 3; ++d) split2(X[2 * d], X[2 * d + 1], xh[d], xl[d]);
         const f16x8 bh = tuple16(xh[0], xh[1], xh[2], 0u), bl = tuple16(xl[0], xl[1], xl[2], 0u);
-        f32x4 H1a[M1], L1a[M1];
+        f32x4 H1a[M1];
 #pragma unroll
-        for (int m = 0; m < M1; ++m) {
-            H1a[m] = mfma16h(A1h[m], bh, zero);
-            L1a[m] = mfma16h(A1h[m], bl, zero);
-            L1a[m] = mfma16h(A1l[m], bh, L1a[m]);
-        }
+        for (int m = 0; m < M1; ++m) H1a[m] = mfma16h(A1h[m], bh, zero);
+#pragma unroll
+        for (int m = 0; m < M1; ++m) H1a[m] = mfma16h(A1h[m], bl, H1a[m]);
+#pragma unroll
+        for (int m = 0; m < M1; ++m) H1a[m] = mfma16h(A1l[m], bh, H1a[m]);
         // activations of layer 1 -> pieces; unit 16 m + 4 q + r sits in register r of row tile m: chunk c of the next
         // contraction takes row tiles 2c (k-slots 0..3) and 2c + 1 (k-slots 4..7)
         uint32_t y1h[M1 + 1][2], y1l[M1 + 1][2];
 #pragma unroll
         for (int m = 0; m < M1; ++m) {
-            const f32x4 y = join16(H1a[m], L1a[m]);
+            const f32x4 y = H1a[m];
             split2(teacher_act<ACT>(y[0]), teacher_act<ACT>(y[1]), y1h[m][0], y1l[m][0]);
             split2(teacher_act<ACT>(y[2]), teacher_act<ACT>(y[3]), y1h[m][1], y1l[m][1]);
         }
         y1h[M1][0] = y1h[M1][1] = y1l[M1][0] = y1l[M1][1] = 0u;          // the zero tile that pads an odd chunk
-        f32x4 H2a[M2], L2a[M2];
+        f32x4 H2a[M2];
 #pragma unroll
-        for (int m = 0; m < M2; ++m) { H2a[m] = B2[m]; L2a[m] = zero; }
+        for (int m = 0; m < M2; ++m) H2a[m] = B2[m];
 #pragma unroll
         for (int c = 0; c < C2; ++c) {
             constexpr int kPad = M1;
@@ -365,21 +361,21 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, ui
             const f16x8 hb = tuple16(y1h[m0][0], y1h[m0][1], y1h[m1][0], y1h[m1][1]);
             const f16x8 lb = tuple16(y1l[m0][0], y1l[m0][1], y1l[m1][0], y1l[m1][1]);
 #pragma unroll
-            for (int m = 0; m < M2; ++m) {
-                H2a[m] = mfma16h(A2h[m][c], hb, H2a[m]);
-                L2a[m] = mfma16h(A2h[m][c], lb, L2a[m]);
-                L2a[m] = mfma16h(A2l[m][c], hb, L2a[m]);
-            }
+            for (int m = 0; m < M2; ++m) H2a[m] = mfma16h(A2h[m][c], hb, H2a[m]);
+#pragma unroll
+            for (int m = 0; m < M2; ++m) H2a[m] = mfma16h(A2h[m][c], lb, H2a[m]);
+#pragma unroll
+            for (int m = 0; m < M2; ++m) H2a[m] = mfma16h(A2l[m][c], hb, H2a[m]);
         }
         uint32_t y2h[M2 + 1][2], y2l[M2 + 1][2];
 #pragma unroll
         for (int m = 0; m < M2; ++m) {
-            const f32x4 y = join16(H2a[m], L2a[m]);
+            const f32x4 y = H2a[m];
             split2(teacher_act<ACT>(y[0]), teacher_act<ACT>(y[1]), y2h[m][0], y2l[m][0]);
             split2(teacher_act<ACT>(y[2]), teacher_act<ACT>(y[3]), y2h[m][1], y2l[m][1]);
         }
         y2h[M2][0] = y2h[M2][1] = y2l[M2][0] = y2l[M2][1] = 0u;
-        f32x4 Ho = B3, Lo = zero;
+        f32x4 Ho = B3;
 #pragma unroll
         for (int c = 0; c < C3; ++c) {
             constexpr int kPad = M2;
@@ -387,11 +383,11 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, ui
             const f16x8 hb = tuple16(y2h[m0][0], y2h[m0][1], y2h[m1][0], y2h[m1][1]);
             const f16x8 lb = tuple16(y2l[m0][0], y2l[m0][1], y2l[m1][0], y2l[m1][1]);
             Ho = mfma16h(A3h[c], hb, Ho);
-            Lo = mfma16h(A3h[c], lb, Lo);
-            Lo = mfma16h(A3l[c], hb, Lo);
+            Ho = mfma16h(A3h[c], lb, Ho);
+            Ho = mfma16h(A3l[c], hb, Ho);
         }
         if (valid && q == 0) {
-            const f32x4 o = join16(Ho, Lo);
+            const f32x4 o = Ho;
 #pragma unroll
             for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[r]);
         }
