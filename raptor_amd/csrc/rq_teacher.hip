@@ -267,9 +267,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
     const f32x2 v = {v0, v1};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 r = v - __builtin_convertvector(h, f32x2);
-    hi = __builtin_bit_cast(uint32_t, h);
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    // residual v - hi in one instruction per value: v_fma_mix_f32 reads the f16 half of `hi` as an fp32 operand
+    // (op_sel_hi marks the 16-bit source, op_sel picks its half); the difference is exact
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(v1));
+    const f32x2 r = {r0, r1};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 __device__ __forceinline__ f16x8 tuple16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
