@@ -64,7 +64,11 @@ PYBIND11_MODULE(l2f_mi355x, m) {
     py::class_<Rng>(m, "VectorRng").def(py::init<>());
     py::class_<Environment>(m, "VectorEnvironment")
         .def(py::init<uint32_t>(), py::arg("n_environments"))
-        .def_readonly("N_ENVIRONMENTS", &Environment::n);
+        .def_property_readonly("N_ENVIRONMENTS", [](const Environment& e) {
+            uint32_t n = e.n;
+            if (e.h) check(rq_env_num_envs(e.h, &n));                                            // README.md:55
+            return n;
+        });
     py::class_<Parameters>(m, "VectorParameters").def(py::init<>());
     py::class_<State>(m, "VectorState").def(py::init<>()).def("assign", [](State& s, const State& other) {
         check(rq_state_assign(s.h, other.h));                                                // README.md:99

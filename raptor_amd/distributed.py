@@ -154,6 +154,14 @@ class NativeReturnsExchange:
         self._fin = weakref.finalize(self, _lib.load().rq_comm_destroy, h)
         self.posts = 0
 
+    def info(self):
+        """(n_ranks, rank) as the communicator itself reports them (rq_comm_info)."""
+        import ctypes as C
+        from . import _lib
+        n, r = C.c_uint32(), C.c_uint32()
+        _lib.call("rq_comm_info", self._h, C.byref(n), C.byref(r))
+        return n.value, r.value
+
     def post(self, env):
         from . import _lib
         _lib.call("rq_allgather_returns", env._require("environment"), self._h)

@@ -1340,6 +1340,7 @@ def test_native_rccl_exchange_one_rank(device, oracle):
     from raptor_amd.distributed import NativeReturnsExchange
     w = World(device, oracle, 4096, seed=41, episode_step_limit=20)
     ex = NativeReturnsExchange(device, 1, 0, NativeReturnsExchange.unique_id())
+    assert ex.info() == (1, 0)
     snaps = []
     for k in range(5):
         w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 20, "fused", True)
