@@ -204,3 +204,51 @@ def test_operand_packers_under_sanitizers(tmp_path):
     r = subprocess.run([exe, os.path.join(root, "raptor_amd", "data", "raptor_policy.bin")], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
+def test_split_f16_scheme_in_numpy_meets_the_fp32_bar(weights, kat):
+    """The arithmetic of RQ_POLICY_F16X2_MFMA restated in numpy, independent of the hardware: every operand as two float16
+    pieces (hi = f16(v), lo = f16(v - hi)), a contraction as hi.hi + hi.lo + lo.hi in float32 (lo.lo dropped), gate rows
+    pre-scaled before the split as the host packer does.  Over the 500 recurrent steps of the reference's known-answer
+    vectors it stays within the fp32 tolerance (1e-5); with the lo pieces removed (plain f16 operands) it does not -
+    so the second piece is what buys the accuracy."""
+    x, y = kat
+    w = weights
+    W0, b0 = w[0:352].reshape(16, 22), w[352:368]
+    Wi, Wh = w[368:1136].reshape(48, 16), w[1136:1904].reshape(48, 16)
+    bi, bh, W2, b2 = w[1904:1952], w[1952:2000], w[2016:2080].reshape(4, 16), w[2080:2084]
+    k = np.concatenate([np.full(32, -1.4426950408889634, np.float32), np.full(16, -2.8853900817779268, np.float32)])[:, None]
+
+    def split(v):
+        v = np.asarray(v, np.float32)
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float32), lo.astype(np.float32)
+
+    def dot(xv, Wm, second_piece):
+        xh, xl = split(xv)
+        wh, wl = split(Wm)
+        acc = xh @ wh.T
+        if second_piece:
+            acc = acc + xl @ wh.T + xh @ wl.T
+        return acc.astype(np.float32)
+
+    def run(second_piece):
+        h = np.zeros((2, 16), np.float32)
+        worst = 0.0
+        for t in range(500):
+            xin = np.concatenate([x[t], np.ones((2, 1), np.float32)], axis=1)              # bias rides as input 22
+            y0 = np.maximum(dot(xin, np.concatenate([W0, b0[:, None]], axis=1), second_piece), 0)
+            gi, gh = dot(y0, k * Wi, second_piece), dot(h, k * Wh, second_piece)                # exp2 arguments
+            e2 = lambda a: np.exp2(a.astype(np.float64))
+            r = 1 / (1 + e2(gi[:, :16] + gh[:, :16] + k[:16, 0] * (bi[:16] + bh[:16])))
+            z = 1 / (1 + e2(gi[:, 16:32] + gh[:, 16:32] + k[16:32, 0] * (bi[16:32] + bh[16:32])))
+            n = 2 / (1 + e2(gi[:, 32:] + k[32:, 0] * bi[32:] + r * (gh[:, 32:] + k[32:, 0] * bh[32:]))) - 1
+            h = (n + z * (h - n)).astype(np.float32)
+            a = dot(h, W2, second_piece) + b2
+            worst = max(worst, float(np.abs(a - y[t]).max()))
+        return worst
+
+    two, one = run(True), run(False)
+    print(f"\n[split-f16 scheme, numpy] known-answer max abs error: two pieces {two:.2e}, one piece (plain f16) {one:.2e}")
+    assert two < 1e-5 < one
