@@ -612,9 +612,26 @@ __device__ __forceinline__ void transpose4(float& n0, float& n1, float& n2, floa
 
 // One recurrent step for the 64 envs of this wave.  o: native observation; hQ[t][r]: hidden state
 // in the Q layout, updated in place; a: native action.  Wave-uniform control flow required.
+//
+// Round 3 - layer_2 left the matrix cores.  Its 16 MFMAs used a quarter of their rows (4 outputs of 16) and cost
+// 226 ns of a 3.23 us step.  Now every lane multiplies ITS slice of W2 with the hidden features it already holds
+// (Q layout: lane (q,j) has h[4q..4q+3] of env (t,j), so p_i = b2[i](q == 0) + sum_r W2[i][4q+r] h[4q+r] is 32 packed
+// fmas for 4 tiles x 4 outputs), writes the partial sums to a 64 x 20-float LDS tile (row = env, 4 floats per lane
+// group: 4 ds_write_b128) and reads its own env's row back (4 ds_read_b128): a_i = (p_i@0 + p_i@1) + (p_i@2 + p_i@3),
+// 6 packed adds, in the native layout.  The LDS round trip hides behind MFMAs that do not depend on it:
+//   PIPE (the 512-register fused rollout kernel): the recurrent half W_h h' of the NEXT step's first GRU pass is
+//     issued right after the gates that produced h' and carries the round trip; its accumulators (Carry) cross
+//     the env step and the loop's back edge.  The observation's own trip through LDS moves under the recurrent
+//     MFMAs of the second pass, which now open the step.  An env whose episode ends gets the accumulators of the
+//     initial hidden state instead (Carry::g0*, computed once per launch by the same MFMA chain).
+//   otherwise (API-granular kernels, 256-register builds: other waves of the SIMD cover the latency) the order of
+//     round 2 stays and the round trip is waited for.
+// Same arithmetic in both: every accumulator sees the same operands in the same order, so fused == chained holds
+// bit for bit as before.
 template <bool LEAN>
 struct ActorF32T {
     static constexpr int kPackedRegs = QW_REGS;
+    static constexpr bool kPipelined = !LEAN;
     // The observation changes layout (one env per lane -> layer_0's B operands) through LDS: lane L writes its 22
     // features to row L, lane (q,j) reads feature 4s+q of row 16t+j.  Row stride 25 floats: both the column writes
     // (stride 25 over 64 lanes) and the operand reads (16 rows x 4 consecutive floats) touch 64 distinct banks but
@@ -622,20 +639,36 @@ struct ActorF32T {
     // recurrent MFMAs (which do not need the observation); as lane swaps (24 v_permlane + 15 copies, VALU work
     // that an f32 MFMA never overlaps) it cost ~150 ns per step.
     static constexpr int kLdsRow = 25;
-    static constexpr int kLdsFloats = 64 * kLdsRow;
+    // layer_2's reduction tile: row = env, 5 x 16 bytes per row (4 lane groups x 4 partial outputs + 16 bytes of
+    // padding: rows 80 bytes apart put 16 consecutive lanes' 16-byte accesses on 16 distinct bank quads)
+    static constexpr int kRedRow4 = 5;
+    static constexpr int kLdsFloats = 64 * kRedRow4 * 4 + 64 * kLdsRow;
     typedef __attribute__((address_space(3))) float LdsFloat;
+    typedef __attribute__((address_space(3))) f32x4 LdsQuad;
     float W[QW_REGS];
-    LdsFloat* wr;            // this lane's row of the wave's kLdsFloats of LDS
+    LdsFloat* wr;            // this lane's row of the wave's observation tile
     LdsFloat* rd[4];         // lane (q,j): row 16t + j, column q, one pointer per tile t (kept in registers: the
                              // offsets of a two-address LDS read reach 255 floats, a tile is 400 apart)
+    LdsQuad* red_wr;         // lane (q,j): row j, quad q of the reduction tile (tile t: + 16 rows)
+    LdsQuad* red_rd;         // lane L: row L
+
+    // what crosses the step boundary in the pipelined build: the accumulators (bias + W_h h') of tile 0 for the
+    // coming step, and the same for the initial hidden state (the same for every env), parked in accumulation
+    // registers: only an episode end reads them
+    struct Carry { f32x4 gr, gz, gnh; float g0[12]; };
 
     // every lane loads its slice of the packed image; all 64 lanes must be active.  WAVES = waves per workgroup.
     template <int WAVES>
     __device__ __forceinline__ void load(const float* __restrict__ packed) {
-        __shared__ float lds[WAVES * kLdsFloats];
+        __shared__ __attribute__((aligned(16))) float lds[WAVES * kLdsFloats];
         const int lane = threadIdx.x & 63;
+        // per wave: the observation tile (64 x 25 floats), then the reduction tile (64 x 5 quads, 16-byte aligned)
         LdsFloat* stage = (LdsFloat*)lds + (threadIdx.x >> 6) * kLdsFloats;
+        LdsQuad* red = (LdsQuad*)(stage + 64 * kLdsRow);
+        red_wr = red + (lane & 15) * kRedRow4 + (lane >> 4);
+        red_rd = red + lane * kRedRow4;
         wr = stage + lane * kLdsRow;
+        asm volatile("" : "+v"(red_wr), "+v"(red_rd), "+v"(wr));      // kept in registers, not re-derived per access
         wr[22] = 1.0f;        // input 22 is the constant 1 that carries layer_0's bias,
         wr[23] = 0.0f;        // input 23 is padding: written once
 #pragma unroll
@@ -645,12 +678,104 @@ struct ActorF32T {
         }
 #pragma unroll
         for (int v = 0; v < QW_REGS; ++v) W[v] = packed[v * 64 + lane];
+        // The 30 images that are only ever an MFMA's A operand (layer_0, W_input, W_hidden) live in ACCUMULATION
+        // registers: the matrix instructions read A / B from either file, the VALU only from the architected 256,
+        // and with one wave per SIMD the other 256 sit idle - parked there, the operands leave the VALU's file to
+        // the env state and the accumulators that cross the step boundary.
+        if constexpr (kPipelined) {
+#pragma unroll
+            for (int v = QW_L0; v < QW_L2; ++v) {
+                const float t = W[v];
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(W[v]) : "v"(t));
+            }
+        }
     }
     __device__ __forceinline__ float h0(int r) const { return W[QW_H0 + r]; }
 
-    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
-        step<0>(o, hQ, a, [] {});
+    // bias + W_h h of tile T: three chains, K-step by K-step
+    template <int T>
+    __device__ __forceinline__ void recurrent_tile(const float (&hQ)[4][4], f32x4& gr, f32x4& gz, f32x4& gnh) const {
+        gr = mfma16(W[QW_GH + 0], hQ[T][0], f32x4{W[QW_BR], W[QW_BR + 1], W[QW_BR + 2], W[QW_BR + 3]});
+        gz = mfma16(W[QW_GH + 4], hQ[T][0], f32x4{W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]});
+        gnh = mfma16(W[QW_GH + 8], hQ[T][0], f32x4{W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]});
+#pragma unroll
+        for (int s = 1; s < 4; ++s) {
+            gr = mfma16(W[QW_GH + 0 + s], hQ[T][s], gr);
+            gz = mfma16(W[QW_GH + 4 + s], hQ[T][s], gz);
+            gnh = mfma16(W[QW_GH + 8 + s], hQ[T][s], gnh);
+        }
     }
+    // the same for tiles TA and TB, K-step by K-step across both (six independent chains in flight)
+    template <int TA, int TB>
+    __device__ __forceinline__ void recurrent_pair(const float (&hQ)[4][4], f32x4& gra, f32x4& gza, f32x4& gnha,
+                                                   f32x4& grb, f32x4& gzb, f32x4& gnhb) const {
+        const f32x4 cbr = {W[QW_BR], W[QW_BR + 1], W[QW_BR + 2], W[QW_BR + 3]};
+        const f32x4 cbz = {W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]};
+        const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
+        gra = mfma16(W[QW_GH + 0], hQ[TA][0], cbr);  gza = mfma16(W[QW_GH + 4], hQ[TA][0], cbz);  gnha = mfma16(W[QW_GH + 8], hQ[TA][0], cbnh);
+        grb = mfma16(W[QW_GH + 0], hQ[TB][0], cbr);  gzb = mfma16(W[QW_GH + 4], hQ[TB][0], cbz);  gnhb = mfma16(W[QW_GH + 8], hQ[TB][0], cbnh);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) {
+            gra = mfma16(W[QW_GH + 0 + s], hQ[TA][s], gra);  gza = mfma16(W[QW_GH + 4 + s], hQ[TA][s], gza);
+            gnha = mfma16(W[QW_GH + 8 + s], hQ[TA][s], gnha);
+            grb = mfma16(W[QW_GH + 0 + s], hQ[TB][s], grb);  gzb = mfma16(W[QW_GH + 4 + s], hQ[TB][s], gzb);
+            gnhb = mfma16(W[QW_GH + 8 + s], hQ[TB][s], gnhb);
+        }
+    }
+    // before the first step of a launch: tile 0's recurrent accumulators, and those of the initial hidden state
+    __device__ __forceinline__ void prime(const float (&hQ)[4][4], Carry& c) const {
+        if constexpr (!kPipelined) return;
+        float h0q[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h0q[t][r] = W[QW_H0 + r];
+        f32x4 g[3];
+        recurrent_tile<0>(h0q, g[0], g[1], g[2]);
+        recurrent_tile<0>(hQ, c.gr, c.gz, c.gnh);
+        // MFMA results read by inline asm: the compiler places the wait states only for instructions it can see, so
+        // they are part of the statement that reads the twelve values (data dependence orders it behind the chains)
+        asm volatile("s_nop 15\n\ts_nop 15\n\t"
+                     "v_accvgpr_write_b32 %0, %12\n\tv_accvgpr_write_b32 %1, %13\n\tv_accvgpr_write_b32 %2, %14\n\t"
+                     "v_accvgpr_write_b32 %3, %15\n\tv_accvgpr_write_b32 %4, %16\n\tv_accvgpr_write_b32 %5, %17\n\t"
+                     "v_accvgpr_write_b32 %6, %18\n\tv_accvgpr_write_b32 %7, %19\n\tv_accvgpr_write_b32 %8, %20\n\t"
+                     "v_accvgpr_write_b32 %9, %21\n\tv_accvgpr_write_b32 %10, %22\n\tv_accvgpr_write_b32 %11, %23"
+                     : "=&a"(c.g0[0]), "=&a"(c.g0[1]), "=&a"(c.g0[2]), "=&a"(c.g0[3]), "=&a"(c.g0[4]), "=&a"(c.g0[5]),
+                       "=&a"(c.g0[6]), "=&a"(c.g0[7]), "=&a"(c.g0[8]), "=&a"(c.g0[9]), "=&a"(c.g0[10]), "=&a"(c.g0[11])
+                     : "v"(g[0][0]), "v"(g[0][1]), "v"(g[0][2]), "v"(g[0][3]), "v"(g[1][0]), "v"(g[1][1]), "v"(g[1][2]),
+                       "v"(g[1][3]), "v"(g[2][0]), "v"(g[2][1]), "v"(g[2][2]), "v"(g[2][3]));
+    }
+    // envs of `mask` (bit 16 t + j) had their hidden state replaced by the initial one after the carry was computed
+    __device__ __forceinline__ void reset_carry(uint64_t mask, Carry& c) const {
+        if constexpr (!kPipelined) return;
+        const bool take = (mask >> (threadIdx.x & 15)) & 1ull;         // the carry covers tile 0
+        float g[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(g[k]) : "a"(c.g0[k]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c.gr[r] = take ? g[r] : c.gr[r];
+            c.gz[r] = take ? g[4 + r] : c.gz[r];
+            c.gnh[r] = take ? g[8 + r] : c.gnh[r];
+        }
+    }
+
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
+        Carry none;
+        run<false, 0>(o, hQ, a, none, [] {});
+    }
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
+        Carry none;
+        run<false, N_STORES>(o, hQ, a, none, early_stores);
+    }
+    // the fused rollout loop: `c` primed before the first step, reset_carry after an episode end
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry& c,
+                                               HOOK early_stores) const {
+        run<kPipelined, N_STORES>(o, hQ, a, c, early_stores);
+    }
+
     // `early_stores`: N_STORES vector-memory stores that only need the observation (the trajectory recorder's).
     // They are emitted into the first GRU pass and interleaved with its MFMAs - a store issues while the matrix
     // pipe executes, whereas a burst of 26 stores after the actor holds the wave for ~0.4 us (measured).
@@ -660,51 +785,53 @@ struct ActorF32T {
     // (tools/overlap.hip: one MFMA + 2 FMAs = 23.9 ns against 14.1 + 2 x 2.1); left alone the scheduler
     // interleaves single MFMAs with the gate arithmetic (23 batches per step instead of 6).
     // Summation order of the r/z gate accumulators: bias, W_h h (k = 0..15), W_i y0 (k = 0..15).
-    template <int N_STORES, class HOOK>
-    __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
+    template <bool PIPE, int N_STORES, class HOOK>
+    __device__ __forceinline__ void run(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry& c,
+                                        HOOK early_stores) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         constexpr int TP = 2;     // GRU tiles per pass: 4 accumulators per tile are live (with all four tiles in
                                   // flight the 512-register build parked MFMA operands in AGPRs, ~25 moves per step)
-        const f32x4 cbr = {W[QW_BR], W[QW_BR + 1], W[QW_BR + 2], W[QW_BR + 3]};
-        const f32x4 cbz = {W[QW_BZ], W[QW_BZ + 1], W[QW_BZ + 2], W[QW_BZ + 3]};
         const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
-        const f32x4 cbnh = {W[QW_BNH], W[QW_BNH + 1], W[QW_BNH + 2], W[QW_BNH + 3]};
         f32x4 gr[TP], gz[TP], gni[TP], gnh[TP];
         float X[6][4];            // X[s][t] at lane (q,j) = o[4s+q] of env (t,j)
 
-        // ---- batch 1: recurrent half of GRU pass 0, with the observation's trip through LDS in its shadow ----
+        // ---- batch 1: recurrent MFMAs with the observation's trip through LDS in their shadow: pass 0's own 24
+        // (tiles 0, 1) in the round-2 order; tile 1's 12 when tile 0's accumulators arrived with the carry (layer_0
+        // consumes the operands K-step by K-step, so the last reads may still be in flight when it starts) ----
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < 22; ++f) wr[f] = o[f];
-#pragma unroll
-        for (int u = 0; u < TP; ++u) {
-            gr[u] = mfma16(W[QW_GH + 0], hQ[u][0], cbr);
-            gz[u] = mfma16(W[QW_GH + 4], hQ[u][0], cbz);
-            gnh[u] = mfma16(W[QW_GH + 8], hQ[u][0], cbnh);
-        }
-#pragma unroll
-        for (int s = 1; s < 4; ++s)
-#pragma unroll
-            for (int u = 0; u < TP; ++u) {
-                gr[u] = mfma16(W[QW_GH + 0 + s], hQ[u][s], gr[u]);
-                gz[u] = mfma16(W[QW_GH + 4 + s], hQ[u][s], gz[u]);
-                gnh[u] = mfma16(W[QW_GH + 8 + s], hQ[u][s], gnh[u]);
-            }
+        if constexpr (PIPE) recurrent_tile<1>(hQ, gr[1], gz[1], gnh[1]);
+        else                recurrent_pair<0, 1>(hQ, gr[0], gz[0], gnh[0], gr[1], gz[1], gnh[1]);
 #pragma unroll
         for (int s = 0; s < 6; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) X[s][t] = rd[t][4 * s];
+        if constexpr (PIPE) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {                                 // 8 MFMAs carry the writes,
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
-        }
+            for (int k = 0; k < 4; ++k) {                             // 4 MFMAs carry the writes,
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            }
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {                                // 12 the reads, 4 cover the last read's latency
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            for (int k = 0; k < 6; ++k) {                             // 6 the reads, 2 + layer_0's first the latency
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                             // 8 MFMAs carry the writes,
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {                            // 12 the reads, 4 cover the last read's latency
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIPE) { gr[0] = c.gr; gz[0] = c.gz; gnh[0] = c.gnh; }
 
         // ---- batch 2: layer_0 ----
         f32x4 y0[4];
@@ -720,27 +847,12 @@ struct ActorF32T {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y0[t][r] = relu(y0[t][r]);
 
-        // ---- batches 3, 4: input half of pass 0; all of pass 1 ----
+        // ---- batches 3, 4: input half of pass 0; pass 1 (with its recurrent half unless the step opened with it) ----
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TP) {
             __builtin_amdgcn_sched_barrier(0);
             if (t0 == 0) early_stores();
-            if (t0 != 0) {
-#pragma unroll
-                for (int u = 0; u < TP; ++u) {
-                    gr[u] = mfma16(W[QW_GH + 0], hQ[t0 + u][0], cbr);
-                    gz[u] = mfma16(W[QW_GH + 4], hQ[t0 + u][0], cbz);
-                    gnh[u] = mfma16(W[QW_GH + 8], hQ[t0 + u][0], cbnh);
-                }
-#pragma unroll
-                for (int s = 1; s < 4; ++s)
-#pragma unroll
-                    for (int u = 0; u < TP; ++u) {
-                        gr[u] = mfma16(W[QW_GH + 0 + s], hQ[t0 + u][s], gr[u]);
-                        gz[u] = mfma16(W[QW_GH + 4 + s], hQ[t0 + u][s], gz[u]);
-                        gnh[u] = mfma16(W[QW_GH + 8 + s], hQ[t0 + u][s], gnh[u]);
-                    }
-            }
+            if (t0 != 0) recurrent_pair<2, 3>(hQ, gr[0], gz[0], gnh[0], gr[1], gz[1], gnh[1]);
 #pragma unroll
             for (int u = 0; u < TP; ++u) gni[u] = mfma16(W[QW_GI + 8], y0[t0 + u][0], cbni);
 #pragma unroll
@@ -763,22 +875,59 @@ struct ActorF32T {
             for (int u = 0; u < TP; ++u) gru_gates_prescaled(gr[u], gz[u], gni[u], gnh[u], hQ[t0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- batch 5: layer_2, the four tiles land in disjoint row blocks of one D = the native layout ----
-        const f32x4 cb2 = {W[QW_B2], W[QW_B2 + 1], W[QW_B2 + 2], W[QW_B2 + 3]};
-        f32x4 d0 = mfma16(W[QW_L2 + 0], hQ[0][0], cb2);
-        f32x4 d1 = mfma16(W[QW_L2 + 4], hQ[1][0], zero);
-        d0 = mfma16(W[QW_L2 + 8], hQ[2][0], d0);
-        d1 = mfma16(W[QW_L2 + 12], hQ[3][0], d1);
+
+        // ---- layer_2: the lane's slice of every output, tile by tile (32 packed fmas) ----
+        f32x2 PL[4], PH[4];       // partial outputs (0, 1) and (2, 3) of tile t
 #pragma unroll
-        for (int s = 1; s < 4; ++s) {
-            d0 = mfma16(W[QW_L2 + 0 + s], hQ[0][s], d0);
-            d1 = mfma16(W[QW_L2 + 4 + s], hQ[1][s], d1);
-            d0 = mfma16(W[QW_L2 + 8 + s], hQ[2][s], d0);
-            d1 = mfma16(W[QW_L2 + 12 + s], hQ[3][s], d1);
+        for (int t = 0; t < 4; ++t) {
+            // The hidden features as the pairs the gates left them in; the broadcast of one half is a source modifier
+            // of the packed fma, written out: as {h, h} (or a shuffle of the pair) the optimiser turns each into an
+            // overlapping two-float load from the array, which then stays in scratch memory.  Inputs are results of
+            // plain packed VALU instructions (gru_gates_prescaled's blend): no hazard the compiler would have to see.
+            const f32x2 H01 = {hQ[t][0], hQ[t][1]}, H23 = {hQ[t][2], hQ[t][3]};
+            const f32x2 wl[4] = {{W[QW_L2 + 0], W[QW_L2 + 1]}, {W[QW_L2 + 4], W[QW_L2 + 5]}, {W[QW_L2 + 8], W[QW_L2 + 9]}, {W[QW_L2 + 12], W[QW_L2 + 13]}};
+            const f32x2 wh[4] = {{W[QW_L2 + 2], W[QW_L2 + 3]}, {W[QW_L2 + 6], W[QW_L2 + 7]}, {W[QW_L2 + 10], W[QW_L2 + 11]}, {W[QW_L2 + 14], W[QW_L2 + 15]}};
+            const f32x2 bl = {W[QW_B2 + 0], W[QW_B2 + 1]}, bh = {W[QW_B2 + 2], W[QW_B2 + 3]};
+            f32x2 pl, ph;
+            RQ_PK_FMA(pl, wl[0], H01, bl, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+            RQ_PK_FMA(ph, wh[0], H01, bh, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+            RQ_PK_FMA(pl, wl[1], H01, pl, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+            RQ_PK_FMA(ph, wh[1], H01, ph, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+            RQ_PK_FMA(pl, wl[2], H23, pl, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+            RQ_PK_FMA(ph, wh[2], H23, ph, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+            RQ_PK_FMA(pl, wl[3], H23, pl, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+            RQ_PK_FMA(ph, wh[3], H23, ph, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+            PL[t] = pl; PH[t] = ph;
         }
+        // a use the barrier is ordered against: pure arithmetic is otherwise emitted where its first user is, past it
+        asm volatile("" : : "v"(PL[0]), "v"(PH[0]), "v"(PL[1]), "v"(PH[1]), "v"(PL[2]), "v"(PH[2]), "v"(PL[3]), "v"(PH[3]));
+        // ---- batch 5 (PIPE): the next step's recurrent MFMAs of tile 0 carry the lane-group reduction ----
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
+        for (int t = 0; t < 4; ++t) red_wr[16 * kRedRow4 * t] = f32x4{PL[t][0], PL[t][1], PH[t][0], PH[t][1]};
+        if constexpr (PIPE) recurrent_tile<0>(hQ, c.gr, c.gz, c.gnh);
+        f32x4 R[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = red_rd[q];
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                 // 4 MFMAs carry the writes,
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                 // 4 the reads, 4 the reads' latency
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the accumulators are next read a whole env step later: a use here, or the chains are emitted after this
+        // point (and the round trip loses its cover)
+        if constexpr (PIPE) asm volatile("" : : "v"(c.gr), "v"(c.gz), "v"(c.gnh));
+        const f32x2 A01 = (f32x2{R[0][0], R[0][1]} + f32x2{R[1][0], R[1][1]}) + (f32x2{R[2][0], R[2][1]} + f32x2{R[3][0], R[3][1]});
+        const f32x2 A23 = (f32x2{R[0][2], R[0][3]} + f32x2{R[1][2], R[1][3]}) + (f32x2{R[2][2], R[2][3]} + f32x2{R[3][2], R[3][3]});
+        a[0] = A01[0]; a[1] = A01[1]; a[2] = A23[0]; a[3] = A23[1];
     }
 };
 
@@ -834,6 +983,14 @@ struct ActorBF16 {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 
+    // the fused rollout's interface (ActorF32T pipelines across the step boundary; nothing to carry here)
+    struct Carry {};
+    __device__ __forceinline__ void prime(const float (&)[4][4], Carry&) const {}
+    __device__ __forceinline__ void reset_carry(uint64_t, Carry&) const {}
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry&, HOOK early_stores) const {
+        step<N_STORES>(o, hQ, a, early_stores);
+    }
     template <int N_STORES, class HOOK>
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
         early_stores();           // the bf16 MFMAs co-execute with everything else: no placement needed
@@ -974,6 +1131,14 @@ struct ActorF16X2 {
     static __device__ __forceinline__ f16x8 tuple(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
         const dwordx4 u = {d0, d1, d2, d3};
         return __builtin_bit_cast(f16x8, u);
+    }
+    // the fused rollout's interface (ActorF32T pipelines across the step boundary; nothing to carry here)
+    struct Carry {};
+    __device__ __forceinline__ void prime(const float (&)[4][4], Carry&) const {}
+    __device__ __forceinline__ void reset_carry(uint64_t, Carry&) const {}
+    template <int N_STORES, class HOOK>
+    __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry&, HOOK early_stores) const {
+        step<N_STORES>(o, hQ, a, early_stores);
     }
     template <int N_STORES, class HOOK>
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {

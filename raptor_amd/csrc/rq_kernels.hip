@@ -452,6 +452,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         const uint64_t thaw = __builtin_amdgcn_ballot_w64(was_frozen);
         if (thaw != 0) select_hidden_q(thaw, h0Q, hQ);
     }
+    typename ACTOR::Carry carry;          // what the actor carries from one step into the next (ActorF32T::Carry)
+    actor.prime(hQ, carry);
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool frozen = AUTORESET ? false : was_frozen;
     // wave-uniform: no env of this wave distinguishes rotor spin-up from spin-down (see dynamics<SYM_TAU>)
@@ -478,13 +480,13 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         if (RECORD) {
             const size_t tt = traj.t0 + t;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(traj.obs + tt * 22 * ld, 0, 22u * row, 0x00020000);
-            actor.template step<22>(o, hn, a, [&] {
+            actor.template step_fused<22>(o, hn, a, carry, [&] {
 #pragma unroll
                 for (int j = 0; j < 22; ++j)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, 0);
             });
         } else {
-            actor.step(o, hn, a);
+            actor.template step_fused<0>(o, hn, a, carry, [] {});
         }
         if (SAS) sample_and_squash(sas, epoch0 + t, genv, hn, a);        // SampleAndSquash output stage (rare)
         if (RECORD) {
@@ -538,7 +540,10 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         }
         if (AUTORESET) {   // policy reset of the envs whose episode ended: h <- initial_hidden_state
             const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
-            if (ended_mask != 0) select_hidden_q(ended_mask, h0Q, hQ);
+            if (ended_mask != 0) {
+                select_hidden_q(ended_mask, h0Q, hQ);
+                actor.reset_carry(ended_mask, carry);
+            }
         }
     }
 

@@ -148,16 +148,17 @@ enum {
     QW_L0 = 0,    //  6: layer_0, K-step s: lane (q,j) = W0[j][4s+q]; input 22 -> b0[j], input 23 -> 0
     QW_GI = 6,    // 12: W_input,  [m][s]: lane (q,j) = Wi[16m+j][4q+s]
     QW_GH = 18,   // 12: W_hidden, [m][s]: lane (q,j) = Wh[16m+j][4q+s]
-    QW_L2 = 30,   // 16: layer_2,  [t][s]: lane (q,j) = (j>>2 == t) ? W2[j&3][4q+s] : 0
-    // biases never occupy an MFMA C operand (that costs a 4-register copy per chain): layer_0's
-    // bias rides in the spare K slot 22 (its B operand is the constant 1), the gate biases are
-    // folded, pre-scaled, into the fma that feeds v_exp_f32, layer_2's is added after the MFMAs
+    QW_L2 = 30,   // 16: layer_2 on the VALU, [r][i]: lane (q,j) = W2[i][4q+r] - the lane's slice of output row i
+                  //     (round 3: the 16 quarter-filled MFMAs of layer_2 became 32 packed fmas on the Q layout + a
+                  //     lane-group reduction through LDS, ActorF32T::layer2_*)
+    // layer_0's bias rides in the spare K slot 22 (its B operand is the constant 1); the gate biases, pre-scaled,
+    // enter through the C operand of each chain's first MFMA; layer_2's starts lane-group 0's partial sum
     QW_BR = 46,   //  4: [r]: -log2(e)  * (bi[4q+r] + bh[4q+r])
     QW_BZ = 50,   //  4: [r]: -log2(e)  * (bi[16+4q+r] + bh[16+4q+r])
     QW_BNI = 54,  //  4: [r]: -2log2(e) * bi[32+4q+r]
     QW_BNH = 58,  //  4: [r]: -2log2(e) * bh[32+4q+r]
     QW_H0 = 62,   //  4: [r]: initial_hidden_state[4q+r]
-    QW_B2 = 66,   //  4: [r]: b2[r] on every lane
+    QW_B2 = 66,   //  4: [i]: q == 0 ? b2[i] : 0   (addend of the lane-group's first partial product)
     QW_REGS = 70
 };
 // bf16 actor (v_mfma_f32_16x16x32_bf16): A operands are bf16x8 = 4 dword images each, element e of

@@ -29,15 +29,15 @@ void pack_policy(const float* w, float* packed) {
                 img(QW_GI + 4 * m + s) = k * w[WI + (16 * m + j) * 16 + 4 * q + s];
                 img(QW_GH + 4 * m + s) = k * w[WH + (16 * m + j) * 16 + 4 * q + s];
             }
-        for (int t = 0; t < 4; ++t)
-            for (int s = 0; s < 4; ++s) img(QW_L2 + 4 * t + s) = ((j >> 2) == t) ? w[W2 + (j & 3) * 16 + 4 * q + s] : 0.0f;
+        for (int r = 0; r < 4; ++r)
+            for (int i = 0; i < 4; ++i) img(QW_L2 + 4 * r + i) = w[W2 + i * 16 + 4 * q + r];
         for (int r = 0; r < 4; ++r) {
             img(QW_BR + r) = kS * (w[BI + 4 * q + r] + w[BH + 4 * q + r]);
             img(QW_BZ + r) = kS * (w[BI + 16 + 4 * q + r] + w[BH + 16 + 4 * q + r]);
             img(QW_BNI + r) = kT * w[BI + 32 + 4 * q + r];
             img(QW_BNH + r) = kT * w[BH + 32 + 4 * q + r];
             img(QW_H0 + r) = w[H0 + 4 * q + r];
-            img(QW_B2 + r) = w[B2 + r];
+            img(QW_B2 + r) = q == 0 ? w[B2 + r] : 0.0f;
         }
     }
 }
