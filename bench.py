@@ -15,12 +15,22 @@ collective, one all-gather of episode returns per 500-step episode (RCCL over xG
 rq_allgather_returns), enqueued behind the rollout that completed the episode and overlapped with the next one.
 
 Timing: after exactly --warmup untimed steps, the timed region - exactly --steps steps (one fused launch
-per <= 500 of them + one exchange each), bracketed by barrier + synchronize on both sides - is REPEATED
-(at least 5 times and until 0.25 s of timed regions have accumulated, at most 2000) and the MEDIAN region
-defines `ms_per_step` and `value` (max over ranks per region); every region is timed and `timing` reports
-first / min / median / max.  A short region (the driver's --steps 20 is one 70 us launch) is bound by launch
-overhead and by the clock ramp of the first ~20 ms; `steady_state` therefore adds 10 back-to-back 500-step
-launches measured in the same run, so that the record carries the steady-state figure too.
+per <= 500 of them), bracketed by barrier + synchronize on both sides - is REPEATED (at least 5 times and
+until 0.25 s of timed regions have accumulated, at most 2000); every region is timed (max over ranks) and
+`timing` reports first / min / median / mean / max.  The exchange belongs to the episode: one all-gather per
+500 steps, posted by the region in which the 500th step falls and waited for inside that region.  `ms_per_step`
+and `value` charge every region its share of it: the median region WITHOUT an exchange plus steps/500 of the
+difference to the median region WITH one (round 3; the plain median of round 2 never saw the 1-in-25 region
+that carries the collective when --steps is 20).  A short region (the driver's --steps 20 is one 70 us launch)
+is bound by launch overhead and by the clock ramp of the first ~20 ms; `steady_state` therefore adds 10
+back-to-back 500-step launches measured in the same run, so that the record carries the steady-state figure
+too, and `config4` the same workload at BASELINE config 3/4's 262 144 envs per GPU.
+
+The orchestration (rendezvous, native-communicator consensus with its torch fallback, timed regions, max over
+ranks, the one JSON line) is `run_benchmark(args, engine, ...)`: `engine` is the product on this rank
+(`GpuEngine`) or, in the CPU tests, a stand-in with the same interface (`--engine tests.bench_stub_engine
+--backend gloo`: tests/test_bench_orchestration.py runs two gloo ranks through it, including a rank that
+fails phase 1 or phase 2 of the consensus).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
   timing        repetitions and the spread of the timed regions
@@ -66,7 +76,7 @@ PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak
 PEAK_HBM_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10000)
@@ -81,7 +91,13 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-native-exchange", action="store_true",
                     help="use the C++ host's RCCL all-gather even with one rank (it is always used with more)")
-    return ap.parse_args()
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the rendezvous (default: the engine's: nccl = RCCL)")
+    ap.add_argument("--engine", default="hip",
+                    help="'hip' = libraptor_quad.so on this rank's GPU (the product); a module path = a stand-in with "
+                         "the same interface (module.create_engine(local_rank, args)): CPU tests of the orchestration")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 262 144-envs-per-GPU block")
+    return ap.parse_args(argv)
 
 
 class Shard:
@@ -106,9 +122,21 @@ class Shard:
                             autoreset=True)
 
 
-def pmc_traffic(kernel, grid):
+def launch_grid(kernel, n):
+    """Threads in the grid the launcher picks for `kernel` at n envs (raptor_amd/csrc/rq_kernels.hip): the committed
+    PMC tables are keyed by grid size, which is not the env count for k_actor_step (several 64-env groups per wave)."""
+    if kernel.startswith("rq::k_actor_step"):
+        groups = (n + 63) // 64
+        gpw = 8 if groups >= 16384 else (4 if groups >= 4096 else 1)
+        return ((groups + gpw - 1) // gpw * 64 + 255) // 256 * 256
+    if kernel.startswith(("rq::k_rollout_fused", "rq::k_actor_sequence", "rq::k_actor_relabel")):
+        return (n + 63) // 64 * 64
+    return (n + 255) // 256 * 256
+
+
+def pmc_traffic(kernel, n):
     """HBM bytes per launch of EXACTLY the kernel instantiation `kernel` (profiled name without its argument
-    list, e.g. "rq::k_rollout_fused<false, true, false, rq::ActorF32T<false> >") at grid size `grid`, from the
+    list, e.g. "rq::k_rollout_fused<false, true, false, rq::ActorF32T<false> >") at `n` envs, from the
     newest committed rocprofv3 PMC summary that has it (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE
     passes of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; the
     median over that kernel's launches, so the handful of warm-up launches of another length do not count).
@@ -119,9 +147,10 @@ def pmc_traffic(kernel, grid):
             table = json.load(open(path))
         except Exception:
             continue
-        d = table.get(f"{kernel}@{grid}")
+        d = table.get(f"{kernel}@{launch_grid(kernel, n)}")
         if d and d.get("hbm_bytes_per_launch_corrected"):
-            return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path),
+            return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"],
+                    "bytes_per_env": round(d["hbm_bytes_per_launch_corrected"] / n, 2), "source": os.path.basename(path),
                     "kernel": kernel, "profiled_launch_us": d.get("median_dur_us", d.get("avg_dur_us_fetch")),
                     "profiled_launches": d.get("calls_fetch")}
     return None
@@ -164,20 +193,26 @@ def chunks(total, size):
 
 
 def kernel_probe(device, n, reps):
-    """Average launch duration (HIP events on the kernels' own stream) of the three API-granular
+    """Median launch duration (HIP events on the kernels' own stream) of the three API-granular
     kernels at batch n, device-resident chain, and their algorithmic HBM bandwidth."""
     sh = Shard(device, n, 0)
     v = sh.vector
     out = {}
 
     def timed(fn):
-        for _ in range(3):
+        """(median, min, max) microseconds per launch: >= 50 warm-up launches, then >= 20 timed batches of `reps`
+        launches each (HIP events on the engine's stream around a batch).  The median of batches, not a mean of
+        launches: one preempted batch (the driver's round-2 record carried a 175 us k_observe) cannot print."""
+        for _ in range(max(50, reps)):
             fn()
         device.synchronize()
-        device.timer_start()
-        for _ in range(reps):
-            fn()
-        return device.timer_stop() / reps * 1e3   # us per launch
+        per = []
+        for _ in range(20):
+            device.timer_start()
+            for _ in range(reps):
+                fn()
+            per.append(device.timer_stop() / reps * 1e3)
+        return float(np.median(per)), float(min(per)), float(max(per))
 
     v.observe(device, sh.env, sh.params, sh.state, None, sh.rng)
     sh.policy.evaluate_step_device(sh.env)
@@ -186,14 +221,17 @@ def kernel_probe(device, n, reps):
         ("k_actor_step", BYTES_ACTOR, lambda: sh.policy.evaluate_step_device(sh.env)),
         ("k_step", BYTES_STEP, lambda: v.step_device(device, sh.env, sh.params, sh.state, sh.state, sh.rng)),
     ):
-        us = timed(fn)
+        us, us_min, us_max = timed(fn)
         gbps = nbytes * n / (us * 1e-6) / 1e9
         tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": "rq::k_actor_step<rq::ActorF32T<true> >",
                           "k_step": "rq::k_step<false>"}[name], n)
-        out[name] = {"bound": "hbm", "us_per_launch": round(us, 3), "bytes_per_env": nbytes,
+        out[name] = {"bound": "hbm", "us_per_launch": round(us, 3),
+                     "us_per_launch_min_max": [round(us_min, 3), round(us_max, 3)], "statistic": "median of 20 batches",
+                     "bytes_per_env": nbytes,
                      "achieved_GBps": round(gbps, 1), "peak_GBps": PEAK_HBM_GBPS,
                      "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                     "traffic": None if tr is None else tr["bytes_per_launch"]}
+                     "traffic": None if tr is None else tr["bytes_per_launch"],
+                     "traffic_bytes_per_env": None if tr is None else tr["bytes_per_env"]}
     # A standalone launch at 65 536 envs is launch-latency-bound and its 20-30 MB working set sits in the 256 MiB
     # Infinity Cache, so its fraction of the HBM peak is not a bandwidth statement.  Split it instead: back-to-back
     # launches of a kernel that only stores one float per thread on the same grid take `near_empty_launch_us` each
@@ -262,6 +300,39 @@ def extension_probe(device, n):
                                 "us_per_step": round(best * 1e3 / steps, 3), "achieved_TFLOPs": round(tf, 2),
                                 "peak_TFLOPs": PEAK_FP32_TFLOPS, "frac": round(tf / PEAK_FP32_TFLOPS, 4),
                                 "bytes_per_step": 104, "achieved_GBps": round(rate * 104 / 1e9, 1)}
+    return out
+
+
+def teacher_probe(device, n, steps=200, hidden=64):
+    """SURVEY.md section 8(f) row 2 in the record: n envs x `steps` recorded steps labelled by the reference's
+    1 000 teachers (README.md:207-216) and by 1 024, exact-f32 MFMA path; envs assigned to teachers by
+    raptor_amd.teachers.balanced_teacher_assignment (whole 16-env tiles per teacher)."""
+    from raptor_amd.teachers import TeacherBank, parameter_count, balanced_teacher_assignment
+    sh = Shard(device, n, 0)
+    tr = sh.vector.Trajectory(sh.env, steps)
+    sh.vector.rollout(device, sh.env, sh.params, sh.state, sh.policy, sh.rng, steps, "fused", autoreset=True, trajectory=tr)
+    rng = np.random.default_rng(0)
+    flop_label = 2 * (22 * hidden + hidden * hidden + hidden * 4)
+    out = {"topology": f"22-{hidden}-{hidden}-4 [UPSTREAM-UNVERIFIED]", "envs": n, "steps": steps, "flop_per_label": flop_label}
+    for teachers in (1000, 1024):
+        W = (rng.standard_normal((teachers, parameter_count(22, hidden, hidden))) * 0.1).astype(np.float32)
+        bank = TeacherBank(device, W, 22, hidden, hidden, "relu", "identity", precision="fp32")
+        for name, ids in (("balanced", balanced_teacher_assignment(n, teachers)),
+                          ("contiguous", (np.arange(n, dtype=np.int64) * teachers // n).astype(np.uint32))):
+            for _ in range(2):
+                tr.relabel_teachers(bank, ids, fetch=False)
+            device.synchronize()
+            per = []
+            for _ in range(5):
+                device.timer_start()
+                tr.relabel_teachers(bank, ids, fetch=False)
+                per.append(device.timer_stop())
+            ms = float(np.median(per))
+            tf = flop_label * n * steps / (ms * 1e-3) / 1e12
+            out[f"teachers_{teachers}_{name}"] = {"ms": round(ms, 3), "labels_per_s": round(n * steps / (ms * 1e-3), 1),
+                                                 "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": PEAK_FP32_TFLOPS,
+                                                 "frac": round(tf / PEAK_FP32_TFLOPS, 4)}
+        del bank
     return out
 
 
@@ -354,130 +425,244 @@ def cpu_baseline(seconds):
                       f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads} threads"}
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+class _NativeExchange:
+    """rq_comm_* / rq_allgather_returns: the all-gather issued by the C++ host (raptor_amd/csrc/rq_comm.cpp)."""
+    kind = "native RCCL (rq_allgather_returns)"
 
+    def __init__(self, ex):
+        self.ex = ex
+
+    def post(self, shard):
+        self.ex.post(shard.env)
+
+    def finish(self):
+        return self.ex.finish(to_host=False)
+
+    def result(self):
+        return self.ex.finish()
+
+
+class _TorchExchange:
+    """raptor_amd.distributed.ReturnsExchange: the same double-buffered exchange through torch.distributed."""
+
+    def __init__(self, ex, why):
+        self.ex = ex
+        self.kind = f"torch.distributed all_gather_into_tensor (native communicator unavailable: {why})"
+
+    def post(self, shard):
+        self.ex.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))
+
+    def finish(self):
+        return self.ex.finish()
+
+    def result(self):
+        t = self.ex.finish()
+        return None if t is None else t.detach().cpu().numpy()
+
+
+class GpuEngine:
+    """What the orchestration needs from the product on one rank: libraptor_quad.so on this rank's MI355X.
+    tests/bench_stub_engine.py implements the same interface without a GPU (CPU tests of run_benchmark)."""
+    name = "hip"
+    default_backend = "nccl"
+
+    def __init__(self, local_rank, args):
+        import torch
+        import raptor_amd.l2f as l2f
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        self.torch, self.local_rank, self.precision = torch, local_rank, args.precision
+        self.device = l2f.Device(local_rank)
+        self.tensor_device = f"cuda:{local_rank}"
+
+    def init_process_group(self, dist, backend):
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=self.torch.device("cuda", self.local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    def make_shard(self, n, offset):
+        return Shard(self.device, n, offset, precision=self.precision)
+
+    def synchronize(self):
+        self.device.synchronize()
+        self.torch.cuda.synchronize()     # hipDeviceSynchronize: every stream of the device, the library's own included
+
+    def native_unique_id(self):
+        from raptor_amd.distributed import NativeReturnsExchange
+        return NativeReturnsExchange.unique_id()
+
+    def native_exchange(self, world, rank, ident):
+        from raptor_amd.distributed import NativeReturnsExchange
+        return _NativeExchange(NativeReturnsExchange(self.device, world, rank, ident))
+
+    def torch_exchange(self, n, n_total, why):
+        from raptor_amd.distributed import ReturnsExchange
+        return _TorchExchange(ReturnsExchange(n, n_total, self.tensor_device, engine_stream=self.device.stream), why)
+
+    def local_returns(self, shard):
+        return shard.env.finished_returns()
+
+    def set_rollout_timing(self, enable):
+        self.device.set_rollout_timing(enable)
+
+    def last_rollout_ms(self):
+        return self.device.last_rollout_ms()
+
+    def timer_start(self):
+        self.device.timer_start()
+
+    def timer_stop(self):
+        return self.device.timer_stop()
+
+    def describe(self):
+        return {"device": self.torch.cuda.get_device_name(self.local_rank), "hip_runtime": self.torch.version.hip}
+
+
+def make_engine(spec, local_rank, args):
+    if spec == "hip":
+        return GpuEngine(local_rank, args)
+    import importlib
+    return importlib.import_module(spec).create_engine(local_rank, args)
+
+
+def effective_region(walls, posts, steps, has_exchange):
+    """Seconds of one timed region of `steps` steps with its share of the per-episode exchange: the median region
+    that posted floor(steps/500) exchanges plus the fractional part of steps/500 times the difference to the median
+    region that posted one more.  -> (seconds, detail dict)"""
+    walls = np.asarray(walls, dtype=np.float64)
+    posts = np.asarray(posts, dtype=np.int64)
+    per = steps / EPISODE if has_exchange else 0.0
+    lo = int(np.floor(per))
+    frac = per - lo
+    detail = {"exchanges_per_region": round(per, 4)}
+    if not has_exchange or frac == 0.0 or not (posts == lo + 1).any() or not (posts == lo).any():
+        sel = walls if not has_exchange or frac == 0.0 else walls[posts == (lo if (posts == lo).any() else lo + 1)]
+        if has_exchange and frac != 0.0:
+            detail["note"] = "only one kind of region was sampled: no exchange share could be charged"
+        return float(np.median(sel)), detail
+    t_lo, t_hi = float(np.median(walls[posts == lo])), float(np.median(walls[posts == lo + 1]))
+    detail.update({"median_region_ms_without_extra_exchange": round(t_lo * 1e3, 4),
+                   "median_region_ms_with_extra_exchange": round(t_hi * 1e3, 4),
+                   "regions_with_extra_exchange": int((posts == lo + 1).sum()),
+                   "exchange_share_ms_per_region": round(frac * (t_hi - t_lo) * 1e3, 5)})
+    return t_lo + frac * (t_hi - t_lo), detail
+
+
+def run_benchmark(args, engine, rank, local_rank, world, dist):
+    """The benchmark on one rank; rank 0 returns the result dict (and main() prints it), the others None."""
     import torch
-    import raptor_amd.l2f as l2f
-    from raptor_amd.distributed import ReturnsExchange
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     n = args.envs_per_gpu
     n_total = n * world
-    device = l2f.Device(local_rank)
-    shard = Shard(device, n, rank * n, precision=args.precision)
-    # the one exchange step of the path: after every episode-length chunk the last
-    # finished return of every env is all-gathered - copy enqueued on the engine's stream, collective on
-    # a side stream, both overlapped with the next chunk's rollout (raptor_amd.distributed.ReturnsExchange)
-    # It is issued by the C++ host (rq_comm_* / rq_allgather_returns: RCCL bound by libraptor_quad.so itself);
-    # torch.distributed only ships the communicator id, provides the barriers and the max over ranks.  Should the
-    # native communicator not come up on this box, the torch-side exchange (same structure) takes over and the
-    # JSON says so.
-    exchange_kind = "native RCCL (rq_allgather_returns)"
+    shard = engine.make_shard(n, rank * n)
+    tdev = engine.tensor_device
 
     def all_ranks_ok(ok):
         if dist is None:
             return ok
-        flag = torch.tensor([1.0 if ok else 0.0], device=f"cuda:{local_rank}")
+        flag = torch.tensor([1.0 if ok else 0.0], device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item() > 0.5)
 
-    from raptor_amd.distributed import NativeReturnsExchange
-    why = ""
-    try:      # phase 1 (no collective inside): can every rank bind RCCL?  rank 0's id is the one that is used
-        ident = [NativeReturnsExchange.unique_id() if (world > 1 or args.force_native_exchange) else None]
-    except Exception as exc:      # noqa: BLE001
-        ident, why = [None], str(exc)
-    native = (world > 1 or args.force_native_exchange) and all_ranks_ok(ident[0] is not None)
-    if world == 1 and not args.force_native_exchange:
-        why = "single rank"
-    if native:
-        if dist is not None:
-            dist.broadcast_object_list(ident, src=0)
-        try:  # phase 2: the collective communicator creation
-            exchange = NativeReturnsExchange(device, world, rank, ident[0])
-        except Exception as exc:  # noqa: BLE001
-            exchange, why = None, str(exc)
-        native = all_ranks_ok(exchange is not None)
-    if native:
-        post = lambda: exchange.post(shard.env)                                            # noqa: E731
-        finish = lambda: exchange.finish(to_host=False)                                    # noqa: E731
-    elif why == "single rank":
-        # one rank: nothing to exchange - the episode returns stay where the engine keeps them (rq_env_get_finished_returns)
-        exchange_kind = "none (one rank: nothing to gather)"
-        exchange = None
-        post = lambda: None                                                                # noqa: E731
-        finish = lambda: None                                                              # noqa: E731
-    else:
-        exchange_kind = f"torch.distributed all_gather_into_tensor (native communicator unavailable: {why})"
-        exchange = ReturnsExchange(n, n_total, f"cuda:{local_rank}", engine_stream=device.stream)
-        post = lambda: exchange.post(lambda buf: shard.env.finished_returns(out=buf, wait=False))   # noqa: E731
-        finish = exchange.finish
+    def max_over_ranks(values):
+        if dist is None:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    # ---- the one exchange step of the path (SURVEY.md section 8(e)): after every episode (500 steps) the last
+    # finished return of every env is all-gathered - copy enqueued on the engine's stream, collective on a side
+    # stream.  Issued by the C++ host (rq_comm_* / rq_allgather_returns: RCCL bound by libraptor_quad.so itself);
+    # torch.distributed only ships the communicator id, provides the barriers and the max over ranks.  Two-phase
+    # consensus: should the native communicator not come up on EVERY rank, every rank takes the torch-side
+    # exchange (same structure) and the JSON says so - no rank is left waiting in a collective the others skipped.
+    want_native = world > 1 or args.force_native_exchange
+    exchange, why = None, "single rank"
+    if want_native:
+        why = ""
+        try:      # phase 1 (no collective inside): can every rank bind RCCL?  rank 0's id is the one that is used
+            ident = [engine.native_unique_id()]
+        except Exception as exc:      # noqa: BLE001
+            ident, why = [None], f"rank {rank}: {exc}"
+        native = all_ranks_ok(ident[0] is not None)
+        if native:
+            if dist is not None:
+                dist.broadcast_object_list(ident, src=0)
+            try:  # phase 2: the collective communicator creation
+                exchange = engine.native_exchange(world, rank, ident[0])
+            except Exception as exc:  # noqa: BLE001
+                exchange, why = None, f"rank {rank}: {exc}"
+            native = all_ranks_ok(exchange is not None)
+        if not native:
+            if dist is not None:      # every rank reports the same reason: the first failing rank's
+                reasons = [None] * world
+                dist.all_gather_object(reasons, why)
+                why = next((r for r in reasons if r), "another rank failed")
+            exchange = engine.torch_exchange(n, n_total, why or "another rank failed")
+    exchange_kind = exchange.kind if exchange is not None else "none (one rank: nothing to gather)"
 
     # The exchange belongs to the EPISODE (500 steps of simulated time), not to a rollout call: a region shorter
-    # than an episode carries its share - one all-gather every 500 steps across regions (a 20-step region posts one
-    # in 25 regions; `timing` reports the mean region beside the median for that reason).
+    # than an episode posts one all-gather every 500 steps across regions (a 20-step region: one in 25).
     since_exchange = [0]
 
-    def run(plan):
+    def run(plan, sh=None, ex=None):
+        sh = shard if sh is None else sh
+        ex = exchange if ex is None else ex
+        posted = 0
         for c in plan:
-            shard.rollout(c, args.mode)
+            sh.rollout(c, args.mode)
             since_exchange[0] += c
             if since_exchange[0] >= EPISODE:
                 since_exchange[0] -= EPISODE
-                post()
+                if ex is not None:
+                    ex.post(sh)
+                    posted += 1
+        return posted
+
+    def finish(ex=None):
+        ex = exchange if ex is None else ex
+        if ex is not None:
+            ex.finish()
 
     def sync_all():
-        device.synchronize()
-        torch.cuda.synchronize()
+        engine.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def timed_region(plan):
-        """exactly sum(plan) steps, barrier + synchronize before, synchronize + barrier after -> wall seconds"""
+    def timed_region(plan, sh=None, ex=None):
+        """exactly sum(plan) steps, barrier + synchronize before, synchronize + barrier after -> (wall seconds, posts)"""
         sync_all()
         t0 = time.perf_counter()
-        run(plan)
-        finish()
-        torch.cuda.synchronize()     # hipDeviceSynchronize: every stream of the device, the library's own included
+        posted = run(plan, sh, ex)
+        finish(ex)
+        engine.synchronize()
         wall = time.perf_counter() - t0              # this rank's clock stops when ITS work is done: the max over
         if dist is not None:                         # ranks is taken afterwards, so the closing barrier is not timed
             dist.barrier()
-        return wall
+        return wall, posted
 
-    def kernel_probe_ms(plan, repetitions):
+    def kernel_probe_ms(plan, repetitions, sh=None, ex=None):
         """Median duration (ms) of one rollout launch of the kind `plan` ends with.  Fused mode: the regions are run
         again with kernel-level timing on (rq_device_set_rollout_timing: the kernel's own begin / end timestamps, the
         figure rocprofv3 prints per dispatch; it costs ~8 us of dispatch per launch, which is why the timed regions
         above run without it).  Chained mode: HIP events around a whole region, per step."""
         out = []
         if args.mode == "fused":
-            device.set_rollout_timing(True)
+            engine.set_rollout_timing(True)
         for _ in range(repetitions):
             sync_all()
             if args.mode == "fused":
-                run(plan)
-                finish()
-                out.append(device.last_rollout_ms())
+                run(plan, sh, ex)
+                finish(ex)
+                out.append(engine.last_rollout_ms())
             else:
-                device.timer_start()
-                run(plan)
-                out.append(device.timer_stop() / sum(plan))
-                finish()
-        device.set_rollout_timing(False)
+                engine.timer_start()
+                run(plan, sh, ex)
+                out.append(engine.timer_stop() / sum(plan))
+                finish(ex)
+        engine.set_rollout_timing(False)
         return float(np.median(out))
 
     # ---- warm-up: one-off costs first (RCCL communicator, first barrier, lazy allocations), then EXACTLY
@@ -489,48 +674,74 @@ def main():
         run(chunks(args.warmup, EPISODE))
         finish()
 
-    # ---- timed regions: each exactly --steps steps; repeated, the median counts (module docstring) ----
+    # ---- timed regions: each exactly --steps steps; repeated (module docstring) ----
     plan = chunks(args.steps, EPISODE)
-    walls = []
+    per_region = args.steps / EPISODE if exchange is not None else 0.0
+    fractional = per_region != int(per_region)
+    walls, posts = [], []
     while True:
-        walls.append(timed_region(plan))
-        total = sum(walls)
-        if dist is not None:      # every rank must take the same decision: the slowest rank's clock decides
-            t = torch.tensor([total], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            total = float(t.item())
-        if len(walls) >= MAX_REPETITIONS or (len(walls) >= MIN_REPETITIONS and total >= MIN_TIMED_SECONDS):
+        w, p = timed_region(plan)
+        walls.append(w)
+        posts.append(p)
+        total = max_over_ranks([sum(walls)])[0]      # every rank must take the same decision: the slowest rank's clock decides
+        enough = len(walls) >= MIN_REPETITIONS and total >= MIN_TIMED_SECONDS
+        if enough and fractional:                    # the regions that carry the exchange must have been sampled
+            enough = sum(1 for q in posts if q > int(per_region)) >= 3
+        if len(walls) >= MAX_REPETITIONS or enough:
             break
-    if dist is not None:          # max over ranks, region by region
-        t = torch.tensor(walls, dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        walls = t.tolist()
-    elapsed = float(np.median(walls))
+    walls = max_over_ranks(walls)                    # max over ranks, region by region
+    elapsed, share = effective_region(walls, posts, args.steps, exchange is not None)
     launch_ms = kernel_probe_ms(plan, min(len(walls), 50))     # one rollout launch of the region's kind
+
+    flop_step = FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV
+
+    def long_launches(sh, ex, n_envs, launches, label):
+        """`launches` x 500-step launches back to back, one region (clocks warm) -> dict"""
+        ss_plan = [EPISODE] * launches
+        run(ss_plan, sh, ex)                         # untimed: the clocks reach their steady state
+        ss_wall, _ = timed_region(ss_plan, sh, ex)
+        ss_kernel_ms = kernel_probe_ms(ss_plan, 3, sh, ex) * len(ss_plan)
+        ss_wall = max_over_ranks([ss_wall])[0]
+        ss_steps = sum(ss_plan)
+        ss_flops = flop_step * n_envs * ss_steps / (ss_kernel_ms * 1e-3) / 1e12
+        return {"launches": len(ss_plan), "steps_per_launch": EPISODE, "envs_per_gpu": n_envs,
+                "env_steps_per_s": round(n_envs * world * ss_steps / ss_wall, 1),
+                "us_per_step_wall": round(ss_wall / ss_steps * 1e6, 4),
+                "us_per_step_kernel": round(ss_kernel_ms / ss_steps * 1e3, 4),
+                "avg_launch_ms": round(ss_kernel_ms / len(ss_plan), 4),
+                "kernel": fused_kernel_name(args.precision, n_envs, EPISODE),
+                "achieved_TFLOPs": round(ss_flops, 3), "peak_TFLOPs": PEAK_FP32_TFLOPS,
+                "frac": round(ss_flops / PEAK_FP32_TFLOPS, 4), "exchanges": launches if ex is not None else 0,
+                "note": label}
 
     # ---- steady state: 10 x 500-step launches back to back (clocks are warm now), one region ----
     steady = None
     if args.mode == "fused":
-        ss_plan = [EPISODE] * 10
-        run(ss_plan)                              # untimed: 17 ms of load, the clocks reach their steady state
-        ss_wall = timed_region(ss_plan)
-        ss_kernel_ms = kernel_probe_ms(ss_plan, 3) * len(ss_plan)
-        if dist is not None:
-            t = torch.tensor([ss_wall], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ss_wall = float(t.item())
-        ss_steps = sum(ss_plan)
-        ss_flops = (FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV) * n * ss_steps / (ss_kernel_ms * 1e-3) / 1e12
-        steady = {"launches": len(ss_plan), "steps_per_launch": EPISODE,
-                  "env_steps_per_s": round(n_total * ss_steps / ss_wall, 1),
-                  "us_per_step_wall": round(ss_wall / ss_steps * 1e6, 4),
-                  "us_per_step_kernel": round(ss_kernel_ms / ss_steps * 1e3, 4),
-                  "avg_launch_ms": round(ss_kernel_ms / len(ss_plan), 4),
-                  "kernel": fused_kernel_name(args.precision, n, EPISODE),
-                  "achieved_TFLOPs": round(ss_flops, 3), "peak_TFLOPs": PEAK_FP32_TFLOPS,
-                  "frac": round(ss_flops / PEAK_FP32_TFLOPS, 4),
-                  "note": "same process, after the timed regions and 10 untimed launches of the same kind; wall = barrier + synchronize on both sides, "
-                          "max over ranks; kernel = the kernel's own begin/end timestamps, last launch of such a region, on rank 0"}
+        steady = long_launches(shard, exchange, n, 10,
+                               "same process, after the timed regions and 10 untimed launches of the same kind; wall = barrier + "
+                               "synchronize on both sides, max over ranks, one all-gather per launch when there is more than one "
+                               "rank; kernel = the kernel's own begin/end timestamps, last launch of such a region, on rank 0")
+
+    # the last all-gathered returns (numpy [world * n]); one rank: the env's own
+    gathered = exchange.result() if exchange is not None else None
+    if gathered is None:
+        gathered = engine.local_returns(shard)
+    gathered_count = int(np.prod(np.shape(gathered)))
+
+    # ---- BASELINE config 3 / 4: 262 144 envs per GPU (2 097 152 on 8 GPUs), one all-gather per 500-step launch ----
+    config4 = None
+    if args.mode == "fused" and not args.no_config4:
+        n4 = 262144
+        shard4 = engine.make_shard(n4, rank * n4)
+        ex4 = exchange
+        if isinstance(exchange, _TorchExchange) or (exchange is not None and not hasattr(exchange, "ex")):
+            ex4 = engine.torch_exchange(n4, n4 * world, why)     # torch-side buffers are sized per shard
+        since_exchange[0] = 0
+        config4 = long_launches(shard4, ex4, n4, 4,
+                                "BASELINE config 3 (one GPU) / config 4 (262 144 envs on each of N GPUs, all-gather of returns per "
+                                "episode): 4 x 500-step launches in one region after 4 untimed ones, same process")
+        config4["total_envs"] = n4 * world
+        del shard4
 
     value = n_total * args.steps / elapsed
     result = {
@@ -546,97 +757,122 @@ def main():
                                f"(RAPTOR checkpoint), domain-randomised params, auto-reset, {args.mode} rollout",
                    "envs_per_gpu": n, "total_envs": n_total, "episode_length": EPISODE,
                    "parallelism": f"env-sharded x{world}, all-gather of returns per episode" if world > 1
-                                  else "single GPU", "mode": args.mode,
-                   "device": torch.cuda.get_device_name(local_rank), "hip_runtime": torch.version.hip},
-        "timing": {"repetitions": len(walls), "steps_per_region": args.steps, "statistic": "median",
+                                  else "single GPU", "mode": args.mode, "engine": engine.name, **engine.describe()},
+        "timing": {"repetitions": len(walls), "steps_per_region": args.steps,
+                   "statistic": "median region without an exchange + steps/500 of the difference to the median region with one"
+                                if exchange is not None else "median",
                    "region_ms": {"first": round(walls[0] * 1e3, 4), "min": round(min(walls) * 1e3, 4),
-                                 "median": round(elapsed * 1e3, 4), "mean": round(float(np.mean(walls)) * 1e3, 4),
-                                 "max": round(max(walls) * 1e3, 4)},
+                                 "median": round(float(np.median(walls)) * 1e3, 4),
+                                 "mean": round(float(np.mean(walls)) * 1e3, 4),
+                                 "max": round(max(walls) * 1e3, 4), "charged": round(elapsed * 1e3, 4)},
+                   "exchange_share": share,
                    "untimed_steps_before_first_region": args.warmup + 1},
     }
     if steady is not None:
         result["steady_state"] = steady
+    if config4 is not None:
+        result["config4"] = config4
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        launches = len(plan) if args.mode == "fused" else 3 * args.steps
-        avg_launch_s = launch_ms * 1e-3                  # one rollout launch (median over the timed regions)
-        if args.mode == "fused" and args.precision in ("bf16", "f16x2"):
-            # config 5: the contractions run on the bf16 XDL pipe (24 MFMAs per wave-step, a few % of its
-            # peak); what bounds the kernel is the fp32 VALU work that remains (gates + env)
-            steps_per_launch = args.steps / len(plan)
-            valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
-            mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
-            kname = fused_kernel_name(args.precision, n, steps_per_launch)
-            tr = pmc_traffic(kname, n)
-            result["roofline"] = {
-                "kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
-                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
-                "traffic": None if tr is None else tr["bytes_per_launch"],
-                "traffic_source": tr,
-                "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
-                        f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the 16-bit MFMA pipe at "
-                        f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak"
-                        + (" (x3 issued: hi.hi, hi.lo, lo.hi products)" if args.precision == "f16x2" else ""),
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                "steps_per_launch": steps_per_launch,
-                "sq_counters": sq_profile("bf16") if args.precision == "bf16" else None}
-        elif args.mode == "fused":
-            steps_per_launch = args.steps / len(plan)
-            flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
-            achieved = flop_per_launch / avg_launch_s / 1e12
-            kname = fused_kernel_name("fp32", n, steps_per_launch)
-            tr = pmc_traffic(kname, n)
-            result["roofline"] = {
-                "kernel": kname, "bound": "mfma", "achieved": round(achieved, 3),
-                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": None if tr is None else tr["bytes_per_launch"],
-                "traffic_source": tr,
-                "note": "compute-bound: state, hidden and constants stay in VGPRs for the whole launch; "
-                        f"algorithmic {FLOP_PER_ENV_STEP} FLOP/env-step (actor {FLOP_ACTOR} + gates {FLOP_GATES} + "
-                        f"env {FLOP_ENV}) against the fp32 vector = f32-MFMA dense peak; algorithmic HBM bytes are "
-                        f"{BYTES_FUSED_LAUNCH} B/env per launch of {int(steps_per_launch)} steps; the measured `traffic` adds "
-                        "the operand image every wave loads and the loop-invariant registers parked in scratch before "
-                        "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own begin/end "
-                        "timestamps, median over up to 50 further regions run with kernel-level timing on (the timed "
-                        "regions run without it: it costs ~8 us of dispatch per launch); short launches carry the "
-                        "kernel's prologue and epilogue (see steady_state for 500-step launches)",
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                "steps_per_launch": steps_per_launch,
-                "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
-                "sq_counters": sq_profile("fp32")}
-        else:
-            bytes_per_step = (BYTES_OBSERVE + BYTES_ACTOR + BYTES_STEP) * n
-            achieved = bytes_per_step / (launch_ms * 1e-3) / 1e9       # one step = three launches
-            result["roofline"] = {
-                "kernel": "k_observe+k_actor_step+k_step (chain)", "bound": "hbm", "achieved": round(achieved, 1),
-                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                "traffic": None, "launches": launches,
-                "note": f"algorithmic {BYTES_OBSERVE}+{BYTES_ACTOR}+{BYTES_STEP} B/env-step"}
-        if world == 1 and not args.no_kernel_probe:
-            result["kernels"] = {"n65536": kernel_probe(device, ENVS_PER_GPU, 200),
-                                 "n2097152": kernel_probe(device, 2097152, 20)}
-            result["extensions_n65536"] = extension_probe(device, ENVS_PER_GPU)
-            result["readme_loop_n8"] = api_loop_probe(device)
-            result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        result["config"]["exchanges_per_timed_region"] = round(args.steps / EPISODE, 4) if exchange is not None else 0
-        # numpy (native) or tensor (torch): the last all-gathered returns; one rank: the env's own
-        gathered = exchange.finish() if exchange is not None else None
-        if gathered is None:
-            gathered = shard.env.finished_returns()
-        result["config"]["gathered_returns"] = int(np.prod(gathered.shape))
-        result["config"]["exchange"] = exchange_kind
-        # RCCL / the HIP runtime print banners through C stdio, which a redirected stdout only flushes at exit:
-        # push them out now so that the JSON line is the LAST line of stdout
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(result), flush=True)
+    launches = len(plan) if args.mode == "fused" else 3 * args.steps
+    avg_launch_s = launch_ms * 1e-3                  # one rollout launch (median over the timed regions)
+    if args.mode == "fused" and args.precision in ("bf16", "f16x2"):
+        # config 5: the contractions run on the bf16 XDL pipe (24 MFMAs per wave-step, a few % of its
+        # peak); what bounds the kernel is the fp32 VALU work that remains (gates + env)
+        steps_per_launch = args.steps / len(plan)
+        valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
+        mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
+        kname = fused_kernel_name(args.precision, n, steps_per_launch)
+        tr = pmc_traffic(kname, n)
+        result["roofline"] = {
+            "kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
+            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
+            "traffic": None if tr is None else tr["bytes_per_launch"],
+            "traffic_source": tr,
+            "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
+                    f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the 16-bit MFMA pipe at "
+                    f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak"
+                    + (" (x3 issued: hi.hi, hi.lo, lo.hi products)" if args.precision == "f16x2" else ""),
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
+            "steps_per_launch": steps_per_launch,
+            "sq_counters": sq_profile("bf16") if args.precision == "bf16" else None}
+    elif args.mode == "fused":
+        steps_per_launch = args.steps / len(plan)
+        flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
+        achieved = flop_per_launch / avg_launch_s / 1e12
+        kname = fused_kernel_name("fp32", n, steps_per_launch)
+        tr = pmc_traffic(kname, n)
+        result["roofline"] = {
+            "kernel": kname, "bound": "mfma", "achieved": round(achieved, 3),
+            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+            "traffic": None if tr is None else tr["bytes_per_launch"],
+            "traffic_source": tr,
+            "note": "compute-bound: state, hidden and constants stay in VGPRs for the whole launch; "
+                    f"algorithmic {FLOP_PER_ENV_STEP} FLOP/env-step (actor {FLOP_ACTOR} + gates {FLOP_GATES} + "
+                    f"env {FLOP_ENV}) against the fp32 vector = f32-MFMA dense peak; algorithmic HBM bytes are "
+                    f"{BYTES_FUSED_LAUNCH} B/env per launch of {int(steps_per_launch)} steps; the measured `traffic` adds "
+                    "the operand image every wave loads and the loop-invariant registers parked in scratch before "
+                    "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own begin/end "
+                    "timestamps, median over up to 50 further regions run with kernel-level timing on (the timed "
+                    "regions run without it: it costs ~8 us of dispatch per launch); short launches carry the "
+                    "kernel's prologue and epilogue (see steady_state for 500-step launches); the north-star's "
+                    "'>= 60 % of the HBM roofline on the step kernel' is kernels.n2097152.k_step (HBM-bound there; at "
+                    "65 536 envs the API-granular kernels are launch-latency-bound on Infinity-Cache-resident data)",
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
+            "steps_per_launch": steps_per_launch,
+            "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
+            "sq_counters": sq_profile("fp32")}
+    else:
+        bytes_per_step = (BYTES_OBSERVE + BYTES_ACTOR + BYTES_STEP) * n
+        achieved = bytes_per_step / (launch_ms * 1e-3) / 1e9       # one step = three launches
+        result["roofline"] = {
+            "kernel": "k_observe+k_actor_step+k_step (chain)", "bound": "hbm", "achieved": round(achieved, 1),
+            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
+            "traffic": None, "launches": launches,
+            "note": f"algorithmic {BYTES_OBSERVE}+{BYTES_ACTOR}+{BYTES_STEP} B/env-step"}
+    if world == 1 and not args.no_kernel_probe and engine.name == "hip":
+        device = engine.device
+        result["kernels"] = {"n65536": kernel_probe(device, ENVS_PER_GPU, 50),
+                             "n2097152": kernel_probe(device, 2097152, 5)}
+        result["extensions_n65536"] = extension_probe(device, ENVS_PER_GPU)
+        result["extensions_n65536"]["teacher_bank"] = teacher_probe(device, ENVS_PER_GPU)
+        result["readme_loop_n8"] = api_loop_probe(device)
+        result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    result["config"]["exchanges_per_timed_region"] = round(args.steps / EPISODE, 4) if exchange is not None else 0
+    result["config"]["gathered_returns"] = gathered_count
+    result["config"]["exchange"] = exchange_kind
+    return result
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    engine = make_engine(args.engine, local_rank, args)
+    dist = None
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        engine.init_process_group(dist, args.backend or engine.default_backend)
+    try:
+        result = run_benchmark(args, engine, rank, local_rank, world, dist)
+        if rank == 0:
+            # RCCL / the HIP runtime print banners through C stdio, which a redirected stdout only flushes at exit:
+            # push them out now so that the JSON line is the LAST line of stdout
+            import ctypes
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(result), flush=True)
+    finally:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

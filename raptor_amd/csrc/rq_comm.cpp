@@ -122,6 +122,7 @@ RQ_API int rq_comm_create(rq_device* dev, uint32_t n_ranks, uint32_t rank, const
     RQ_REQUIRE(dev && id && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     RQ_REQUIRE(n_ranks >= 1 && rank < n_ranks, RQ_ERR_INVALID_ARGUMENT, "rank must be in [0, n_ranks)");
+    RQ_REQUIRE(n_ranks <= 0x7FFFFFFFu, RQ_ERR_INVALID_ARGUMENT, "n_ranks exceeds what RCCL's int arguments hold");
     RQ_REQUIRE(bytes >= RQ_COMM_ID_BYTES, RQ_ERR_INVALID_ARGUMENT, "the id must be RQ_COMM_ID_BYTES (128) bytes");
     Rccl* r = rccl();
     RQ_REQUIRE(r->lib, RQ_ERR_NO_DEVICE, r->error);
@@ -135,6 +136,10 @@ RQ_API int rq_comm_create(rq_device* dev, uint32_t n_ranks, uint32_t rank, const
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[j], hipEventDisableTiming);
     }
     if (e != hipSuccess) { rq_comm_destroy(c); return rq::fail(RQ_ERR_HIP, "rq_comm_create: stream/event creation failed"); }
+    // Everything that can fail locally (RCCL binding, device, host allocation, stream, events) has happened above:
+    // ncclCommInitRank is a COLLECTIVE - a rank that returned early would leave its peers waiting inside it.  A host
+    // should therefore agree that every rank can get this far before any rank calls rq_comm_create (bench.py: phase 1
+    // of its consensus, rq_comm_unique_id on every rank); what remains is a failure inside RCCL's own bootstrap.
     NcclId nid;
     std::memcpy(nid.bytes, id, RQ_COMM_ID_BYTES);
     const int nrc = r->comm_init_rank(&c->comm, (int)n_ranks, nid, (int)rank);      // collective over all ranks

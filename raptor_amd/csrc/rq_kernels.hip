@@ -19,6 +19,8 @@
 // Below 1024 envs k_observe / k_actor_step / k_step exchange host rows through a pinned mailbox (Mailbox).
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "rq_device_math.hpp"
 
 namespace rq {
@@ -459,6 +461,10 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     // wave-uniform: no env of this wave distinguishes rotor spin-up from spin-down (see dynamics<SYM_TAU>)
     const bool sym_tau = __builtin_amdgcn_ballot_w64(k.itr != k.itf) == 0;
 
+    // The loop exists twice, once per dynamics variant (round 3): with the wave-uniform choice inside the loop the two
+    // variants met in a join that cost the state's registers a copy per step (~8 moves) plus the branch itself.
+    auto rollout_loop = [&](auto sym_choice) {
+    constexpr bool SYM = decltype(sym_choice)::value;
     for (uint32_t t = 0; t < n_steps; ++t) {
         const uint64_t live = AUTORESET ? ~0ull : __builtin_amdgcn_ballot_w64(!frozen);
         if (!AUTORESET && live == 0) break;   // wave-uniform exit: every env of the wave is frozen
@@ -510,8 +516,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         QuadState yn = y;
         f32x2 A01, A23;
         bool term;
-        const float r = sym_tau ? step_inplace<true>(c, k, ds, yn, a, A01, A23, term)
-                                : step_inplace<false>(c, k, ds, yn, a, A01, A23, term);
+        const float r = step_inplace<SYM>(c, k, ds, yn, a, A01, A23, term);
         bool ended = false;
         uint8_t done_code = 4;          // frozen: computed on a scratch copy, not committed
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
@@ -546,6 +551,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             }
         }
     }
+    };
+    if (sym_tau) rollout_loop(std::true_type{});
+    else         rollout_loop(std::false_type{});
 
     const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
     if (valid && commit) {

@@ -272,7 +272,7 @@ class VectorModule:
                     want = {np.float32: torch.float32, np.uint32: torch.int32, np.uint8: torch.uint8}[dtype]
                     if (not out.is_cuda or out.device.index != self._device.ordinal or not out.is_contiguous() or
                             out.numel() != mod.N_ENVIRONMENTS or (out.dtype != want and not
-                                                                 (dtype is np.uint32 and out.dtype == torch.uint32))):
+                                                                 (dtype is np.uint32 and out.dtype == getattr(torch, "uint32", None)))):
                         raise ValueError(f"out must be a contiguous {want} tensor of {mod.N_ENVIRONMENTS} elements on "
                                          f"cuda:{self._device.ordinal}")
                     _lib.call(fn, h, C.c_void_p(out.data_ptr()), 1 if wait else 2)

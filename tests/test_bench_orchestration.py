@@ -1,0 +1,118 @@
+"""bench.py's own N > 1 orchestration on CPU: two gloo ranks through bench.run_benchmark with the stand-in engine
+(tests/bench_stub_engine.py) instead of the GPU library.  What an 8-GPU node would otherwise meet for the first
+time: the rendezvous, the two-phase consensus on the native communicator (also when one rank fails phase 1 or
+phase 2: no deadlock, the torch-side exchange is taken on EVERY rank and reported), the per-episode exchange across
+short regions and its share in `value`, the max over ranks, and exactly one JSON line on rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra_env=None, args=("--steps", "20", "--warmup", "5"), timeout=240):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.update(extra_env or {})
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--engine", "tests.bench_stub_engine",
+               "--backend", "gloo", "--no-cpu-baseline", "--envs-per-gpu", "64", *args]
+        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("bench.py deadlocked (a rank was left waiting in a collective)")
+        assert p.returncode == 0, err[-2000:]
+        outs.append(out)
+    return outs
+
+
+def _json_line(out):
+    lines = [l for l in out.strip().split("\n") if l.strip()]
+    records = [l for l in lines if l.lstrip().startswith("{")]         # gloo prints a connection banner on stdout
+    assert len(records) == 1 and lines[-1] == records[0], lines         # ONE JSON line, and it is the last line
+    return json.loads(records[0])
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_native_exchange_one_json_line():
+    outs = _run(2)
+    d = _json_line(outs[0])
+    assert "{" not in outs[1]                                      # only rank 0 prints a record
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["total_envs"] == 128 and d["config"]["envs_per_gpu"] == 64
+    assert d["config"]["exchange"].startswith("native RCCL")
+    assert d["config"]["gathered_returns"] == 128                   # every rank's shard arrived
+    assert d["value"] > 0 and d["higher_is_better"] is True and d["unit"] == "env-steps/s"
+    # 20-step regions: one exchange in 25 regions; the regions that carry it were sampled and charged for
+    share = d["timing"]["exchange_share"]
+    assert share["exchanges_per_region"] == pytest.approx(0.04)
+    assert share["regions_with_extra_exchange"] >= 3
+    assert d["timing"]["region_ms"]["charged"] >= d["timing"]["region_ms"]["min"]
+    assert d["config4"]["total_envs"] == 2 * 262144 and d["config4"]["exchanges"] == 4
+    assert d["steady_state"]["exchanges"] == 10
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("phase,rank", [("RQ_STUB_FAIL_PHASE1", 1), ("RQ_STUB_FAIL_PHASE1", 0), ("RQ_STUB_FAIL_PHASE2", 1),
+                                         ("RQ_STUB_FAIL_PHASE2", 0)])
+def test_consensus_falls_back_on_every_rank_without_deadlock(phase, rank):
+    outs = _run(2, {phase: str(rank)}, args=("--steps", "500", "--warmup", "500", "--no-config4"))
+    d = _json_line(outs[0])
+    assert d["config"]["exchange"].startswith("torch.distributed all_gather_into_tensor")
+    assert f"rank {rank}" in d["config"]["exchange"]               # the reason names the rank that failed
+    assert d["config"]["gathered_returns"] == 128
+    assert d["timing"]["exchange_share"]["exchanges_per_region"] == 1.0
+
+
+@pytest.mark.timeout(300)
+def test_single_process_has_nothing_to_gather():
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "tests.bench_stub_engine", "--no-cpu-baseline",
+                          "--envs-per-gpu", "64", "--steps", "20", "--warmup", "5", "--no-config4"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _json_line(out.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["exchange"].startswith("none") and d["config"]["gathered_returns"] == 64
+    assert d["timing"]["statistic"] == "median"
+
+
+def test_effective_region_charges_the_exchange_share():
+    import bench
+    walls = [1.0] * 24 + [3.0] + [1.0] * 24 + [3.0] + [1.0] * 24 + [3.0]
+    posts = [0] * 24 + [1] + [0] * 24 + [1] + [0] * 24 + [1]
+    t, detail = bench.effective_region(walls, posts, 20, True)
+    assert t == pytest.approx(1.0 + 0.04 * 2.0) and detail["regions_with_extra_exchange"] == 3
+    t, _ = bench.effective_region([2.0, 2.5, 3.0], [1, 1, 1], 500, True)          # whole episodes: plain median
+    assert t == pytest.approx(2.5)
+    t, _ = bench.effective_region([2.0, 2.5, 3.0], [0, 0, 0], 20, False)         # one rank: nothing to charge
+    assert t == pytest.approx(2.5)
+    t, detail = bench.effective_region([1.0, 1.0], [0, 0], 20, True)             # exchange regions never sampled
+    assert t == pytest.approx(1.0) and "note" in detail
+
+
+def test_launch_grid_matches_the_launchers():
+    import bench
+    assert bench.launch_grid("rq::k_actor_step<rq::ActorF32T<true> >", 2097152) == 262144     # 8 groups per wave
+    assert bench.launch_grid("rq::k_actor_step<rq::ActorF32T<true> >", 65536) == 65536
+    assert bench.launch_grid("rq::k_step<false>", 65536) == 65536
+    assert bench.launch_grid("rq::k_rollout_fused<false, true, false, false, rq::ActorF32T<false> >", 1000) == 1024

@@ -1413,6 +1413,117 @@ def test_native_rccl_exchange_across_gpus():
     assert np.array_equal(res[0][2], full) and np.array_equal(res[1][2], full)
 
 
+def _shared_gpu_exchange_worker(rank, world, n, episodes, fake_lib, conn):
+    """One rank of test_native_exchange_two_ranks_on_one_gpu: a process of its own on GPU 0, RCCL = the tests-only
+    fake (tests/fake_rccl.cpp, shared memory between the processes), selected before the library binds RCCL."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["RQ_RCCL_LIBRARY"] = fake_lib
+    try:
+        import raptor_amd.l2f as l2f
+        from raptor_amd.distributed import NativeReturnsExchange
+        from raptor_amd.foundation_policy import Raptor
+        dev = l2f.Device(0)
+        v = l2f.VectorModule(n, rank * n)
+        rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+        v.initialize_rng(dev, rng, 9)
+        v.initialize_environment(dev, env)
+        cfg = env.config
+        cfg.episode_step_limit = 30
+        env.config = cfg
+        v.sample_initial_parameters(dev, env, params, rng)
+        v.sample_initial_state(dev, env, params, state, rng)
+        pol = Raptor(dev)
+        if rank == 0:
+            ident = NativeReturnsExchange.unique_id()
+            conn.send(("id", ident))
+        ident = conn.recv()                                   # the parent relays rank 0's id to every rank
+        ex = NativeReturnsExchange(dev, world, rank, ident)
+        assert ex.info() == (world, rank)
+        snaps = []
+        for k in range(episodes):
+            # no host synchronisation between posts: the copy of episode k's returns sits on the engine's stream behind
+            # rollout k, the collective on the side stream; episode k + 1 is enqueued right behind
+            v.rollout(dev, env, params, state, pol, rng, 30, "fused", True)
+            ex.post(env)
+            if k in (1, episodes - 1):                        # read back twice: after the buffers were recycled, too
+                dev.synchronize()
+                snaps.append((k, env.finished_returns().copy(), ex.finish()))
+        conn.send(("done", snaps))
+    except Exception as exc:      # noqa: BLE001
+        import traceback
+        conn.send(("error", f"rank {rank}: {exc}\n{traceback.format_exc()}"))
+
+
+@pytest.mark.timeout(600)
+def test_native_exchange_two_ranks_on_one_gpu(device, tmp_path):
+    """rq_comm_create / rq_allgather_returns / rq_comm_gathered with n_ranks = 2 (round 3): two processes share the one
+    GPU of this box and bind a tests-only RCCL (tests/fake_rccl.cpp: all-gather = device->host copy, a host function
+    in the stream that meets the other rank in shared memory, host->device copy - enqueued on the stream the product
+    hands it, completing in stream order like the real one).  Exercised with two ranks for the first time: the
+    communicator creation as a collective, the double-buffered send / receive pairs across seven posts, the event
+    ordering between the engine's stream and the side stream, and the GLOBAL env order of the result - which must
+    equal the finished returns of the same 2 n envs rolled out unsharded (RNG keyed by global id)."""
+    import shutil
+    import subprocess
+    import multiprocessing as mp
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                 "fake_rccl.cpp"), "-o", fake, "-lrt"],
+                   check=True, capture_output=True)
+    n, world, episodes = 4096, 2, 7
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(world)]
+    procs = [ctx.Process(target=_shared_gpu_exchange_worker, args=(r, world, n, episodes, fake, pipes[r][1])) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    try:
+        assert pipes[0][0].poll(240), "rank 0 produced no communicator id"
+        kind, ident = pipes[0][0].recv()
+        assert kind == "id", ident
+        assert ident.startswith(b"/rqfake_"), "the product bound another RCCL than the one RQ_RCCL_LIBRARY names"
+        for r in range(world):
+            pipes[r][0].send(ident)
+        res = []
+        for r in range(world):
+            assert pipes[r][0].poll(300), f"rank {r} hung (a rank left waiting in the collective)"
+            kind, payload = pipes[r][0].recv()
+            assert kind == "done", payload
+            res.append(payload)
+    finally:
+        for pr in procs:
+            pr.join(30)
+            if pr.is_alive():
+                pr.kill()
+    # the unsharded batch on this process's own device: same seed, same config, global ids 0 .. 2n - 1
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+    v = l2f.VectorModule(world * n, 0)
+    rng, env, params, state = v.VectorRng(), v.VectorEnvironment(), v.VectorParameters(), v.VectorState()
+    v.initialize_rng(device, rng, 9)
+    v.initialize_environment(device, env)
+    cfg = env.config
+    cfg.episode_step_limit = 30
+    env.config = cfg
+    v.sample_initial_parameters(device, env, params, rng)
+    v.sample_initial_state(device, env, params, state, rng)
+    pol = Raptor(device)
+    whole = {}
+    for k in range(episodes):
+        v.rollout(device, env, params, state, pol, rng, 30, "fused", True)
+        if k in (1, episodes - 1):
+            whole[k] = env.finished_returns().copy()
+    for i in range(2):
+        k = res[0][i][0]
+        local = np.concatenate([res[r][i][1] for r in range(world)])
+        for r in range(world):
+            got = res[r][i][2]
+            assert got.shape == (world * n,)
+            assert np.array_equal(got, local), f"rank {r}, episode {k}: gathered != concatenation of the ranks' returns"
+        assert np.array_equal(local, whole[k]), f"episode {k}: sharded returns differ from the unsharded batch"
+
+
 # ------------------------------------------------------------------------------ teacher bank -
 def _teacher_weights(rng, n_teachers, in_dim, h1, h2):
     from raptor_amd.teachers import parameter_count
