@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raptor_amd.l2f as l2f                       # noqa: E402
 from raptor_amd.foundation_policy import Raptor, load_weights   # noqa: E402
-from raptor_amd.teachers import TeacherBank, parameter_count    # noqa: E402
+from raptor_amd.teachers import TeacherBank, balanced_teacher_assignment, parameter_count    # noqa: E402
 
 
 def main():
@@ -49,12 +49,13 @@ def main():
     device.synchronize()
     t2 = time.perf_counter()
 
-    # the distillation step proper (README.md:208-216): every quadrotor has ITS teacher, an MLP; here 64 random
-    # 22-64-64-4 teachers stand in for the trained ones and env i is labelled by teacher i % 64 - one launch
+    # the distillation step proper (README.md:208-216): every quadrotor has ITS teacher, an MLP; here random
+    # 22-64-64-4 teachers stand in for the trained ones - one launch.  balanced_teacher_assignment deals whole 16-env
+    # tiles to the teachers (contiguous groups), so no matrix work is spent on padding whatever the teacher count
     n_teachers = 64
     bank = TeacherBank(device, (np.random.default_rng(1).standard_normal((n_teachers, parameter_count(22, 64, 64))) * 0.1)
                        .astype(np.float32), 22, 64, 64, "relu", "tanh")
-    traj.relabel_teachers(bank, np.arange(env.N_ENVIRONMENTS) % n_teachers, overwrite=True, fetch=False)
+    traj.relabel_teachers(bank, balanced_teacher_assignment(env.N_ENVIRONMENTS, n_teachers), overwrite=True, fetch=False)
     device.synchronize()
     t3 = time.perf_counter()
 

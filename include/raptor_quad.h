@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define RQ_ABI_VERSION 1
+#define RQ_ABI_VERSION 2   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m and the entry points added in round 2 */
 
 #if defined(__GNUC__)
 #define RQ_API __attribute__((visibility("default")))
@@ -105,7 +105,7 @@ enum rq_state_field {
     RQ_S_VEL = 7,        /* 3: linear velocity, world frame [m/s]                                */
     RQ_S_OMEGA = 10,     /* 3: angular velocity, body frame [rad/s]                              */
     RQ_S_RPM = 13,       /* 4: rotor speeds                                                      */
-    RQ_S_LAST_ACTION = 17, /* 4: previous (clipped) action = ActionHistory(1)                    */
+    RQ_S_LAST_ACTION = 17, /* 4: previous action = ActionHistory(1): clipped, or raw (action_history_raw) */
     RQ_S_FORCE = 21,     /* 3: per-episode disturbance force, world frame [N]                    */
     RQ_S_TORQUE = 24,    /* 3: per-episode disturbance torque, body frame [N m]                  */
     RQ_STATE_DIM = 27
@@ -156,6 +156,11 @@ typedef struct rq_env_config {
      * or any non-finite state */
     uint32_t termination_enabled;
     float termination_position, termination_linear_velocity, termination_angular_velocity;
+    /* ActionHistory(1) of the observation (h5:/actor@meta): 0 = the action as the rotors received it, clipped to
+     * [-1, 1] (default); 1 = the policy's raw output.  Which one l2f stores is not in the reference tree
+     * [UPSTREAM-UNVERIFIED]; the shipped actor's output is unbounded (checkpoint.h:210 reaches +-3), so the two
+     * differ on saturated steps (measured effect on the closed-loop statistics: DESIGN.md section 2). */
+    uint32_t action_history_raw;
 } rq_env_config;
 
 typedef struct rq_device rq_device;   /* l2f.Device                                             */
@@ -282,7 +287,9 @@ typedef enum rq_policy_precision {
                                  v_mfma_f32_16x16x32_f16, exact products, fp32 accumulate and gates: known-answer error
                                  ~1e-6 like fp32, on the matrix pipe that overlaps with the vector ALU.  Not fp32
                                  arithmetic: RQ_POLICY_FP32 stays the default and the benchmarked configuration.
-                                 Range: an input or activation beyond the f16 range (|x| >= 65520) becomes infinite */
+                                 Range (round 3): observations and layer_0's output are SATURATED at the largest f16,
+                                 +-65 504 (a NaN input reads as -65 504), before they are split - an input beyond that is a
+                                 bounded error (the gates saturate), never an infinity or NaN in the GRU state */
 } rq_policy_precision;
 
 /* weights: RQ_POLICY_NUM_WEIGHTS float32 in the order documented at RQ_POLICY_NUM_WEIGHTS

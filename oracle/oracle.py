@@ -42,6 +42,7 @@ class EnvConfig(C.Structure):
         ("termination_enabled", C.c_uint32),
         ("termination_position", C.c_float), ("termination_linear_velocity", C.c_float),
         ("termination_angular_velocity", C.c_float),
+        ("action_history_raw", C.c_uint32),
     ]
 
     def __setattr__(self, name, value):       # a misspelt field must not silently configure nothing

@@ -116,6 +116,7 @@ ORC_EXPORT void orc_default_config(rq_env_config* c) {
     c->termination_position = 1.0f;      /* see rq_env_default_config (raptor_amd/csrc/rq_capi.cpp): the reference's own log */
     c->termination_linear_velocity = 1000.0f;
     c->termination_angular_velocity = 1000.0f;
+    c->action_history_raw = 0;
 }
 
 /* ---------------------------------------------------------------- actor ---------------- */
@@ -476,7 +477,7 @@ static void step_one(const rq_env_config* c, const float* p, const float* s, con
     float f6[6];
     for (int i = 0; i < 6; ++i) f6[i] = s[RQ_S_FORCE + i];
     for (int i = 0; i < 17; ++i) ns[i] = y[i];
-    for (int i = 0; i < 4; ++i) ns[RQ_S_LAST_ACTION + i] = ac[i];
+    for (int i = 0; i < 4; ++i) ns[RQ_S_LAST_ACTION + i] = c->action_history_raw ? a[i] : ac[i];   /* ActionHistory(1) */
     for (int i = 0; i < 6; ++i) ns[RQ_S_FORCE + i] = f6[i];
 
     /* termination + reward of the transition (evaluated on next state and clipped action) */

@@ -55,6 +55,7 @@ class EnvConfig(C.Structure):
         ("termination_enabled", C.c_uint32),
         ("termination_position", C.c_float), ("termination_linear_velocity", C.c_float),
         ("termination_angular_velocity", C.c_float),
+        ("action_history_raw", C.c_uint32),
     ]
 
     def __setattr__(self, name, value):
@@ -217,7 +218,7 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
-        if lib.rq_abi_version() != 1:
+        if lib.rq_abi_version() != 2:
             raise RaptorQuadError(-1, "ABI version mismatch between raptor_amd and libraptor_quad.so")
         _lib = lib
     return _lib

@@ -589,6 +589,7 @@ RQ_API int rq_env_default_config(rq_env_config* c) {
     c->termination_position = 1.0f;
     c->termination_linear_velocity = 1000.0f;
     c->termination_angular_velocity = 1000.0f;
+    c->action_history_raw = 0;             // [UPSTREAM-UNVERIFIED] which one l2f's ActionHistory holds; see raptor_quad.h
     return RQ_OK;
 }
 

@@ -1128,6 +1128,13 @@ struct ActorF16X2 {
         const f32x2 r = {r0, r1};
         lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
     }
+    // The same for values that are not bounded by construction (observations, layer_0's output): f16 overflows to
+    // infinity at 65 520 and the residual v - inf would poison the GRU state with NaN (the fp32 and bf16 builds stay
+    // finite there).  Saturating split: the value is clamped to the largest f16 first (one v_med3_f32 each; a NaN
+    // input becomes -65 504), so a diverging env degrades to a bounded error.  The hidden state needs none: |h| <= 1.
+    static __device__ __forceinline__ void split2_sat(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+        split2(clampf(v0, -65504.0f, 65504.0f), clampf(v1, -65504.0f, 65504.0f), hi, lo);
+    }
     static __device__ __forceinline__ f16x8 tuple(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
         const dwordx4 u = {d0, d1, d2, d3};
         return __builtin_bit_cast(f16x8, u);
@@ -1158,7 +1165,7 @@ struct ActorF16X2 {
                 const float v0 = o[f0 < 22 ? f0 : 21];
                 const float v1 = f1 < 22 ? o[f1 < 22 ? f1 : 21] : (f1 == 22 ? 1.0f : 0.0f);
                 uint32_t hi, lo;
-                split2(v0, v1, hi, lo);
+                split2_sat(v0, v1, hi, lo);
                 PH[d][c] = __builtin_bit_cast(float, hi);
                 PL[d][c] = __builtin_bit_cast(float, lo);
             }
@@ -1190,8 +1197,9 @@ struct ActorF16X2 {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f32x4 y0 = H[t];
-                split2(relu(y0[0]), relu(y0[1]), yh[t][0], yl[t][0]);
-                split2(relu(y0[2]), relu(y0[3]), yh[t][1], yl[t][1]);
+                // max(x, 0) and the upper clamp in one v_med3_f32 (NaN -> 0)
+                split2(clampf(y0[0], 0.0f, 65504.0f), clampf(y0[1], 0.0f, 65504.0f), yh[t][0], yl[t][0]);
+                split2(clampf(y0[2], 0.0f, 65504.0f), clampf(y0[3], 0.0f, 65504.0f), yh[t][1], yl[t][1]);
             }
         }
         // gates: accumulators = exp2 arguments (rows pre-scaled on the host before the split, biases through C)

@@ -343,6 +343,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     const Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool term;
     const float r = step_inplace<false>(c, k, ds, y, a, AC01, AC23, term);
+    if (c.action_history_raw) { AC01 = f32x2{a[0], a[1]}; AC23 = f32x2{a[2], a[3]}; }   // what ActionHistory(1) keeps
     const bool ended = stats_update(c.episode_step_limit, r, term, s);
     st.last_reward[i] = r;
     st.last_terminated[i] = term ? 1 : 0;
@@ -522,6 +523,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
             y = yn;
             LA01 = A01; LA23 = A23;
+            if (__builtin_expect(c.action_history_raw != 0, 0)) {      // wave-uniform (kernel argument)
+                LA01 = f32x2{a[0], a[1]}; LA23 = f32x2{a[2], a[3]};
+            }
             last_r = r; last_t = term;
             ended = stats_update(c.episode_step_limit, r, term, s);
             done_code = term ? 1 : (ended ? 2 : 0);

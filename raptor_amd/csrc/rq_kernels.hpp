@@ -15,6 +15,7 @@ struct StepCfg {   // the rq_env_config members one transition reads
     float reward_position, reward_orientation, reward_linear_velocity, reward_angular_velocity, reward_action;
     uint32_t termination_enabled;
     float termination_position, termination_linear_velocity, termination_angular_velocity;
+    uint32_t action_history_raw;
 };
 
 struct NoiseCfg { float position, orientation, linear_velocity, angular_velocity; };
@@ -32,7 +33,7 @@ inline StepCfg step_cfg(const rq_env_config& c) {
             c.reward_termination_penalty, c.reward_position, c.reward_orientation,
             c.reward_linear_velocity, c.reward_angular_velocity, c.reward_action,
             c.termination_enabled, c.termination_position, c.termination_linear_velocity,
-            c.termination_angular_velocity};
+            c.termination_angular_velocity, c.action_history_raw};
 }
 inline NoiseCfg noise_cfg(const rq_env_config& c) {
     return {c.noise_position, c.noise_orientation, c.noise_linear_velocity, c.noise_angular_velocity};

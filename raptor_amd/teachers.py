@@ -51,3 +51,23 @@ class TeacherBank:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision
         _lib.call("rq_teacher_bank_set_precision", self._h, PRECISIONS[precision])
+
+
+def balanced_teacher_assignment(n_envs, n_teachers):
+    """teacher id of every env (uint32 [n_envs], contiguous groups) with WHOLE 16-env tiles per teacher.
+
+    The relabel kernels give one wave a tile of up to 16 envs of ONE teacher; a teacher with 66 envs (65 536 envs over
+    the reference's 1 000 teachers, README.md:207-216, split evenly) fills 5 tiles of which the last holds 2 envs: 18 %
+    of the matrix work is padding (0.54 of the f32 MFMA peak against 0.66 at 1 024 teachers, round 2).  Here the
+    n_envs / 16 tiles are dealt out instead: 65 536 / 1 000 -> 96 teachers x 80 envs + 904 teachers x 64 envs, no
+    padding at all.  Which env is flown by which teacher's quadrotor is the caller's choice when it samples the
+    parameters (one teacher = one set of dynamics); this only fixes the group sizes."""
+    n_envs, n_teachers = int(n_envs), int(n_teachers)
+    if n_envs <= 0 or n_teachers <= 0:
+        raise ValueError("n_envs and n_teachers must be positive")
+    tiles = (n_envs + 15) // 16
+    base, extra = divmod(tiles, n_teachers)
+    per_teacher = np.full(n_teachers, base, np.int64)
+    per_teacher[:extra] += 1                                  # tiles of each teacher
+    ids = np.repeat(np.arange(n_teachers, dtype=np.uint32), per_teacher * 16)[:n_envs]
+    return np.ascontiguousarray(ids)

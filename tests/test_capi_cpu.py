@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_status_strings():
     from raptor_amd import _lib
     lib = _lib.load()
-    assert lib.rq_abi_version() == 1
+    assert lib.rq_abi_version() == 2
     assert lib.rq_status_string(0) == b"ok"
     assert b"device" in lib.rq_status_string(-2)
 
@@ -38,7 +38,7 @@ def test_default_config_matches_oracle(oracle):
     cfg = _lib.EnvConfig()
     _lib.call("rq_env_default_config", ctypes.byref(cfg))
     ref = oracle.default_config()
-    assert ctypes.sizeof(cfg) == ctypes.sizeof(ref) == cfg.struct_size == 144
+    assert ctypes.sizeof(cfg) == ctypes.sizeof(ref) == cfg.struct_size == 148
     assert bytes(cfg) == bytes(ref)
 
 

@@ -84,3 +84,85 @@ def test_closed_loop_statistics_against_the_reference_training_log(oracle, weigh
     share, length = st.fin_terminated.mean(), st.fin_lengths.mean()
     assert abs(share - REFERENCE_LOG["share_terminated"]) < 0.012, share
     assert abs(length - REFERENCE_LOG["episode_length"]) < 5.0, length
+
+
+# The same log holds a second record, parameter-free on the dynamics side: the shipped policy on the NOMINAL Crazyflie
+# (tags crazyflie/*, last record; last-20-epoch means 0.0425 / 481.1).  The terminated episodes' mean length follows
+# from the two: (477.4 - 0.95 * 500) / 0.05 = 48 steps.  crazyflie/return/* are not comparable: that environment carries a
+# termination penalty of about -100 (first epoch: return -102 +- 5.8 at length 29.7 +- 8.3 with every episode terminated -
+# the spread of the return is far below length spread x reward, so a constant dominates it) and a per-step reward of about
+# 0.28, where the sampled-quadrotor evaluation pays about 1.29 per step and no such penalty: the two evaluations do not
+# share their MDP constants, so nothing says they share the termination threshold or the initial distribution either.
+REFERENCE_LOG_CRAZYFLIE = {"share_terminated": 0.05, "episode_length": 477.4, "episode_length_std": 98.4,
+                           "share_terminated_last20": 0.0425, "episode_length_last20": 481.1,
+                           "terminated_episode_length_implied": 48.0, "return_mean": 127.8, "return_std": 69.4}
+
+
+def _nominal_crazyflie(O, weights, n=16384, seed=3, **over):
+    cfg = O.default_config()
+    cfg.domain_randomization = 0
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    P = O.sample_initial_parameters(cfg, seed, 0, 0, n)
+    st = O.Stats(n)
+    S = O.sample_initial_state(cfg, seed, st.episode, 0, P)
+    H = np.zeros((n, 16), np.float32)
+    O.rollout(cfg, weights, seed, 0, 0, P, S, H, 500, 0, st, O.max_threads())
+    assert (st.fin_counts == 1).all()
+    term = st.fin_terminated.astype(bool)
+    L = st.fin_lengths.astype(np.float64)
+    return term.mean(), L.mean(), (L[term].mean() if term.any() else float("nan")), L.std()
+
+
+def test_nominal_crazyflie_statistics_of_this_specification(oracle, weights):
+    """What THIS specification gives for the nominal Crazyflie ('stated mismatch'): about one
+    episode in a hundred terminates - the log says one in twenty - while the terminated episodes end after ~52 steps,
+    as the log implies (48).  The failures are the right kind (hard initial conditions lost within half a second);
+    there are five times too few of them.  Pinned here so that a change of the specification shows."""
+    share, length, len_term, _ = _nominal_crazyflie(oracle, weights)
+    assert 0.005 < share < 0.016, share
+    assert 493.0 < length < 498.0, length
+    assert abs(len_term - REFERENCE_LOG_CRAZYFLIE["terminated_episode_length_implied"]) < 12.0, len_term
+
+
+@pytest.mark.xfail(strict=True, reason="stated mismatch (DESIGN.md section 2): the log's nominal-Crazyflie evaluation "
+                                       "terminates 5 % of its episodes, this specification 1 %; strict, so that a "
+                                       "specification change that closes the gap is noticed and documented")
+def test_nominal_crazyflie_statistics_against_the_reference_training_log(oracle, weights):
+    share, length, _, _ = _nominal_crazyflie(oracle, weights)
+    assert abs(share - REFERENCE_LOG_CRAZYFLIE["share_terminated"]) < 0.012
+    assert abs(length - REFERENCE_LOG_CRAZYFLIE["episode_length"]) < 5.0
+
+
+@pytest.mark.parametrize("candidate", [dict(init_max_angle=1.9), dict(termination_position=0.75), dict(disturbance_force_std=0.19)])
+def test_single_constant_candidates_that_would_close_the_crazyflie_gap(oracle, weights, candidate):
+    """Each of three different single-constant changes reproduces the log's nominal-Crazyflie share and length (an
+    initial tilt of up to 109 degrees instead of 90 even its length spread, 98.4 against the log's 98.4): two logged
+    numbers cannot choose between them, and each of them moves the sampled-quadrotor statistic the default threshold
+    was fitted to away from the log (0.042 -> 0.07 ... 0.09, measured) unless the domain-randomisation ranges - this
+    repository's own - move too.  None is adopted; the degeneracy is what is recorded."""
+    share, length, _, _ = _nominal_crazyflie(oracle, weights, **candidate)
+    assert abs(share - REFERENCE_LOG_CRAZYFLIE["share_terminated"]) < 0.012, (candidate, share)
+    assert abs(length - REFERENCE_LOG_CRAZYFLIE["episode_length"]) < 5.0, (candidate, length)
+
+
+def test_action_history_raw_or_clipped_hardly_moves_the_statistics(oracle, weights):
+    """rq_env_config.action_history_raw (which action ActionHistory(1) keeps is not in the reference tree): the
+    closed-loop statistics do not depend on it within their sampling error - the shipped policy saturates its
+    commands on a few transient steps only.  Measured (16 384 envs x 2 seeds): nominal 0.0093 -> 0.0091 terminated,
+    sampled quadrotors 0.0398 -> 0.0378."""
+    a = _nominal_crazyflie(oracle, weights, n=8192)
+    b = _nominal_crazyflie(oracle, weights, n=8192, action_history_raw=1)
+    assert abs(a[0] - b[0]) < 0.004 and abs(a[1] - b[1]) < 2.0, (a, b)
+    # and the switch does what it says: the observation carries the unclipped command
+    cfg = oracle.default_config()
+    cfg.action_history_raw = 1
+    P = oracle.sample_initial_parameters(cfg, 0, 0, 0, 4)
+    S = oracle.sample_initial_state(cfg, 0, np.zeros(4, np.uint32), 0, P)
+    act = np.tile(np.array([[2.5, -3.0, 0.25, 1.0]], np.float32), (4, 1))
+    S1, _, _ = oracle.step(cfg, P, S, act)
+    assert np.array_equal(oracle.observe(cfg, 0, 0, 0, P, S1)[:, 18:22], act)
+    cfg.action_history_raw = 0
+    S0, _, _ = oracle.step(cfg, P, S, act)
+    assert np.array_equal(oracle.observe(cfg, 0, 0, 0, P, S0)[:, 18:22], np.clip(act, -1, 1))
+    assert np.array_equal(S0[:, :17], S1[:, :17])          # the dynamics see the clipped command either way

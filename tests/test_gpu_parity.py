@@ -1252,6 +1252,99 @@ def test_closed_loop_statistics_against_the_reference_training_log_on_the_gpu(de
     assert abs(length - REFERENCE_LOG["episode_length"]) < 4.0, length
 
 
+def test_nominal_crazyflie_statistics_on_the_gpu(device, oracle):
+    """The second record of the reference's log (tests/test_closed_loop.py::REFERENCE_LOG_CRAZYFLIE) on the HIP path:
+    65 536 nominal Crazyflies, shipped policy.  The specification's own figures (about 1 % terminated after ~52 steps,
+    the log: 5 % after ~48) - a stated mismatch, DESIGN.md section 2 - and one of the single-constant candidates that
+    would close it (initial tilt up to 1.9 rad) as the HIP kernels compute them."""
+    from test_closed_loop import REFERENCE_LOG_CRAZYFLIE as LOG
+
+    def stats(**over):
+        w = World(device, oracle, 65536, seed=3, domain_randomization=0, **over)
+        w.policy.reset()
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 500, "fused", autoreset=False)
+        assert (w.env.finished_counts() == 1).all()
+        term = w.env.finished_terminated().astype(bool)
+        L = w.env.finished_lengths().astype(np.float64)
+        return term.mean(), L.mean(), L[term].mean()
+
+    share, length, len_term = stats()
+    print(f"[nominal Crazyflie, HIP path] share terminated {share:.4f} (log {LOG['share_terminated']}), length {length:.1f} "
+          f"(log {LOG['episode_length']}), terminated after {len_term:.1f} steps (log implies {LOG['terminated_episode_length_implied']})")
+    assert 0.006 < share < 0.014 and 494.0 < length < 497.5, (share, length)
+    assert abs(len_term - LOG["terminated_episode_length_implied"]) < 10.0, len_term
+    assert abs(share - LOG["share_terminated"]) > 0.03          # the stated mismatch, on this path as well
+    share, length, _ = stats(init_max_angle=1.9)
+    assert abs(share - LOG["share_terminated"]) < 0.008 and abs(length - LOG["episode_length"]) < 4.0, (share, length)
+
+
+def test_action_history_raw_on_the_gpu(device, oracle):
+    """rq_env_config.action_history_raw: k_step and the fused kernel keep the policy's raw output as ActionHistory(1),
+    bit for bit what the oracle keeps; the dynamics still see the clipped command."""
+    w = World(device, oracle, 777, seed=5, action_history_raw=1)
+    rng = np.random.default_rng(0)
+    act = (rng.standard_normal((w.n, 4)) * 2.0).astype(np.float32)
+    w.sync_oracle_to_gpu_state()
+    w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+    ns, r, t = oracle.step(w.cfg, w.P, w.S, act)
+    got = w.next_state.numpy()
+    assert np.array_equal(got, ns) and np.array_equal(got[:, 17:21], act)
+    assert np.array_equal(w.env.rewards(), r)
+    # fused == chained with the switch on, over saturating steps
+    a = World(device, oracle, 3000, seed=6, action_history_raw=1, init_max_angle=3.0)
+    b = World(device, oracle, 3000, seed=6, action_history_raw=1, init_max_angle=3.0)
+    a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 40, "fused", True)
+    b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 40, "chained", True)
+    sa, sb = a.state.numpy(), b.state.numpy()
+    assert np.array_equal(sa, sb)
+    assert np.abs(sa[:, 17:21]).max() > 1.0          # the history really holds unclipped commands
+
+
+def test_split_f16_actor_saturates_out_of_range_inputs(device, oracle, weights):
+    """RQ_POLICY_F16X2_MFMA beyond the f16 range (|x| >= 65 520 converts to infinity, and infinity minus infinity in the
+    residual would be NaN in the GRU state for good): observations and layer_0's output are saturated at +-65 504 before
+    the split, so evaluate_step, evaluate_sequence and a fused rollout with termination switched off from a caller-set
+    far-away state all stay finite - as the fp32 build does - and inputs just inside the range are still fp32-grade."""
+    import torch
+    from raptor_amd.foundation_policy import Raptor
+    rng = np.random.default_rng(11)
+    B = 512
+    pol, ref = Raptor(device, precision="f16x2"), Raptor(device)
+    obs = rng.standard_normal((B, 22)).astype(np.float32)
+    obs[:, 0] = 1.0e6                      # a position a diverging env reaches with termination off
+    obs[1::2, 13] = -3.0e9
+    obs[::7, 5] = np.float32(65520.0)      # exactly where the f16 conversion turns infinite
+    obs[::11, 17] = np.nan
+    pol.reset()
+    for _ in range(3):
+        a = pol.evaluate_step(obs)
+        assert np.isfinite(a).all()
+    h = pol.hidden_state(B)
+    assert np.isfinite(h).all() and np.abs(h).max() <= 1.0 + 1e-6
+    # evaluate_sequence on a tensor with the same rows
+    x = torch.from_numpy(np.nan_to_num(np.stack([obs] * 4), nan=7.0e4)).to(f"cuda:{torch.cuda.current_device()}")
+    pol.reset()
+    y = pol.evaluate_sequence(x)
+    assert torch.isfinite(y).all()
+    # just inside the range the split is exact to 2^-22 relative: fp32-grade against the fp32 build (gates saturated or not)
+    near = rng.standard_normal((B, 22)).astype(np.float32)
+    near[:, 3] = 6.0e4
+    pol.reset(); ref.reset()
+    d = np.abs(pol.evaluate_step(near) - ref.evaluate_step(near)).max()
+    assert d < 5e-3, d                     # operands of 6e4 carry 6e4 x 2^-22 = 0.014 absolute into the pre-activations
+    # a fused rollout, termination off, from a state set far outside the range
+    w = World(device, oracle, 2048, seed=13, termination_enabled=0)
+    S = w.state.numpy()
+    S[::3, 0] = 2.0e5
+    S[1::3, 9] = -8.0e4
+    w.state.set(S)
+    w.policy.set_precision("f16x2")
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 30, "fused", autoreset=False)
+    assert np.isfinite(w.policy.hidden_state(w.n)).all()
+    assert np.isfinite(w.state.numpy()[:, 17:21]).all()      # the commands the policy issued
+
+
 def test_sample_and_squash_layer(device, oracle, weights):
     """The full SampleAndSquash output stage (mean / log-std split + Philox sampling; not in the shipped checkpoint,
     semantics unpinned): evaluate_step against the oracle's restatement of the same definition, fused rollout ==

@@ -252,3 +252,25 @@ def test_split_f16_scheme_in_numpy_meets_the_fp32_bar(weights, kat):
     two, one = run(True), run(False)
     print(f"\n[split-f16 scheme, numpy] known-answer max abs error: two pieces {two:.2e}, one piece (plain f16) {one:.2e}")
     assert two < 1e-5 < one
+
+
+def test_balanced_teacher_assignment_deals_whole_tiles():
+    """raptor_amd.teachers.balanced_teacher_assignment: the reference's 1 000 teachers (README.md:207-216) over 65 536
+    envs -> 96 x 80 + 904 x 64 envs, every teacher a whole number of the relabel kernels' 16-env tiles (an even split,
+    66 envs each, pads 18 % of the tiles); contiguous, ordered groups; every env assigned; odd sizes covered."""
+    from raptor_amd.teachers import balanced_teacher_assignment
+    ids = balanced_teacher_assignment(65536, 1000)
+    count = np.bincount(ids, minlength=1000)
+    assert ids.dtype == np.uint32 and ids.shape == (65536,) and (np.diff(ids.astype(np.int64)) >= 0).all()
+    assert (count == 80).sum() == 96 and (count == 64).sum() == 904 and (count % 16 == 0).all()
+    tiles = sum((c + 15) // 16 for c in count)
+    assert tiles == 65536 // 16                              # no padding tile at all
+    even = np.bincount((np.arange(65536) * 1000 // 65536), minlength=1000)
+    assert sum((c + 15) // 16 for c in even) > 1.17 * tiles  # what the even split costs
+    ids = balanced_teacher_assignment(1000, 7)               # 63 tiles over 7 teachers, the last one partial
+    count = np.bincount(ids, minlength=7)
+    assert count.sum() == 1000 and (count[:-1] % 16 == 0).all() and count.max() - count.min() <= 16
+    ids = balanced_teacher_assignment(100, 1000)             # fewer tiles than teachers: the first ones get a tile each
+    assert np.bincount(ids, minlength=1000)[:7].tolist() == [16] * 6 + [4] and len(ids) == 100
+    with pytest.raises(ValueError):
+        balanced_teacher_assignment(0, 3)

@@ -30,7 +30,7 @@ def test_philox_random123_known_answers(oracle):
 def test_default_config_struct(oracle):
     cfg = oracle.default_config()
     import ctypes
-    assert cfg.struct_size == ctypes.sizeof(oracle.EnvConfig) == 144
+    assert cfg.struct_size == ctypes.sizeof(oracle.EnvConfig) == 148
     assert cfg.dt == pytest.approx(0.01) and cfg.episode_step_limit == 500   # README.md:25,95
 
 
