@@ -303,7 +303,7 @@ def extension_probe(device, n):
     return out
 
 
-def teacher_probe(device, n, steps=200, hidden=64):
+def teacher_probe(device, n, steps=500, hidden=64):
     """SURVEY.md section 8(f) row 2 in the record: n envs x `steps` recorded steps labelled by the reference's
     1 000 teachers (README.md:207-216) and by 1 024, exact-f32 MFMA path; envs assigned to teachers by
     raptor_amd.teachers.balanced_teacher_assignment (whole 16-env tiles per teacher)."""
@@ -319,7 +319,7 @@ def teacher_probe(device, n, steps=200, hidden=64):
         bank = TeacherBank(device, W, 22, hidden, hidden, "relu", "identity", precision="fp32")
         for name, ids in (("balanced", balanced_teacher_assignment(n, teachers)),
                           ("contiguous", (np.arange(n, dtype=np.int64) * teachers // n).astype(np.uint32))):
-            for _ in range(2):
+            for _ in range(4):                     # untimed: the first launches of a bank run on cold caches and clocks
                 tr.relabel_teachers(bank, ids, fetch=False)
             device.synchronize()
             per = []

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/raptor_quad.h"
@@ -66,6 +67,18 @@ struct rq_device {
     float* mb_out = nullptr;       // pinned host rows written by kernels
     uint32_t mb_seq = 0;           // last sequence number handed to a launch
     uint32_t mb_in_busy = 0;       // sequence number of the last launch that reads mb_in
+    // observation cache of the small-batch loop (round 3): k_step also assembles the observation of the state it
+    // produced - into the env's device buffer and, row-major, into pinned host memory - so that the observe() that
+    // follows step() + assign() (README.md:96-99) is a host memcpy, no launch.  Valid for the (env, params, state)
+    // objects and versions recorded here; any write to one of them, a real observe launch or another env's step ends it.
+    float* mb_obs = nullptr;       // pinned host rows [n][RQ_OBSERVATION_DIM]
+    const rq_env* oc_env = nullptr;
+    const rq_params* oc_params = nullptr;
+    uint64_t oc_params_version = 0;
+    const rq_state* oc_state[2] = {nullptr, nullptr};   // the state k_step wrote, and the one it was assigned to
+    uint64_t oc_version[2] = {0, 0};
+    uint32_t oc_seq = 0;           // mailbox sequence number of the launch that fills the cache
+    bool oc_in_alt = false;        // the field-major copy still sits in the env's obs_alt (not yet swapped in)
 };
 
 struct rq_rng {
@@ -90,17 +103,22 @@ struct rq_env {
     // chained rollouts replay a captured hipGraph of kGraphSteps steps (3 kernel nodes per step + the
     // epoch-counter bump); one executable graph per distinct argument set
     struct GraphEntry {
-        const float* params; float* state; float* hidden; const float* packed; const float* weights;
+        const float* params; float* state; float* hidden; const float* packed; const float* weights; const float* obs;
         uint32_t flags; int precision; rq_env_config cfg; uint64_t seed;
         int sas_mode; uint64_t sas_seed; const float* ls_image;
         hipGraphExec_t exec;
     };
     std::vector<GraphEntry> graphs;
     uint32_t* epoch_dev = nullptr;   // device-side noise epoch read by the graph's observe nodes
+    bool obs_exposed = false;        // rq_env_observation_device_ptr was called: the caller may write the buffer (no observation cache)
+    float* obs_alt = nullptr;        // [RQ_OBSERVATION_DIM][ld]: where k_step leaves the observation of the state it wrote; a cached
+                                     // observe() swaps it with `obs` (the env's observation buffer changes on observe only)
 };
 
-struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
-struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; };
+// version: bumped by every library call that writes the buffer; exposed: the raw device pointer was handed out, the
+// library no longer knows when it is written (the observation cache then never applies)
+struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; uint64_t version = 1; bool exposed = false; };
+struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; uint64_t version = 1; bool exposed = false; };
 
 struct rq_trajectory {
     rq_env* env = nullptr;
@@ -242,17 +260,33 @@ int ensure_mailbox(rq_device* dev) {
     *static_cast<volatile uint32_t*>(flag) = 0;
     hipError_t e1 = hipHostMalloc(&in, kMailboxRowFloats * sizeof(float), hipHostMallocDefault);
     hipError_t e2 = hipHostMalloc(&out, kMailboxRowFloats * sizeof(float), hipHostMallocDefault);
+    void* obs = nullptr;
     hipError_t e3 = hipMalloc(&dev->mb_counter, sizeof(uint32_t));
     if (e3 == hipSuccess) e3 = hipMemsetAsync(dev->mb_counter, 0, sizeof(uint32_t), dev->stream);
+    if (e3 == hipSuccess) e3 = hipHostMalloc(&obs, kMailboxRowFloats * sizeof(float), hipHostMallocDefault);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         (void)hipHostFree(flag); if (in) (void)hipHostFree(in); if (out) (void)hipHostFree(out);
+        if (obs) (void)hipHostFree(obs);
         if (dev->mb_counter) { (void)hipFree(dev->mb_counter); dev->mb_counter = nullptr; }
         return fail(RQ_ERR_OUT_OF_MEMORY, "ensure_mailbox: pinned host allocation failed");
     }
     dev->mb_flag = static_cast<uint32_t*>(flag);
     dev->mb_in = static_cast<float*>(in);
     dev->mb_out = static_cast<float*>(out);
+    dev->mb_obs = static_cast<float*>(obs);
     return RQ_OK;
+}
+
+// ---- observation cache (rq_device::oc_*) ------------------------------------------------------------------
+void obs_cache_drop(rq_device* dev) { dev->oc_env = nullptr; dev->oc_state[0] = dev->oc_state[1] = nullptr; }
+
+bool obs_cache_holds(const rq_device* dev, const rq_env* env, const rq_params* params, const rq_state* state) {
+    if (dev->oc_env != env || env->obs_exposed || dev->oc_params != params || params->exposed || params->version != dev->oc_params_version ||
+        state->exposed)
+        return false;
+    for (int k = 0; k < 2; ++k)
+        if (dev->oc_state[k] == state && dev->oc_version[k] == state->version) return true;
+    return false;
 }
 
 // spin until the launch with sequence number seq (or a later one: launches finish in stream order) signalled
@@ -459,6 +493,7 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->mb_flag) (void)hipHostFree(dev->mb_flag);
     if (dev->mb_in) (void)hipHostFree(dev->mb_in);
     if (dev->mb_out) (void)hipHostFree(dev->mb_out);
+    if (dev->mb_obs) (void)hipHostFree(dev->mb_obs);
     if (dev->mb_counter) (void)hipFree(dev->mb_counter);
     if (dev->staging_in) (void)hipHostFree(dev->staging_in);
     delete dev;
@@ -644,6 +679,7 @@ RQ_API int rq_env_destroy(rq_env* env) {
     if (!env) return RQ_OK;
     DeviceScope on_device(env->ordinal);   // hipFree synchronises the device; the parent is not touched
     if (env->obs) (void)hipFree(env->obs);
+    if (env->obs_alt) (void)hipFree(env->obs_alt);
     if (env->act) (void)hipFree(env->act);
     if (env->stats_block) (void)hipFree(env->stats_block);
     if (env->epoch_dev) (void)hipFree(env->epoch_dev);
@@ -714,10 +750,12 @@ RQ_API int rq_params_get(const rq_params* p, float* host_out) {
 }
 RQ_API int rq_params_set(rq_params* p, const float* host_in) {
     RQ_REQUIRE(p && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    p->version += 1;
     return host_to_soa(p->env->dev, host_in, p->env->n, RQ_PARAM_DIM, p->env->ld, RQ_PARAM_DIM, p->d);
 }
 RQ_API int rq_params_device_ptr(const rq_params* p, float** dev_ptr) {
     RQ_REQUIRE(p && dev_ptr, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    const_cast<rq_params*>(p)->exposed = true;        // the caller may write through the pointer at any time
     *dev_ptr = p->d; return RQ_OK;
 }
 
@@ -748,6 +786,11 @@ RQ_API int rq_state_assign(rq_state* dst, const rq_state* src) {
     DeviceScope on_device(dst->env->dev); int rc = on_device.rc; if (rc) return rc;
     RQ_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)RQ_STATE_DIM * dst->env->ld * sizeof(float),
                           hipMemcpyDeviceToDevice, dst->env->dev->stream));
+    dst->version += 1;
+    rq_device* dev = dst->env->dev;                   // the cached observation of src is the observation of dst now
+    if (dev->oc_state[0] == src && dev->oc_version[0] == src->version && !src->exposed) {
+        dev->oc_state[1] = dst; dev->oc_version[1] = dst->version;
+    }
     return RQ_OK;
 }
 RQ_API int rq_state_get(const rq_state* s, float* host_out) {
@@ -756,10 +799,12 @@ RQ_API int rq_state_get(const rq_state* s, float* host_out) {
 }
 RQ_API int rq_state_set(rq_state* s, const float* host_in) {
     RQ_REQUIRE(s && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    s->version += 1;
     return host_to_soa(s->env->dev, host_in, s->env->n, RQ_STATE_DIM, s->env->ld, RQ_STATE_DIM, s->d);
 }
 RQ_API int rq_state_device_ptr(const rq_state* s, float** dev_ptr) {
     RQ_REQUIRE(s && dev_ptr, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    const_cast<rq_state*>(s)->exposed = true;         // the caller may write through the pointer at any time
     *dev_ptr = s->d; return RQ_OK;
 }
 
@@ -771,6 +816,7 @@ RQ_API int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* 
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     RQ_HIP(rq::launch_sample_params(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed,
                                     rng->param_epoch, params->d));
+    params->version += 1;
     rng->param_epoch += 1;
     return RQ_OK;
 }
@@ -782,6 +828,7 @@ RQ_API int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params*
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     RQ_HIP(rq::launch_sample_state(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed, params->d,
                                    state->d, env->st));
+    state->version += 1;
     return RQ_OK;
 }
 
@@ -791,6 +838,17 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
     RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
+    if (env->n < kGpuLayoutMinEnvs && !rq::noise_enabled(env->cfg) && obs_cache_holds(dev, env, params, state)) {
+        // the step that produced this state assembled its observation already: obs_alt holds it on the device (swapped
+        // in here), the pinned rows hold it for the host - wait for that launch's flag (usually long set) and copy; no launch
+        rng->epoch += 1;
+        if (dev->oc_in_alt) { std::swap(env->obs, env->obs_alt); dev->oc_in_alt = false; }
+        if (!observation) return RQ_OK;
+        rc = mailbox_wait(dev, dev->oc_seq); if (rc) return rc;
+        std::memcpy(observation, dev->mb_obs, (size_t)env->n * RQ_OBSERVATION_DIM * sizeof(float));
+        return RQ_OK;
+    }
+    if (dev->oc_env == env) obs_cache_drop(dev);       // a real observation replaces whatever was cached
     const bool mailbox = observation && env->n < kGpuLayoutMinEnvs;
     rq::Mailbox mb{};
     if (mailbox) { rc = ensure_mailbox(dev); if (rc) return rc; mb = mailbox_for(dev, nullptr, 0, dev->mb_out); }
@@ -813,25 +871,48 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     RQ_REQUIRE(next_state->env == env, RQ_ERR_SHAPE_MISMATCH, "next_state belongs to another env");
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     rq::Mailbox mb{};
-    if (action && env->n < kGpuLayoutMinEnvs) {
+    // small batches: the kernel also assembles the observation of the state it writes (device buffer + pinned rows):
+    // the observe() of the next loop iteration then needs no launch (obs_cache_holds)
+    const bool cache_obs = env->n < kGpuLayoutMinEnvs && !rq::noise_enabled(env->cfg) && !params->exposed &&
+                           !next_state->exposed && !env->obs_exposed;
+    if (cache_obs && !env->obs_alt) {
+        RQ_HIP(hipMalloc(&env->obs_alt, (size_t)RQ_OBSERVATION_DIM * env->ld * sizeof(float)));
+        RQ_HIP(hipMemsetAsync(env->obs_alt, 0, (size_t)RQ_OBSERVATION_DIM * env->ld * sizeof(float), dev->stream));
+    }
+    if (env->n < kGpuLayoutMinEnvs && (action || cache_obs)) {
         // the kernel reads the actions from the mailbox (and files them in env->act); nothing to wait for
         rc = ensure_mailbox(dev); if (rc) return rc;
-        rc = mailbox_in_free(dev); if (rc) return rc;
-        std::memcpy(dev->mb_in, action, (size_t)env->n * RQ_ACTION_DIM * sizeof(float));
-        mb = mailbox_for(dev, dev->mb_in, RQ_ACTION_DIM, nullptr);
+        if (action) {
+            rc = mailbox_in_free(dev); if (rc) return rc;
+            std::memcpy(dev->mb_in, action, (size_t)env->n * RQ_ACTION_DIM * sizeof(float));
+        }
+        if (cache_obs && dev->oc_env) {                // the pinned rows are about to be rewritten: a host reader of the
+            rc = mailbox_wait(dev, dev->oc_seq); if (rc) return rc;     // previous ones cannot exist (calls are synchronous),
+        }                                              // but their producer must be done before the next one starts
+        mb = mailbox_for(dev, action ? dev->mb_in : nullptr, RQ_ACTION_DIM, cache_obs ? dev->mb_obs : nullptr);
     } else if (action) {
         rc = host_to_soa(dev, action, env->n, RQ_ACTION_DIM, env->ld, RQ_ACTION_DIM, env->act);
         if (rc) return rc;
     }
+    obs_cache_drop(dev);
+    next_state->version += 1;
     RQ_HIP_MB(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
                               next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
-                              nullptr, nullptr, mb), dev, mb);
+                              nullptr, nullptr, mb, cache_obs ? env->obs_alt : nullptr), dev, mb);
+    if (cache_obs) {
+        dev->oc_env = env; dev->oc_params = params; dev->oc_params_version = params->version;
+        dev->oc_state[0] = next_state; dev->oc_version[0] = next_state->version;
+        dev->oc_state[1] = nullptr;
+        dev->oc_seq = mb.seq;
+        dev->oc_in_alt = true;
+    }
     if (dts) for (uint32_t i = 0; i < env->n; ++i) dts[i] = env->cfg.dt;
     return RQ_OK;
 }
 
 RQ_API int rq_env_observation_device_ptr(const rq_env* env, float** p) {
     RQ_REQUIRE(env && p, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    const_cast<rq_env*>(env)->obs_exposed = true;
     *p = env->obs; return RQ_OK;
 }
 RQ_API int rq_env_action_device_ptr(const rq_env* env, float** p) {
@@ -1180,6 +1261,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     rc = policy_size(policy, env->n); if (rc) return rc;
     RQ_REQUIRE(policy->ld == env->ld, RQ_ERR_SHAPE_MISMATCH, "policy batch does not match the env");
+    if (dev->oc_env == env) obs_cache_drop(dev);
     const rq::Batch b = batch_of(env);
     const rq::StepCfg sc = rq::step_cfg(env->cfg);
     const rq::NoiseCfg nc = rq::noise_cfg(env->cfg);
@@ -1220,7 +1302,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
             // host no longer pays ~3.5 us per launch, which is what bounds small batches
             hipGraphExec_t exec = nullptr;
             for (auto& g : env->graphs)
-                if (g.params == params->d && g.state == state->d && g.hidden == policy->hidden &&
+                if (g.params == params->d && g.state == state->d && g.hidden == policy->hidden && g.obs == env->obs &&
                     g.packed == packed_of(policy) && g.weights == policy->w_dev && g.flags == flags &&
                     g.precision == policy->precision && g.seed == rng->seed && g.sas_mode == policy->sas_mode &&
                     g.sas_seed == policy->sas_seed && g.ls_image == policy->ls_image &&
@@ -1242,7 +1324,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                     (void)hipGraphExecDestroy(env->graphs.front().exec);
                     env->graphs.erase(env->graphs.begin());
                 }
-                env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, flags,
+                env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, env->obs, flags,
                                        policy->precision, env->cfg, rng->seed, policy->sas_mode, policy->sas_seed,
                                        policy->ls_image, exec});
             }
@@ -1254,6 +1336,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     }
     rng->epoch += n_steps;
     if (traj) traj->length += n_steps;
+    if (n_steps) state->version += 1;
     return RQ_OK;
 }
 

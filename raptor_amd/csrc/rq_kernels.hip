@@ -322,7 +322,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
                                          const float* state, float* __restrict__ action, float* next_state,
                                          const StatsPtrs& st, uint32_t flags, const SampleCfg& sc, uint64_t seed,
                                          float* __restrict__ hidden, const float* __restrict__ weights,
-                                         const Mailbox& mb) {
+                                         const Mailbox& mb, float* __restrict__ obs_of_next) {
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
@@ -370,6 +370,21 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     y.store([&](int j, float v) { field(next_state, j, ld)[i] = v; });
     field(next_state, (RQ_S_LAST_ACTION + 0), ld)[i] = AC01[0]; field(next_state, (RQ_S_LAST_ACTION + 1), ld)[i] = AC01[1];
     field(next_state, (RQ_S_LAST_ACTION + 2), ld)[i] = AC23[0]; field(next_state, (RQ_S_LAST_ACTION + 3), ld)[i] = AC23[1];
+    if (!ROLLOUT && obs_of_next != nullptr) {   // wave-uniform (kernel argument): what k_observe<false> would assemble
+        float head[22], o[RQ_OBSERVATION_DIM];
+        observe_head<false>(y, AC01, AC23, NoiseCfg{}, seed, 0u, b.env_offset + i, head);
+#pragma unroll
+        for (int j = 0; j < 22; ++j) o[j] = head[j];
+        const float inv = 2.0f / (k.rmax - k.rmin);
+        o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
+        o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
+#pragma unroll
+        for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) field(obs_of_next, j, ld)[i] = o[j];
+        if (mb.rows_out != nullptr) {
+#pragma unroll
+            for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) mb.rows_out[(size_t)i * RQ_OBSERVATION_DIM + j] = o[j];
+        }
+    }
     if (write_dist) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) field(next_state, (RQ_S_FORCE + j), ld)[i] = f6[j];
@@ -382,9 +397,11 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
                                                  const float* state, float* __restrict__ action,
                                                  float* next_state, StatsPtrs st, uint32_t flags, SampleCfg sc,
                                                  uint64_t seed, float* __restrict__ hidden,
-                                                 const float* __restrict__ weights, Mailbox mb) {
+                                                 const float* __restrict__ weights, Mailbox mb,
+                                                 float* __restrict__ obs_of_next) {
     const uint32_t i = env_index();
-    if (i < b.n) step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb);
+    if (i < b.n)
+        step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb, obs_of_next);
     mailbox_signal(mb);
 }
 // ------------------------------------------------------------------ fused rollout ------
@@ -701,14 +718,14 @@ hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t
 
 hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
                        float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
-                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb) {
+                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb, float* obs_of_next) {
     if (b.n == 0) return hipSuccess;
     if (rollout)
         k_step<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                              sc, seed, hidden, weights, mb);
+                                                              sc, seed, hidden, weights, mb, nullptr);
     else
         k_step<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                               sc, seed, hidden, weights, mb);
+                                                               sc, seed, hidden, weights, mb, obs_of_next);
     return hipGetLastError();
 }
 

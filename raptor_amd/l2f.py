@@ -523,6 +523,12 @@ class VectorModule:
     # names and the field names inside data[i] follow the l2f parameter / state structure as recalled
     # [UPSTREAM-UNVERIFIED: no file in /root/reference states them]; they are here so that GPU rollouts can be
     # inspected with a ui-server-like client, not as a parity claim.
+    @staticmethod
+    def _num(v):
+        """JSON has no NaN / Infinity (a browser's JSON.parse rejects the tokens Python would emit): null instead."""
+        v = float(v)
+        return v if np.isfinite(v) else None
+
     def set_ui_message(self, device, env, ui):
         """README.md:86 - announces what is going to be rendered: N quadrotors."""
         return json.dumps({"namespace": ui.ns, "channel": "setUI",
@@ -542,18 +548,19 @@ class VectorModule:
                 "rotor_torque_constants": [float(p[19])] * 4,
                 "rotor_time_constants_rising": [float(p[20])] * 4, "rotor_time_constants_falling": [float(p[21])] * 4,
                 "action_limit": {"min": float(p[22]), "max": float(p[23])}, "hovering_rpm": float(p[24])}})
-        return json.dumps({"namespace": ui.ns, "channel": "setParameters", "data": data})
+        return json.dumps({"namespace": ui.ns, "channel": "setParameters", "data": data}, allow_nan=False)
 
     def set_state_action_message(self, device, env, params, ui, state, action):
         """README.md:76 - the states (a ``copy(state)`` whose ``.states[i].position`` was shifted works, README.md:73-75)
         and the actions about to be applied, one entry per env."""
         S = state.numpy()
         A = np.asarray(action, np.float32).reshape(self.N_ENVIRONMENTS, ACTION_DIM)
-        data = [{"state": {"position": [float(v) for v in s[0:3]], "orientation": [float(v) for v in s[3:7]],
-                           "linear_velocity": [float(v) for v in s[7:10]], "angular_velocity": [float(v) for v in s[10:13]],
-                           "rpm": [float(v) for v in s[13:17]]},
-                 "action": [float(v) for v in a]} for s, a in zip(S, A)]
-        return json.dumps({"namespace": ui.ns, "channel": "setStateAction", "data": data})
+        f = self._num
+        data = [{"state": {"position": [f(v) for v in s[0:3]], "orientation": [f(v) for v in s[3:7]],
+                           "linear_velocity": [f(v) for v in s[7:10]], "angular_velocity": [f(v) for v in s[10:13]],
+                           "rpm": [f(v) for v in s[13:17]]},
+                 "action": [f(v) for v in a]} for s, a in zip(S, A)]
+        return json.dumps({"namespace": ui.ns, "channel": "setStateAction", "data": data}, allow_nan=False)
 
 
 _modules = {}

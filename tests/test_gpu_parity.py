@@ -602,6 +602,92 @@ def test_readme_loop_runs_as_written(device):
     assert np.isfinite(p).all() and np.median(np.linalg.norm(p, axis=1)) < 0.2   # the policy hovers them
 
 
+def test_observation_cache_of_the_small_batch_loop(device, oracle):
+    """Round 3: below 1 024 envs k_step also assembles the observation of the state it writes, and the observe() that
+    follows step() + assign() (README.md:96-99) is a host memcpy of those rows - no launch.  The rows must be exactly
+    what k_observe computes (= the oracle's, bit for bit), and every way of changing what an observation depends on
+    between the two calls must be seen: a state written through .states / set(), a re-sampled state, re-sampled or
+    edited parameters, observation noise switched on, another state object, another env on the same device."""
+    O = oracle
+    w = World(device, oracle, 200, seed=21)
+    w.sync_oracle_to_gpu_state()
+    obs = np.zeros((w.n, 26), np.float32)
+    rng = np.random.default_rng(5)
+
+    def loop_iteration(check=True):
+        w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+        if check:
+            assert np.array_equal(obs, O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+        act = (rng.standard_normal((w.n, 4)) * 0.7).astype(np.float32)
+        w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+        w.S, _, _ = O.step(w.cfg, w.P, w.S, act)
+        w.state.assign(w.next_state)
+
+    for _ in range(5):                    # iterations 2.. are served from the cache
+        loop_iteration()
+    # the env's device buffer holds the same observation (what evaluate_step_device would read)
+    w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+    assert np.array_equal(w.env.observation(), obs) and np.array_equal(obs, O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+    # 1. the state is edited through the writable views between step and observe
+    loop_iteration()
+    for i, st in enumerate(w.state.states):
+        st.position[1] += 0.01 * (i % 7)
+    w.S = w.state.numpy()
+    loop_iteration()
+    # 2. set() with a new array; 3. observing next_state itself (the object the step wrote); 4. a third state object
+    S2 = w.S.copy(); S2[:, 7:10] *= 0.5
+    w.state.set(S2); w.S = S2
+    loop_iteration()
+    w.vector.observe(device, w.env, w.params, w.next_state, obs, w.rng)
+    assert np.array_equal(obs, O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+    other = w.vector.VectorState()
+    w.vector.sample_initial_state(device, w.env, w.params, other, w.rng)
+    w.vector.observe(device, w.env, w.params, other, obs, w.rng)
+    assert np.array_equal(obs[:, :3], other.numpy()[:, :3]) and not np.array_equal(obs[:, :3], w.S[:, :3])
+    loop_iteration()                      # and back to the loop's own state
+    # 5. parameters re-sampled (the privileged tail depends on them), then edited through set()
+    loop_iteration()
+    w.vector.sample_initial_parameters(device, w.env, w.params, w.rng)
+    w.P = w.params.numpy()
+    loop_iteration()
+    loop_iteration()
+    P2 = w.P.copy(); P2[:, 23] *= 1.25
+    w.params.set(P2); w.P = P2
+    loop_iteration()
+    # 6. a rollout writes the state
+    loop_iteration(check=False)
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 3, "fused", False)
+    w.S = w.state.numpy()
+    loop_iteration()
+    # 7. noise switched on: observations are drawn per call again (cache off), and differ from the noiseless ones
+    loop_iteration()
+    cfg = w.env.config
+    cfg.noise_position = 0.01
+    w.env.config = cfg
+    w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+    clean = O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S)
+    assert not np.array_equal(obs[:, :3], clean[:, :3]) and np.array_equal(obs[:, 12:], clean[:, 12:])
+    cfg.noise_position = 0.0
+    w.env.config = cfg
+    loop_iteration()
+    # 8. a second env on the same device in between: its step takes the pinned rows over
+    v = World(device, oracle, 64, seed=22)
+    v.sync_oracle_to_gpu_state()
+    act = np.zeros((v.n, 4), np.float32)
+    loop_iteration()
+    v.vector.step(device, v.env, v.params, v.state, act, v.next_state, v.rng)
+    loop_iteration()
+    vobs = np.zeros((v.n, 26), np.float32)
+    v.S, _, _ = O.step(v.cfg, v.P, v.S, act)
+    v.vector.observe(device, v.env, v.params, v.next_state, vobs, v.rng)
+    assert np.array_equal(vobs, O.observe(v.cfg, v.seed, 0, v.offset, v.P, v.S))
+    # 9. device-resident: observe(None) after step needs no launch either and leaves the right buffer for the actor
+    loop_iteration(check=False)
+    w.vector.observe(device, w.env, w.params, w.state, None, w.rng)
+    assert np.array_equal(w.env.observation(), O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+
+
 def test_device_resident_chain_equals_host_chain(device, oracle):
     """observe(None) -> evaluate_step_device -> step(None) == the NumPy-passing loop, bit for bit."""
     a = World(device, oracle, 500, seed=6)
@@ -1423,6 +1509,64 @@ def test_ui_messages_have_the_keys_the_readme_uses(device):
     x = state.numpy()[:, 0]
     assert np.allclose([d["state"]["position"][0] for d in sm["data"]], x + 0.1 * np.arange(8), atol=1e-6)
     assert np.array_equal(state.numpy()[:, 0], x)         # the original state is untouched
+
+
+def test_ui_messages_round_trip_through_a_client_like_the_readmes(device):
+    """README.md:63-92 end to end, without a ui-server: the handshake's namespace ends up in every message, the
+    parameters message survives the README's own configure_3d_model (json.loads -> data[i]["ui"] = {...} -> json.dumps)
+    with the dynamics entries intact, every message is STRICT JSON (what a browser's JSON.parse accepts - a diverged
+    env's NaN state reads as null, not as the bare NaN token Python would emit), and the state-action message follows
+    the state across a step."""
+    import json
+    import raptor_amd.l2f as l2f
+    from raptor_amd.foundation_policy import Raptor
+
+    def configure_3d_model(parameters_message):            # README.md:63-70, verbatim
+        parameters_message = json.loads(parameters_message)
+        for d in parameters_message["data"]:
+            d["ui"] = {
+                "model": "95d22881d444145176db6027d44ebd3a15e9699a",
+                "name": "x500"
+            }
+        return json.dumps(parameters_message)
+
+    def strict(msg):                                        # a JavaScript client's view of the wire
+        def no_constant(name):
+            raise ValueError(f"not JSON: {name}")
+        return json.loads(msg, parse_constant=no_constant)
+
+    vector = l2f.vector(8)
+    rng, env, ui = vector.VectorRng(), vector.VectorEnvironment(), l2f.UI()
+    params, state, next_state = vector.VectorParameters(), vector.VectorState(), vector.VectorState()
+    vector.initialize_rng(device, rng, 0)
+    vector.initialize_environment(device, env)
+    vector.sample_initial_parameters(device, env, params, rng)
+    vector.sample_initial_state(device, env, params, state, rng)
+    handshake = {"channel": "handshake", "data": {"namespace": "session-42"}}          # README.md:82-85
+    ui.ns = handshake["data"]["namespace"]
+    sent = [vector.set_ui_message(device, env, ui), configure_3d_model(vector.set_parameters_message(device, env, params, ui))]
+    policy = Raptor(device)
+    policy.reset()
+    obs = np.zeros((8, env.OBSERVATION_DIM), np.float32)
+    for _ in range(3):
+        vector.observe(device, env, params, state, obs, rng)
+        action = policy.evaluate_step(obs[:, :22])
+        vector.step(device, env, params, state, action, next_state, rng)
+        state.assign(next_state)
+        sent.append(vector.set_state_action_message(device, env, params, ui, state, action))
+    seen = [strict(m) for m in sent]
+    assert all(m["namespace"] == "session-42" and isinstance(m["channel"], str) for m in seen)
+    assert len({m["channel"] for m in seen}) == 3           # three kinds of message, told apart by their channel
+    pm = seen[1]
+    assert [d["ui"]["name"] for d in pm["data"]] == ["x500"] * 8
+    assert np.allclose([d["dynamics"]["mass"] for d in pm["data"]], params.numpy()[:, 0])
+    assert np.allclose([d["state"]["position"] for d in seen[-1]["data"]], state.numpy()[:, :3])
+    assert np.allclose([d["action"] for d in seen[-1]["data"]], action, atol=1e-7)
+    S = state.numpy()
+    S[2, 0] = np.nan                                        # a diverged env must not break the client's parser
+    state.set(S)
+    bad = strict(vector.set_state_action_message(device, env, params, ui, state, action))
+    assert bad["data"][2]["state"]["position"][0] is None and bad["data"][1]["state"]["position"][0] is not None
 
 
 # ------------------------------------------------------------------------------ native RCCL exchange -
