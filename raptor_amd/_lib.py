@@ -218,7 +218,8 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
-        if lib.rq_abi_version() != 2:
+        # RAPTOR_QUAD_ABI_ANY: same-box timing of an OLDER build (tools/ab_run.sh); only calls both versions share work
+        if lib.rq_abi_version() != 2 and not os.environ.get("RAPTOR_QUAD_ABI_ANY"):
             raise RaptorQuadError(-1, "ABI version mismatch between raptor_amd and libraptor_quad.so")
         _lib = lib
     return _lib

@@ -41,6 +41,10 @@ __device__ __forceinline__ void mailbox_signal(const Mailbox& mb) {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (gridDim.x == 1) {                    // the only workgroup: nothing to count (small batches: one atomic less)
+            __hip_atomic_store(mb.flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
         const uint32_t done = __hip_atomic_fetch_add(mb.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {
             __hip_atomic_store(mb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -127,8 +131,8 @@ template <typename ACTOR>
 __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
                                                        const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
-                                                       float* __restrict__ hidden, uint32_t ld_h,
-                                                       float* __restrict__ act, uint32_t ld_act,
+                                                       const float* __restrict__ hidden_in, float* __restrict__ hidden,
+                                                       uint32_t ld_h, float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen, SasArgs sas,
                                                        Mailbox mb) {
     ACTOR actor;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
 #pragma unroll
             for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
         }
-        load_hidden_q(hidden, ld_h, wave_base, n, hQ);
+        load_hidden_q(hidden_in, ld_h, wave_base, n, hQ);      // == hidden unless the new state goes elsewhere (speculation)
         fz = frozen != nullptr ? (uint32_t)frozen[i] : 0u;
     };
     if (first >= n) { mailbox_signal(mb); return; }          // wave-uniform
@@ -668,7 +672,8 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add) {
 
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
-                             int precision, SasArgs sas, Mailbox mb) {
+                             int precision, SasArgs sas, Mailbox mb, const float* hidden_in) {
+    if (hidden_in == nullptr) hidden_in = hidden;
     if (n == 0) return hipSuccess;
     // enough waves to fill the 1024 SIMDs first, then several 64-env groups per wave so that the
     // per-wave operand-image load (18 KB, more than a group's own 14.8 KB of data) is amortised
@@ -676,12 +681,12 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
     if (precision == RQ_POLICY_F16X2_MFMA)
-        k_actor_step<ActorF16X2><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
+        k_actor_step<ActorF16X2><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);
     else if (precision == RQ_POLICY_BF16_MFMA)
-        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
+        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);
     else
         // the two-tiles-per-pass build: ~30 registers fewer live, 2-3 % faster at every size (same arithmetic)
-        k_actor_step<ActorF32Lean><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden, ld_h, act, ld_act, frozen, sas, mb);
+        k_actor_step<ActorF32Lean><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);
     return hipGetLastError();
 }
 

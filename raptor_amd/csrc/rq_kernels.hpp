@@ -111,10 +111,11 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.
 // frozen != nullptr: envs with frozen[i] != 0 are skipped (rollout semantics).
 // `precision`: rq_policy_precision; `sas`: the optional SampleAndSquash output stage.
+// hidden_in != nullptr: the state BEFORE the step is read from there and `hidden` only written (speculative evaluation).
 // `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
-                             int precision, SasArgs sas, Mailbox mb = Mailbox{});
+                             int precision, SasArgs sas, Mailbox mb = Mailbox{}, const float* hidden_in = nullptr);
 // Raptor over a sequence: obs [steps][n][stride] (first 22 columns) -> act [steps][n][4], both row-major on
 // the device; hidden [16][ld_h] is the state before step 0 on entry and after the last step on return
 hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, const float* packed, const float* obs,

@@ -688,6 +688,70 @@ def test_observation_cache_of_the_small_batch_loop(device, oracle):
     assert np.array_equal(w.env.observation(), O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
 
 
+def test_speculative_policy_step_is_invisible(device, oracle, weights):
+    """Round 3: in the small-batch loop rq_step also launches the policy the device last evaluated on the observation
+    it cached, and evaluate_step takes that result when it is called with bit-identical rows, the same policy and an
+    untouched hidden state (no launch).  Whatever the caller does instead must give exactly what a fresh evaluation
+    gives: other rows, a reset or an edited hidden state in between, another policy object, a changed precision.
+    Checked against the oracle's actor driven with the same inputs (actions to ACTOR_TOL, hidden state likewise)."""
+    from raptor_amd.foundation_policy import Raptor
+    O = oracle
+    w = World(device, oracle, 8, seed=31)
+    w.sync_oracle_to_gpu_state()
+    other = Raptor(device)
+    obs = np.zeros((w.n, 26), np.float32)
+    H = np.tile(weights[2000:2016], (w.n, 1)).astype(np.float32)        # oracle-side hidden of w.policy
+    H2 = H.copy()                                                        # ... and of `other`
+    w.policy.reset(); other.reset()
+    rng = np.random.default_rng(9)
+    hits_possible = 0
+    for it in range(60):
+        w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+        assert np.array_equal(obs, O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
+        kind = ["same", "same", "same", "other_rows", "reset", "set_hidden", "other_policy", "precision"][it % 8] if it > 2 else "same"
+        x = np.ascontiguousarray(obs[:, :22])
+        if kind == "other_rows":
+            x = x.copy(); x[3, 5] += np.float32(1e-3)
+        elif kind == "reset":
+            w.policy.reset(); H[:] = weights[2000:2016]
+        elif kind == "set_hidden":
+            H = (H * np.float32(0.5)).astype(np.float32); w.policy.set_hidden_state(H)
+        if kind == "other_policy":
+            act = other.evaluate_step(obs[:, :22])
+            ref = O.actor_batch_step(weights, x, H2)
+        elif kind == "precision":
+            w.policy.set_precision("bf16"); w.policy.set_precision("fp32")      # back to fp32: same numbers, new version
+            act = w.policy.evaluate_step(obs[:, :22])
+            ref = O.actor_batch_step(weights, x, H)
+        else:
+            act = w.policy.evaluate_step(obs[:, :22] if kind == "same" else x)
+            ref = O.actor_batch_step(weights, x, H)
+            hits_possible += kind == "same"
+        assert np.abs(act - ref).max() < 10 * ACTOR_TOL, (it, kind)
+        w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+        w.S, _, _ = O.step(w.cfg, w.P, w.S, act)
+        w.state.assign(w.next_state)
+    assert np.abs(w.policy.hidden_state(w.n) - H).max() < 20 * ACTOR_TOL
+    assert np.abs(other.hidden_state(w.n) - H2).max() < 20 * ACTOR_TOL
+    assert hits_possible > 20
+    # and the same sequence of calls gives the same bits whether results come from speculation or from fresh launches:
+    # two policies, one fed the cached rows (hits), one fed copies with a different row stride (rows equal -> still a hit
+    # candidate) - then a run through the device-resident entry point, which never speculates
+    a, b = World(device, oracle, 8, seed=32), World(device, oracle, 8, seed=32)
+    a.policy.reset(); b.policy.reset()
+    oa = np.zeros((8, 26), np.float32)
+    for _ in range(25):
+        a.vector.observe(device, a.env, a.params, a.state, oa, a.rng)
+        act = a.policy.evaluate_step(oa[:, :22])
+        a.vector.step(device, a.env, a.params, a.state, act, a.next_state, a.rng)
+        a.state.assign(a.next_state)
+        b.vector.observe(device, b.env, b.params, b.state, None, b.rng)
+        b.policy.evaluate_step_device(b.env)
+        b.vector.step_device(device, b.env, b.params, b.state, b.state, b.rng)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(8), b.policy.hidden_state(8))
+
+
 def test_device_resident_chain_equals_host_chain(device, oracle):
     """observe(None) -> evaluate_step_device -> step(None) == the NumPy-passing loop, bit for bit."""
     a = World(device, oracle, 500, seed=6)
