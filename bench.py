@@ -112,6 +112,11 @@ class Shard:
         self.params, self.state = v.VectorParameters(), v.VectorState()
         v.initialize_rng(device, self.rng, seed)
         v.initialize_environment(device, self.env)
+        cfg = self.env.config
+        # the one fitted MDP constant of the specification, pinned here as well: a change of the library's default
+        #  must not move the benchmarked workload unnoticed
+        cfg.termination_position = 1.0
+        self.env.config = cfg
         v.sample_initial_parameters(device, self.env, self.params, self.rng)
         v.sample_initial_state(device, self.env, self.params, self.state, self.rng)
         self.policy = Raptor(device, precision=precision)
@@ -199,15 +204,23 @@ def kernel_probe(device, n, reps):
     v = sh.vector
     out = {}
 
+    def fresh_episode():
+        # k_step is timed stepping the SAME action over and over: left alone the quadrotors fly off, and a terminated env
+        # writes its episode statistics on every further step (16 B per env more than the 297 the figure is priced at)
+        v.sample_initial_state(device, sh.env, sh.params, sh.state, sh.rng)
+
     def timed(fn):
         """(median, min, max) microseconds per launch: >= 50 warm-up launches, then >= 20 timed batches of `reps`
-        launches each (HIP events on the engine's stream around a batch).  The median of batches, not a mean of
-        launches: one preempted batch (the driver's round-2 record carried a 175 us k_observe) cannot print."""
+        launches each (HIP events on the engine's stream around a batch), every batch from a freshly sampled state.
+        The median of batches, not a mean of launches: one preempted batch (the driver's round-2 record carried a
+        175 us k_observe) cannot print."""
         for _ in range(max(50, reps)):
             fn()
         device.synchronize()
         per = []
         for _ in range(20):
+            fresh_episode()
+            device.synchronize()
             device.timer_start()
             for _ in range(reps):
                 fn()
@@ -644,10 +657,14 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         return wall, posted
 
     def kernel_probe_ms(plan, repetitions, sh=None, ex=None):
-        """Median duration (ms) of one rollout launch of the kind `plan` ends with.  Fused mode: the regions are run
-        again with kernel-level timing on (rq_device_set_rollout_timing: the kernel's own begin / end timestamps, the
-        figure rocprofv3 prints per dispatch; it costs ~8 us of dispatch per launch, which is why the timed regions
-        above run without it).  Chained mode: HIP events around a whole region, per step."""
+        """Average duration (ms) of one rollout launch of the kind `plan` ends with.  Fused mode: the regions are run again
+        with kernel-level timing on (rq_device_set_rollout_timing, round 3: every wave records the wall-clock tick at which
+        it came in and went out; the duration is first-wave-in to last-wave-out on one die).  Calibrated under rocprofv3 in
+        one process: 74.7 us where the profiler prints 73.8 us per dispatch for plain launches of the
+        same kind, 1 532 vs 1 539 us for 500-step launches; round 2's hipExtLaunchKernel events read 82.7 us there, and the
+        launches carrying them ran 4 us longer themselves.  The MEAN over the repetitions, which cover whole episode
+        periods: every env's episode started together, so every 500 steps the whole batch resets at once and the launches
+        right after it run ~10 % longer than those late in the episode.  Chained mode: HIP events around a region, per step."""
         out = []
         if args.mode == "fused":
             engine.set_rollout_timing(True)
@@ -663,7 +680,10 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
                 out.append(engine.timer_stop() / sum(plan))
                 finish(ex)
         engine.set_rollout_timing(False)
-        return float(np.median(out))
+        sync_all()
+        if os.environ.get("RQ_BENCH_DEBUG"):
+            print("kernel_probe_ms", sum(plan), [round(x * 1e3, 1) for x in out], file=sys.stderr)
+        return float(np.mean(out)) if args.mode == "fused" else float(np.median(out))
 
     # ---- warm-up: one-off costs first (RCCL communicator, first barrier, lazy allocations), then EXACTLY
     # --warmup untimed steps of the same rollout ----
@@ -691,7 +711,9 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             break
     walls = max_over_ranks(walls)                    # max over ranks, region by region
     elapsed, share = effective_region(walls, posts, args.steps, exchange is not None)
-    launch_ms = kernel_probe_ms(plan, min(len(walls), 50))     # one rollout launch of the region's kind
+    # one rollout launch of the region's kind; fused: whole episode periods of regions (at least 2, ~0.2 s at most)
+    periods = max(1, int(np.ceil(EPISODE / max(args.steps, 1)))) if args.steps < EPISODE else 1
+    launch_ms = kernel_probe_ms(plan, 2 * periods if args.mode == "fused" else min(len(walls), 50))
 
     flop_step = FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV
 
@@ -720,7 +742,7 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         steady = long_launches(shard, exchange, n, 10,
                                "same process, after the timed regions and 10 untimed launches of the same kind; wall = barrier + "
                                "synchronize on both sides, max over ranks, one all-gather per launch when there is more than one "
-                               "rank; kernel = the kernel's own begin/end timestamps, last launch of such a region, on rank 0")
+                               "rank; kernel = first-wave-in / last-wave-out span of the last launch of three more such regions, on rank 0")
 
     # the last all-gathered returns (numpy [world * n]); one rank: the env's own
     gathered = exchange.result() if exchange is not None else None
@@ -813,9 +835,10 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
                     f"env {FLOP_ENV}) against the fp32 vector = f32-MFMA dense peak; algorithmic HBM bytes are "
                     f"{BYTES_FUSED_LAUNCH} B/env per launch of {int(steps_per_launch)} steps; the measured `traffic` adds "
                     "the operand image every wave loads and the loop-invariant registers parked in scratch before "
-                    "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own begin/end "
-                    "timestamps, median over up to 50 further regions run with kernel-level timing on (the timed "
-                    "regions run without it: it costs ~8 us of dispatch per launch); short launches carry the "
+                    "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own first-wave-in / "
+                    "last-wave-out span on the wall clock (rq_device_set_rollout_timing; within ~1 % of the per-dispatch "
+                    "duration rocprofv3 prints for the timed regions' launches, profiles/r03_summary.md), mean over "
+                    "further regions of the same kind covering whole episode periods; short launches carry the "
                     "kernel's prologue and epilogue (see steady_state for 500-step launches); the north-star's "
                     "'>= 60 % of the HBM roofline on the step kernel' is kernels.n2097152.k_step (HBM-bound there; at "
                     "65 536 envs the API-granular kernels are launch-latency-bound on Infinity-Cache-resident data)",

@@ -151,8 +151,9 @@ typedef struct rq_env_config {
     float reward_scale, reward_constant, reward_termination_penalty;
     float reward_position, reward_orientation, reward_linear_velocity,
           reward_angular_velocity, reward_action;
-    /* termination: |p_i| > .. (default 1 m: the value at which the shipped policy reproduces the share_terminated /
-     * episode_length of the reference's own training log), |v_i| > .., |w_i| > .. (any axis)
+    /* termination: |p_i| > .. (default 1 m [UPSTREAM-UNVERIFIED]: fitted - the value at which the shipped policy reproduces
+     * the sampled-quadrotor share_terminated / episode_length of the reference's own training log; its nominal-Crazyflie
+     * record is NOT reproduced), |v_i| > .., |w_i| > .. (any axis)
      * or any non-finite state */
     uint32_t termination_enabled;
     float termination_position, termination_linear_velocity, termination_angular_velocity;
@@ -183,10 +184,12 @@ RQ_API int rq_device_synchronize(rq_device* dev);
 /* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
 RQ_API int rq_device_timer_start(rq_device* dev);
 RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
-/* Kernel-level timing of fused rollouts, off by default: while enabled every fused rollout kernel is launched with
- * two events that take the kernel's own begin and end timestamps (hipExtLaunchKernel; costs ~8 us of dispatch per
- * launch, measured), and rq_device_last_rollout_ms returns the duration of the most recent one - the figure
- * rocprofv3 --kernel-trace prints for that dispatch - after waiting for it to finish. */
+/* Kernel-level timing of fused rollouts, off by default: while enabled every wave of a fused rollout kernel records the
+ * wall-clock tick (constant 100 MHz) at which it came in and went out, and rq_device_last_rollout_ms returns, after waiting
+ * for the most recent one, first-wave-in to last-wave-out on one die (the eight dies' counters are offset against one
+ * another; the longest die counts).  Calibrated under rocprofv3 in one process: within ~1 % of the per-dispatch duration
+ * the profiler prints for launches of 20 steps and more (it excludes the ~3 us of wave-launch ramp and completion signal
+ * that dominate a 1-step launch).  Round 2 used hipExtLaunchKernel's begin / end events: they read ~8 us long. */
 RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
 RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
 /* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only

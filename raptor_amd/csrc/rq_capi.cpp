@@ -60,7 +60,9 @@ struct rq_device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    hipEvent_t ev_kbegin = nullptr, ev_kend = nullptr;   // begin / end of the most recent fused rollout kernel
+    unsigned long long* k_span = nullptr;        // device [k_span_waves][2]: per wave, in / out ticks of the last timed fused rollout
+    uint32_t k_span_waves = 0, k_span_used = 0;
+    double k_ticks_per_ms = 1e5;                 // wall clock rate (100 MHz on gfx950)
     bool k_timing = false;         // rq_device_set_rollout_timing
     bool k_timed = false;          // a launch carried the two events
     void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
@@ -546,8 +548,6 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     hipError_t e1 = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&d->ev_start);
     hipError_t e3 = hipEventCreate(&d->ev_stop);
-    if (e3 == hipSuccess) e3 = hipEventCreate(&d->ev_kbegin);
-    if (e3 == hipSuccess) e3 = hipEventCreate(&d->ev_kend);
     if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&d->ev_h2d, hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         delete d;
@@ -564,8 +564,7 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
     if (dev->ev_h2d) (void)hipEventDestroy(dev->ev_h2d);
-    if (dev->ev_kbegin) (void)hipEventDestroy(dev->ev_kbegin);
-    if (dev->ev_kend) (void)hipEventDestroy(dev->ev_kend);
+    if (dev->k_span) (void)hipFree(dev->k_span);
     if (dev->staging) (void)hipHostFree(dev->staging);
     if (dev->rows) (void)hipFree(dev->rows);
     if (dev->rows2) (void)hipFree(dev->rows2);
@@ -607,6 +606,11 @@ RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable) {
     RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
     dev->k_timing = enable != 0;
     if (!dev->k_timing) dev->k_timed = false;
+    if (dev->k_timing) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev->ordinal) == hipSuccess && khz > 0)
+            dev->k_ticks_per_ms = (double)khz;
+    }
     return RQ_OK;
 }
 
@@ -615,8 +619,21 @@ RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
     RQ_REQUIRE(dev->k_timed, RQ_ERR_NOT_INITIALIZED,
                "no fused rollout was launched on this device with rq_device_set_rollout_timing enabled");
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
-    RQ_HIP(hipEventSynchronize(dev->ev_kend));
-    RQ_HIP(hipEventElapsedTime(kernel_ms, dev->ev_kbegin, dev->ev_kend));
+    std::vector<unsigned long long> span;
+    try { span.resize((size_t)dev->k_span_used * 2); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    RQ_HIP(hipMemcpyAsync(span.data(), dev->k_span, span.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, dev->stream));
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    unsigned long long first[8], last[8], longest = 0;
+    for (int x = 0; x < 8; ++x) { first[x] = ~0ull; last[x] = 0; }
+    for (uint32_t w = 0; w < dev->k_span_used; ++w) {
+        const unsigned long long in = span[2 * (size_t)w] & 0x0FFFFFFFFFFFFFFFull, out = span[2 * (size_t)w + 1];
+        const int x = (int)(out >> 60) & 7;
+        first[x] = std::min(first[x], in);
+        last[x] = std::max(last[x], out & 0x0FFFFFFFFFFFFFFFull);
+    }
+    for (int x = 0; x < 8; ++x)                         // the die whose first wave in lies furthest before its last wave out
+        if (last[x] > first[x]) longest = std::max(longest, last[x] - first[x]);
+    *kernel_ms = (float)((double)longest / dev->k_ticks_per_ms);
     return RQ_OK;
 }
 
@@ -1419,10 +1436,20 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     if (traj && n_steps && !(flags & RQ_ROLLOUT_AUTORESET))   // steps a frozen wave never reaches read as "not stepped"
         RQ_HIP(hipMemsetAsync(traj->done + (size_t)traj->length * env->ld, 4, (size_t)n_steps * env->ld, dev->stream));
     if (mode == RQ_ROLLOUT_FUSED) {
+        if (dev->k_timing && n_steps) {                   // one (in, out) record per wave = per workgroup of the fused kernel
+            const uint32_t waves = (env->n + 63u) / 64u;
+            if (dev->k_span_waves < waves) {
+                RQ_HIP(hipStreamSynchronize(dev->stream));
+                if (dev->k_span) { RQ_HIP(hipFree(dev->k_span)); dev->k_span = nullptr; dev->k_span_waves = 0; }
+                RQ_HIP(hipMalloc(&dev->k_span, (size_t)waves * 2 * sizeof(unsigned long long)));
+                dev->k_span_waves = waves;
+            }
+            dev->k_span_used = waves;
+        }
         RQ_HIP(rq::launch_rollout_fused(dev->stream, b, sc, nc, noise, smp, rng->seed, rng->epoch, n_steps, flags,
                                         params->d, state->d, policy->hidden, policy->w_dev, packed_of(policy), env->st,
                                         policy->precision, sas_of(policy, rng->epoch, nullptr, env->offset), tp,
-                                        dev->k_timing ? dev->ev_kbegin : nullptr, dev->k_timing ? dev->ev_kend : nullptr));
+                                        dev->k_timing ? dev->k_span : nullptr));
         dev->k_timed = dev->k_timing && n_steps > 0;
     } else {
         // one step = observe -> evaluate_step -> step (-> record) on the stream

@@ -424,7 +424,14 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
                                                                float* __restrict__ hidden,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ packed, StatsPtrs st,
-                                                               TrajPtrs traj, SasArgs sas) {
+                                                               TrajPtrs traj, SasArgs sas,
+                                                               unsigned long long* __restrict__ span) {
+    // kernel-level timing (rq_device_set_rollout_timing): every wave leaves the wall-clock ticks (constant rate) at which it
+    // came in and went out, and its XCD: the eight dies' counters are offset against one another by microseconds, one die's
+    // are consistent - the host takes first-in / last-out per die
+    // (one record per wave, no atomics: 128 waves of a die updating one word cost the launch 8 us)
+    unsigned long long t_in = 0;
+    if (span != nullptr) t_in = (unsigned long long)wall_clock64();
     ACTOR actor;
     actor.template load<kFusedBlock / 64>(packed);
     const uint32_t i0 = env_index();
@@ -601,6 +608,14 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     }
     if (valid && !commit && n_steps > 0) st.last_done[i] = 4;   // not stepped by this rollout (as k_step reports it)
     store_hidden_q(hidden, ld, wave_base, __builtin_amdgcn_ballot_w64(valid && commit), hQ);
+    if (span != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);                // the wave's stores have left
+        if (threadIdx.x == 0) {
+            const unsigned long long xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;        // HW_REG_XCC_ID[3:0]
+            span[2 * (size_t)blockIdx.x] = t_in;
+            span[2 * (size_t)blockIdx.x + 1] = ((unsigned long long)wall_clock64() & 0x0FFFFFFFFFFFFFFFull) | (xcd << 60);
+        }
+    }
 }
 
 // Chained-mode counterpart of the fused kernel's prologue under auto-reset: envs left frozen by an earlier
@@ -745,19 +760,21 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
                                 const float* packed, StatsPtrs st, int precision, SasArgs sas, TrajPtrs traj,
-                                hipEvent_t ev_begin, hipEvent_t ev_end) {
+                                unsigned long long* span) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
-    // hipExtLaunchKernelGGL: the two events take the kernel's own begin / end timestamps (not the stream's
-    // position when a record command is processed), which is what rq_device_last_rollout_ms reports
+    // span != nullptr: every wave leaves its (in, out | xcd << 60) wall-clock ticks at span[2 * workgroup]
+    // (rq_device_last_rollout_ms).  Round 2 took the kernel's begin / end from hipExtLaunchKernel events; calibrated under
+    // rocprofv3 in one process, an event-carrying launch itself runs ~4 us longer than a plain one and the events read
+    // ~4 us more on top.
 #define RQ_LAUNCH_FUSED(NZ, AR, RC, ACT) \
-    hipExtLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, false, ACT>), dim3(g), dim3(kFusedBlock), 0, s, ev_begin, ev_end, 0, \
-                          b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas)
+    hipLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, false, ACT>), dim3(g), dim3(kFusedBlock), 0, s, \
+                       b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas, span)
     // with the SampleAndSquash stage: only the 256-register builds carry it
 #define RQ_LAUNCH_FUSED_SAS(NZ, AR, RC, ACT) \
-    hipExtLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, true, ACT>), dim3(g), dim3(kFusedBlock), 0, s, ev_begin, ev_end, 0, \
-                          b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas)
+    hipLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, true, ACT>), dim3(g), dim3(kFusedBlock), 0, s, \
+                       b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas, span)
 #define RQ_LAUNCH_FUSED_SAS_RC(NZ, AR, ACT) \
     do { if (rec) RQ_LAUNCH_FUSED_SAS(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED_SAS(NZ, AR, false, ACT); } while (0)
 #define RQ_LAUNCH_FUSED_SAS_ACT(ACT)                                                      \

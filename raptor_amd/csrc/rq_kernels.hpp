@@ -143,7 +143,7 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 uint64_t seed, uint32_t epoch0, uint32_t n_steps, uint32_t flags,
                                 const float* params, float* state, float* hidden, const float* weights,
                                 const float* packed, StatsPtrs st, int precision, SasArgs sas, TrajPtrs traj,
-                                hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                                unsigned long long* span = nullptr);
 // chained mode: copy step t (env obs/action buffers + last reward / done code) into the trajectory
 hipError_t launch_record(hipStream_t s, Batch b, const float* obs, const float* act, StatsPtrs st, TrajPtrs traj);
 // ---- MFMA operand images of the policy (layout rationale: rq_device_math.hpp "actor") ----------

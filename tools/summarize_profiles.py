@@ -53,6 +53,19 @@ for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         d["avg_dur_us_" + which] = sum(x[1] for x in v) / len(v) / 1e3
         d["vgpr"], d["agpr"], d["sgpr"] = v[0][2], v[0][3], v[0][4]
 
+sys.path.insert(0, root)
+from bench import launch_grid                      # noqa: E402
+
+
+def envs_of(name, grid):
+    """env count of a dispatch: the grid for most kernels; k_actor_step packs several 64-env groups per wave, so its
+    grid is matched against the batches bench.py launches it at (65 536 and 2 097 152)"""
+    for n in (2097152, 65536):
+        if launch_grid(name, n) == grid and name.startswith("rq::k_actor_step"):
+            return n
+    return grid
+
+
 out = {}
 for (name, grid), d in sorted(pmc.items()):
     if not name.startswith("rq::"):
@@ -65,7 +78,8 @@ for (name, grid), d in sorted(pmc.items()):
     traffic = None if f is None or w is None else (2.0 * f + w) * 1024.0
     out[f"{name}@{grid}"] = {**{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()},
                              "hbm_bytes_per_launch_corrected": traffic,
-                             "hbm_bytes_per_env": None if traffic is None else round(traffic / grid, 2)}
+                             "envs": envs_of(name, grid),
+                             "hbm_bytes_per_env": None if traffic is None else round(traffic / envs_of(name, grid), 2)}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 
 for fn in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
@@ -114,8 +128,8 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
                 "kind of box: DESIGN.md section 6); under rocprofv3 itself the profiler's signal handling inflates them "
                 "by ~15 us per launch, so the profiled run's own figure reads high.\n")
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
-    f.write("| kernel@grid | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|\n")
+    f.write("| kernel@grid | envs | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|---|\n")
     for k, d in out.items():
-        f.write(f"| `{k}` | {d.get('vgpr')}/{d.get('agpr')}/{d.get('sgpr')} | {d.get('avg_dur_us_fetch', 0):.2f} | "
+        f.write(f"| `{k}` | {d.get('envs')} | {d.get('vgpr')}/{d.get('agpr')}/{d.get('sgpr')} | {d.get('avg_dur_us_fetch', 0):.2f} | "
                 f"{d.get('FETCH_SIZE_KiB_avg', 0):.1f} | {d.get('WRITE_SIZE_KiB_avg', 0):.1f} | {d.get('hbm_bytes_per_env')} |\n")
 print("wrote", dst, os.listdir(dst))
