@@ -666,15 +666,19 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         periods: every env's episode started together, so every 500 steps the whole batch resets at once and the launches
         right after it run ~10 % longer than those late in the episode.  Chained mode: HIP events around a region, per step."""
         out = []
+        sync_all()
         if args.mode == "fused":
             engine.set_rollout_timing(True)
         for _ in range(repetitions):
-            sync_all()
             if args.mode == "fused":
+                # no device-wide synchronize between these launches (last_rollout_ms waits on the engine's stream): with one
+                # the span reads ~5 us longer than the profiler's per-dispatch duration of the timed regions' own launches
+                # (which do follow a synchronize): profiles/r03_summary.md 73.7 us, this probe 78.8 with / 74-75 without
                 run(plan, sh, ex)
                 finish(ex)
                 out.append(engine.last_rollout_ms())
             else:
+                sync_all()
                 engine.timer_start()
                 run(plan, sh, ex)
                 out.append(engine.timer_stop() / sum(plan))

@@ -80,6 +80,7 @@ __device__ __forceinline__ void box_muller_fast(float u1, float u2, float& n0, f
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RQ_PK_MUL(d, a, b, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
 #define RQ_PK_FMA(d, a, b, c, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(d) : "v"(a), "v"(b), "v"(c))
+#define RQ_PK_ADD(d, a, b) asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat(float s) { return f32x2{s, s}; }
 // a pair whose low half is s and whose high half is never read (no instruction spent on it)
@@ -925,8 +926,15 @@ struct ActorF32T {
         // the accumulators are next read a whole env step later: a use here, or the chains are emitted after this
         // point (and the round trip loses its cover)
         if constexpr (PIPE) asm volatile("" : : "v"(c.gr), "v"(c.gz), "v"(c.gnh));
-        const f32x2 A01 = (f32x2{R[0][0], R[0][1]} + f32x2{R[1][0], R[1][1]}) + (f32x2{R[2][0], R[2][1]} + f32x2{R[3][0], R[3][1]});
-        const f32x2 A23 = (f32x2{R[0][2], R[0][3]} + f32x2{R[1][2], R[1][3]}) + (f32x2{R[2][2], R[2][3]} + f32x2{R[3][2], R[3][3]});
+        // (a_0, a_1) and (a_2, a_3): (p@0 + p@1) + (p@2 + p@3), six packed adds (written out: the compiler split two of
+        // them into scalar adds; the operands come out of LDS loads, whose waits the compiler places for asm as well)
+        f32x2 A01, A23, T01, T23;
+        RQ_PK_ADD(A01, (f32x2{R[0][0], R[0][1]}), (f32x2{R[1][0], R[1][1]}));
+        RQ_PK_ADD(A23, (f32x2{R[0][2], R[0][3]}), (f32x2{R[1][2], R[1][3]}));
+        RQ_PK_ADD(T01, (f32x2{R[2][0], R[2][1]}), (f32x2{R[3][0], R[3][1]}));
+        RQ_PK_ADD(T23, (f32x2{R[2][2], R[2][3]}), (f32x2{R[3][2], R[3][3]}));
+        RQ_PK_ADD(A01, A01, T01);
+        RQ_PK_ADD(A23, A23, T23);
         a[0] = A01[0]; a[1] = A01[1]; a[2] = A23[0]; a[3] = A23[1];
     }
 };
