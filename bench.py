@@ -669,11 +669,17 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         sync_all()
         if args.mode == "fused":
             engine.set_rollout_timing(True)
+            # the chip's clock state follows its recent load with a time constant of milliseconds: 50 launches read 70.7 us
+            # right after 2 000 regions, 78.8 us after half a second of idling (tools/probe_debug.py, round 3) - so the probe
+            # first runs ~10 ms of the same launches untimed (the host-side statistics since the last timed region idled the GPU)
+            for _ in range(max(2, min(400, 2500 // max(sum(plan), 1)))):     # a fixed count: every rank posts the same exchanges
+                run(plan, sh, ex)
+                finish(ex)
+                engine.last_rollout_ms()
         for _ in range(repetitions):
             if args.mode == "fused":
-                # no device-wide synchronize between these launches (last_rollout_ms waits on the engine's stream): with one
-                # the span reads ~5 us longer than the profiler's per-dispatch duration of the timed regions' own launches
-                # (which do follow a synchronize): profiles/r03_summary.md 73.7 us, this probe 78.8 with / 74-75 without
+                # last_rollout_ms waits on the engine's stream; no device-wide synchronize, no gap: the GPU stays in the state
+                # the warm-up left it in
                 run(plan, sh, ex)
                 finish(ex)
                 out.append(engine.last_rollout_ms())
