@@ -484,6 +484,9 @@ class GpuEngine:
         import raptor_amd.l2f as l2f
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        # RQ_BENCH_DEVICE: every rank on ONE device (tests: two ranks share the single GPU of the test box, with the
+        # tests-only RCCL of tests/fake_rccl.cpp and the gloo rendezvous); normally rank r of the node drives GPU r
+        local_rank = int(os.environ.get("RQ_BENCH_DEVICE", local_rank))
         torch.cuda.set_device(local_rank)
         self.torch, self.local_rank, self.precision = torch, local_rank, args.precision
         self.device = l2f.Device(local_rank)
@@ -494,6 +497,7 @@ class GpuEngine:
             dist.init_process_group("nccl", device_id=self.torch.device("cuda", self.local_rank))
         else:
             dist.init_process_group(backend)
+            self.tensor_device = "cpu"        # the few control scalars (consensus flags, max over ranks) travel through gloo
 
     def make_shard(self, n, offset):
         return Shard(self.device, n, offset, precision=self.precision)

@@ -1825,6 +1825,56 @@ def test_native_exchange_two_ranks_on_one_gpu(device, tmp_path):
         assert np.array_equal(local, whole[k]), f"episode {k}: sharded returns differ from the unsharded batch"
 
 
+@pytest.mark.timeout(900)
+def test_bench_py_with_two_ranks_on_one_gpu(device, tmp_path):
+    """bench.py itself with WORLD_SIZE = 2 on the GPU (round 3): the product engine (GpuEngine: libraptor_quad.so), the
+    two-phase consensus, the NATIVE exchange (rq_comm_* bound to tests/fake_rccl.cpp through RQ_RCCL_LIBRARY, both ranks
+    on this box's one GPU through RQ_BENCH_DEVICE), 20-step regions with their share of the all-gather, the 262 144-envs
+    block - what `torch.distributed.run --nproc-per-node N bench.py --gpus N` meets on a multi-GPU node, minus xGMI.
+    torch.distributed only rendezvouses (gloo)."""
+    import json
+    import shutil
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", os.path.join(root, "tests", "fake_rccl.cpp"), "-o", fake, "-lrt"],
+                   check=True, capture_output=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RQ_BENCH_DEVICE="0", RQ_RCCL_LIBRARY=fake)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20",
+                                       "--warmup", "5", "--no-cpu-baseline", "--envs-per-gpu", "8192"], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("bench.py --gpus 2 hung")
+        assert p.returncode == 0, err[-3000:]
+        outs.append(out)
+    records = [l for l in outs[0].strip().split("\n") if l.lstrip().startswith("{")]
+    assert len(records) == 1 and outs[0].strip().split("\n")[-1] == records[0] and "{" not in outs[1]
+    d = json.loads(records[0])
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 16384 and d["config"]["engine"] == "hip"
+    assert d["config"]["exchange"].startswith("native RCCL"), d["config"]["exchange"]
+    assert d["config"]["gathered_returns"] == 16384
+    assert d["timing"]["exchange_share"]["regions_with_extra_exchange"] >= 3
+    assert d["steady_state"]["exchanges"] == 10 and d["config4"]["total_envs"] == 2 * 262144 and d["config4"]["exchanges"] == 4
+    assert d["value"] > 1e8 and d["roofline"]["frac"] > 0.01
+    print(f"[bench.py, 2 ranks on one GPU, fake RCCL] value {d['value']:.3g} env-steps/s, region {d['timing']['region_ms']['charged']:.4f} ms, "
+          f"exchange share {d['timing']['exchange_share']}")
+
+
 # ------------------------------------------------------------------------------ teacher bank -
 def _teacher_weights(rng, n_teachers, in_dim, h1, h2):
     from raptor_amd.teachers import parameter_count

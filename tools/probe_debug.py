@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Kernel-level span of 20-step fused launches (65 536 envs) against what the GPU did just before: fresh process, after torch
+came up, right after 2 000 synchronised regions, after half a second of idling, after 5 000 busy steps.  The clock state
+follows the recent load with a time constant of milliseconds: 70.7 us ... 78.8 us for the same launch (round 3)."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import raptor_amd.l2f as l2f
 from bench import Shard
