@@ -761,6 +761,21 @@ struct ActorF32T {
         }
     }
 
+    // envs of `mask` did NOT take the step just evaluated (a recording's frozen steps): what is carried for them is again
+    // what it was before the step (`before` = carry_of(c) taken then)
+    struct Saved { f32x4 gr, gz, gnh; };
+    __device__ __forceinline__ Saved carry_of(const Carry& c) const { return kPipelined ? Saved{c.gr, c.gz, c.gnh} : Saved{}; }
+    __device__ __forceinline__ void hold_carry(uint64_t mask, const Saved& before, Carry& c) const {
+        if constexpr (!kPipelined) return;
+        const bool take = (mask >> (threadIdx.x & 15)) & 1ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c.gr[r] = take ? before.gr[r] : c.gr[r];
+            c.gz[r] = take ? before.gz[r] : c.gz[r];
+            c.gnh[r] = take ? before.gnh[r] : c.gnh[r];
+        }
+    }
+
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
         Carry none;
         run<false, 0>(o, hQ, a, none, [] {});
@@ -993,8 +1008,11 @@ struct ActorBF16 {
 
     // the fused rollout's interface (ActorF32T pipelines across the step boundary; nothing to carry here)
     struct Carry {};
+    struct Saved {};
     __device__ __forceinline__ void prime(const float (&)[4][4], Carry&) const {}
     __device__ __forceinline__ void reset_carry(uint64_t, Carry&) const {}
+    __device__ __forceinline__ Saved carry_of(const Carry&) const { return Saved{}; }
+    __device__ __forceinline__ void hold_carry(uint64_t, const Saved&, Carry&) const {}
     template <int N_STORES, class HOOK>
     __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry&, HOOK early_stores) const {
         step<N_STORES>(o, hQ, a, early_stores);
@@ -1149,8 +1167,11 @@ struct ActorF16X2 {
     }
     // the fused rollout's interface (ActorF32T pipelines across the step boundary; nothing to carry here)
     struct Carry {};
+    struct Saved {};
     __device__ __forceinline__ void prime(const float (&)[4][4], Carry&) const {}
     __device__ __forceinline__ void reset_carry(uint64_t, Carry&) const {}
+    __device__ __forceinline__ Saved carry_of(const Carry&) const { return Saved{}; }
+    __device__ __forceinline__ void hold_carry(uint64_t, const Saved&, Carry&) const {}
     template <int N_STORES, class HOOK>
     __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry&, HOOK early_stores) const {
         step<N_STORES>(o, hQ, a, early_stores);

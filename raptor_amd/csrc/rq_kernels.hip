@@ -243,12 +243,14 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
     float x[22], x1[22];
     load_row(0, x);
     if (kTwoAhead) load_row(steps > 1 ? 1 : 0, x1);
+    typename ACTOR::Carry carry;          // the f32 actor pipelines across the step boundary (ActorF32T::Carry)
+    actor.prime(hQ, carry);
     for (uint32_t t = 0; t < steps; ++t) {
         float xn[22];
         const bool more = t + (kTwoAhead ? 2 : 1) < steps;                  // wave-uniform
         if (more) load_row(t + (kTwoAhead ? 2 : 1), xn);
         float a[4];
-        actor.step(x, hQ, a);
+        actor.template step_fused<0>(x, hQ, a, carry, [] {});
         if (squash) squash_action(a);
         if (valid) *reinterpret_cast<float4*>(act + ((size_t)t * n + i0) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         if (kTwoAhead) {
@@ -286,6 +288,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h0Q[t][r] = actor.h0(r);
+    typename ACTOR::Carry carry;          // see k_actor_sequence
+    actor.prime(hQ, carry);
     for (uint32_t t = 0; t < steps; ++t) {
         float x[22], a[4], hn[4][4];
 #pragma unroll
@@ -295,11 +299,17 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
-        actor.step(x, hn, a);
+        const typename ACTOR::Saved before = actor.carry_of(carry);
+        actor.template step_fused<0>(x, hn, a, carry, [] {});
         if (squash) squash_action(a);
         select_hidden_q(__builtin_amdgcn_ballot_w64(d != 4), hn, hQ);          // frozen: state not advanced
+        const uint64_t held = __builtin_amdgcn_ballot_w64(d == 4);
+        if (held != 0) actor.hold_carry(held, before, carry);                   // ... nor what is carried for its next step
         const uint64_t ended = __builtin_amdgcn_ballot_w64(d == 1 || d == 2);
-        if (ended != 0) select_hidden_q(ended, h0Q, hQ);                        // episode end: policy reset
+        if (ended != 0) {                                                       // episode end: policy reset
+            select_hidden_q(ended, h0Q, hQ);
+            actor.reset_carry(ended, carry);
+        }
         if (valid) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) field(act, t * 4 + k, ld)[i] = a[k];

@@ -1271,6 +1271,31 @@ def test_trajectory_relabel_with_the_recording_policy_is_the_identity(device, or
     assert np.array_equal(traj.numpy()["act"], rec["act"])                 # overwrite=False left the buffer alone
 
 
+def test_trajectory_relabel_across_a_frozen_stretch(device, oracle):
+    """One recording made of two rollouts: the first without auto-reset (envs freeze when their episode ends, code 4 for
+    the rest of it), the second with (the frozen envs thaw: new episode, policy state reset).  The relabel kernel carries
+    recurrent accumulators from one step into the next (round 3): a frozen step must leave them as they were, an episode
+    end must replace them - the recording policy has to get its own actions back bit for bit on every live step, the
+    first one after the frozen stretch included."""
+    from raptor_amd.foundation_policy import Raptor
+    w = World(device, oracle, 1000, seed=35, episode_step_limit=13, termination_position=0.7)
+    T1, T2 = 30, 30
+    traj = w.vector.Trajectory(w.env, T1 + T2)
+    w.policy.reset()
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T1, "fused", autoreset=False, trajectory=traj)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, T2, "fused", autoreset=True, trajectory=traj)
+    rec = traj.numpy()
+    assert (rec["done"][:T1] == 4).any() and not (rec["done"][T1:] == 4).any()
+    thawed = rec["done"][T1 - 1] == 4                 # frozen at the end of the first rollout, stepping again in the second
+    assert thawed.sum() > 100
+    teacher = Raptor(device)
+    teacher.reset()
+    relabelled = traj.relabel(teacher)
+    live = rec["done"] != 4
+    assert np.array_equal(relabelled[live], rec["act"][live])
+    assert np.array_equal(relabelled[T1][thawed], rec["act"][T1][thawed])      # the first step after the frozen stretch
+
+
 def test_trajectory_relabel_with_another_policy(device, oracle, weights):
     """A different policy (perturbed weights, standing in for a teacher) on the recorded observations: equals
     the oracle's actor run over each env's observation sequence with a reset after every recorded episode end;
