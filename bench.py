@@ -861,13 +861,17 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
             "sq_counters": sq_profile("fp32")}
     else:
-        bytes_per_step = (BYTES_OBSERVE + BYTES_ACTOR + BYTES_STEP) * n
-        achieved = bytes_per_step / (launch_ms * 1e-3) / 1e9       # one step = three launches
+        # round 3: two launches per step - k_step also writes the next step's observation (104 B/env) from the state it
+        # holds in registers, so the chain no longer re-reads the state for a k_observe launch
+        bytes_obs_write = 4 * 26
+        bytes_per_step = (BYTES_ACTOR + BYTES_STEP + bytes_obs_write) * n
+        achieved = bytes_per_step / (launch_ms * 1e-3) / 1e9
         result["roofline"] = {
-            "kernel": "k_observe+k_actor_step+k_step (chain)", "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-            "traffic": None, "launches": launches,
-            "note": f"algorithmic {BYTES_OBSERVE}+{BYTES_ACTOR}+{BYTES_STEP} B/env-step"}
+            "kernel": "k_actor_step+k_step (chain, observation assembled by the step)", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
+            "traffic": None, "launches": 2 * args.steps,
+            "note": f"algorithmic {BYTES_ACTOR}+{BYTES_STEP}+{bytes_obs_write} B/env-step; launch-latency-bound at 65 536 envs "
+                    "(Infinity-Cache-resident working set), see `kernels`"}
     if world == 1 and not args.no_kernel_probe and engine.name == "hip":
         device = engine.device
         result["kernels"] = {"n65536": kernel_probe(device, ENVS_PER_GPU, 50),

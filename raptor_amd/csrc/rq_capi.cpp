@@ -1018,7 +1018,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     next_state->version += 1;
     RQ_HIP_MB(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
                               next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
-                              nullptr, nullptr, mb, cache_obs ? env->obs_alt : nullptr), dev, mb);
+                              nullptr, nullptr, mb, cache_obs ? env->obs_alt : nullptr, rq::NoiseCfg{}, false, 0u, nullptr), dev, mb);
     if (cache_obs) {
         dev->oc_env = env; dev->oc_params = params; dev->oc_params_version = params->version;
         dev->oc_state[0] = next_state; dev->oc_version[0] = next_state->version;
@@ -1452,17 +1452,22 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                                         dev->k_timing ? dev->k_span : nullptr));
         dev->k_timed = dev->k_timing && n_steps > 0;
     } else {
-        // one step = observe -> evaluate_step -> step (-> record) on the stream
+        // one step = observe -> evaluate_step -> step (-> record) on the stream.  Without a recording the step kernel
+        // also assembles the NEXT step's observation (round 3: two launches per step instead of three; the first
+        // observation of the rollout is a launch of its own, the one assembled by the last step is not used)
+        const bool fold_observe = traj == nullptr;
         auto enqueue_step = [&](uint32_t epoch, const uint32_t* epoch_base, uint32_t t_record) -> hipError_t {
-            hipError_t e = rq::launch_observe(dev->stream, b, nc, noise, rng->seed, epoch, epoch_base, params->d,
-                                              state->d, env->obs);
+            hipError_t e = hipSuccess;
+            if (!fold_observe)
+                e = rq::launch_observe(dev->stream, b, nc, noise, rng->seed, epoch, epoch_base, params->d, state->d, env->obs);
             if (e == hipSuccess)
                 e = rq::launch_actor_step(dev->stream, env->n, packed_of(policy), env->obs, env->ld, policy->hidden,
                                           policy->ld, env->act, env->ld, env->st.frozen, policy->precision,
                                           sas_of(policy, epoch, epoch_base, env->offset));
             if (e == hipSuccess)
                 e = rq::launch_step(dev->stream, b, sc, params->d, state->d, env->act, state->d, env->st,
-                                    /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev);
+                                    /*rollout=*/1, flags, smp, rng->seed, policy->hidden, policy->w_dev, rq::Mailbox{},
+                                    fold_observe ? env->obs : nullptr, nc, noise, epoch + 1, epoch_base);
             if (e == hipSuccess && traj) {
                 rq::TrajPtrs tt = tp; tt.t0 = tp.t0 + t_record;
                 e = rq::launch_record(dev->stream, b, env->obs, env->act, env->st, tt);
@@ -1472,6 +1477,8 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
         if (n_steps && (flags & RQ_ROLLOUT_AUTORESET))   // envs frozen by an earlier rollout start their next episode
             RQ_HIP(rq::launch_thaw_frozen(dev->stream, b, smp, rng->seed, params->d, state->d, env->st, policy->hidden,
                                           policy->w_dev));
+        if (fold_observe && n_steps)     // the rollout's first observation (after the thaw: of the re-sampled states)
+            RQ_HIP(rq::launch_observe(dev->stream, b, nc, noise, rng->seed, rng->epoch, nullptr, params->d, state->d, env->obs));
         uint32_t done_steps = 0;
         if (!traj && n_steps >= kGraphSteps) {
             // replay a captured graph of kGraphSteps steps; kernel boundaries stay (~1.5 us each) but the

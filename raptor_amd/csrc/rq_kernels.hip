@@ -331,12 +331,23 @@ __device__ __forceinline__ void store_stats(const StatsPtrs& st, uint32_t i, con
     }
 }
 
+// the observation of the state a step writes, produced by the step itself: obs [RQ_OBSERVATION_DIM][ld] (nullptr = off).
+// rq_step below 1 024 envs (the small-batch loop's cache, no noise) and the chained rollout's two-kernel step (round 3:
+// observe of step t + 1 folded into step t; with noise: the draw of epoch `epoch` + *epoch_base, as k_observe makes it).
+struct ObsNext {
+    float* obs;
+    NoiseCfg nc;
+    uint32_t noise;               // 0 / 1
+    uint32_t epoch;
+    const uint32_t* epoch_base;
+};
+
 template <bool ROLLOUT>
 __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepCfg& c, const float* __restrict__ params,
                                          const float* state, float* __restrict__ action, float* next_state,
                                          const StatsPtrs& st, uint32_t flags, const SampleCfg& sc, uint64_t seed,
                                          float* __restrict__ hidden, const float* __restrict__ weights,
-                                         const Mailbox& mb, float* __restrict__ obs_of_next) {
+                                         const Mailbox& mb, const ObsNext& on) {
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
@@ -384,16 +395,21 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     y.store([&](int j, float v) { field(next_state, j, ld)[i] = v; });
     field(next_state, (RQ_S_LAST_ACTION + 0), ld)[i] = AC01[0]; field(next_state, (RQ_S_LAST_ACTION + 1), ld)[i] = AC01[1];
     field(next_state, (RQ_S_LAST_ACTION + 2), ld)[i] = AC23[0]; field(next_state, (RQ_S_LAST_ACTION + 3), ld)[i] = AC23[1];
-    if (!ROLLOUT && obs_of_next != nullptr) {   // wave-uniform (kernel argument): what k_observe<false> would assemble
+    if (on.obs != nullptr) {   // wave-uniform (kernel argument): what k_observe would assemble for the state just written
         float head[22], o[RQ_OBSERVATION_DIM];
-        observe_head<false>(y, AC01, AC23, NoiseCfg{}, seed, 0u, b.env_offset + i, head);
+        if (on.noise) {
+            const uint32_t epoch = on.epoch + (on.epoch_base != nullptr ? *on.epoch_base : 0u);
+            observe_head<true>(y, AC01, AC23, on.nc, seed, epoch, b.env_offset + i, head);
+        } else {
+            observe_head<false>(y, AC01, AC23, on.nc, seed, 0u, b.env_offset + i, head);
+        }
 #pragma unroll
         for (int j = 0; j < 22; ++j) o[j] = head[j];
         const float inv = 2.0f / (k.rmax - k.rmin);
         o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
         o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
 #pragma unroll
-        for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) field(obs_of_next, j, ld)[i] = o[j];
+        for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) field(on.obs, j, ld)[i] = o[j];
         if (mb.rows_out != nullptr) {
 #pragma unroll
             for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) mb.rows_out[(size_t)i * RQ_OBSERVATION_DIM + j] = o[j];
@@ -411,11 +427,10 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
                                                  const float* state, float* __restrict__ action,
                                                  float* next_state, StatsPtrs st, uint32_t flags, SampleCfg sc,
                                                  uint64_t seed, float* __restrict__ hidden,
-                                                 const float* __restrict__ weights, Mailbox mb,
-                                                 float* __restrict__ obs_of_next) {
+                                                 const float* __restrict__ weights, Mailbox mb, ObsNext on) {
     const uint32_t i = env_index();
     if (i < b.n)
-        step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb, obs_of_next);
+        step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb, on);
     mailbox_signal(mb);
 }
 // ------------------------------------------------------------------ fused rollout ------
@@ -748,14 +763,16 @@ hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t
 
 hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
                        float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
-                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb, float* obs_of_next) {
+                       SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb, float* obs_of_next,
+                       NoiseCfg nc, bool noise, uint32_t obs_epoch, const uint32_t* obs_epoch_base) {
     if (b.n == 0) return hipSuccess;
+    const ObsNext on{obs_of_next, nc, noise ? 1u : 0u, obs_epoch, obs_epoch_base};
     if (rollout)
         k_step<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                              sc, seed, hidden, weights, mb, nullptr);
+                                                              sc, seed, hidden, weights, mb, on);
     else
         k_step<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                               sc, seed, hidden, weights, mb, obs_of_next);
+                                                               sc, seed, hidden, weights, mb, on);
     return hipGetLastError();
 }
 

@@ -128,12 +128,14 @@ hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t
 // vector.step (README.md:98) + reward/termination/statistics.  rollout != 0 adds the
 // episode-end handling of rq_rollout (freeze or auto-reset incl. hidden-state reset).
 // With mb.rows_in the actions come from the mailbox and are also written to `action` (field-major).
-// obs_of_next != nullptr (rollout == 0 only): the observation of the state just written, as vector.observe would
-// assemble it without noise, goes to obs_of_next [RQ_OBSERVATION_DIM][ld] and, row-major, to mb.rows_out.
+// obs_of_next != nullptr: the observation of the state just written (after an auto-reset: of the re-sampled one), as
+// vector.observe would assemble it - with the noise draw of epoch obs_epoch + *obs_epoch_base when `noise` - goes to
+// obs_of_next [RQ_OBSERVATION_DIM][ld] and, row-major, to mb.rows_out.
 hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, const float* state,
                        float* action, float* next_state, StatsPtrs st, int rollout, uint32_t flags,
                        SampleCfg sc, uint64_t seed, float* hidden, const float* weights, Mailbox mb = Mailbox{},
-                       float* obs_of_next = nullptr);
+                       float* obs_of_next = nullptr, NoiseCfg nc = NoiseCfg{}, bool noise = false, uint32_t obs_epoch = 0,
+                       const uint32_t* obs_epoch_base = nullptr);
 // chained rollouts under auto-reset: envs left frozen by an earlier rollout start their next episode
 // (sample_initial_state with the env's episode counter + policy state reset), as the fused kernel's prologue does
 hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params, float* state,
