@@ -15,6 +15,7 @@ python bench.py --envs-per-gpu 1048576 --no-cpu-baseline --no-kernel-probe > $DS
 python bench.py --mode chained --steps 2000 --warmup 500 --no-cpu-baseline --no-kernel-probe > $DST/${TAG}_bench_chained.json 2>/dev/null; echo "chained rc=$?"
 python tools/teacher_rate.py --teachers 1024 > $DST/${TAG}_teacher_rate.json 2>/dev/null
 python tools/teacher_rate.py --teachers 1000 >> $DST/${TAG}_teacher_rate.json 2>/dev/null
+python tools/teacher_rate.py --teachers 1000 --assignment contiguous >> $DST/${TAG}_teacher_rate.json 2>/dev/null
 OUT=$R/gpurun_out/sq_teacher_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -123,10 +123,9 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
         f.write(f"\nbench.py in the same (profiled) run: timed regions of {b['steps']} steps x {tm.get('repetitions')} repetitions, "
                 f"`roofline.kernel` = `{rl.get('kernel')}`, `roofline.avg_launch_ms` = {rl.get('avg_launch_ms')}; "
                 f"`steady_state.kernel` = `{ss.get('kernel')}`, `steady_state.avg_launch_ms` = {ss.get('avg_launch_ms')}.  "
-                "bench.py takes these from the kernels' own begin/end timestamps (hipExtLaunchKernel events): in an "
-                "un-profiled run they equal the per-dispatch durations above (the same command un-profiled on the same "
-                "kind of box: DESIGN.md section 6); under rocprofv3 itself the profiler's signal handling inflates them "
-                "by ~15 us per launch, so the profiled run's own figure reads high.\n")
+                "bench.py takes these from the kernels' own first-wave-in / last-wave-out spans (per-wave wall-clock records, "
+                "rq_device_set_rollout_timing): in an un-profiled run they agree with the per-dispatch durations above to ~1 % "
+                "(profiles/r03_kernel_timing_calibration.md; the same command un-profiled: DESIGN.md section 6).\n")
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
     f.write("| kernel@grid | envs | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|---|\n")
     for k, d in out.items():

@@ -15,13 +15,16 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raptor_amd.l2f as l2f                       # noqa: E402
 from bench import Shard                            # noqa: E402
-from raptor_amd.teachers import TeacherBank, parameter_count   # noqa: E402
+from raptor_amd.teachers import TeacherBank, balanced_teacher_assignment, parameter_count   # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=500)
 ap.add_argument("--teachers", type=int, default=1000)
 ap.add_argument("--hidden", type=int, default=64)
+ap.add_argument("--assignment", choices=("balanced", "contiguous"), default="balanced",
+                help="balanced: raptor_amd.teachers.balanced_teacher_assignment (whole 64-env tiles per teacher where the "
+                     "counts allow); contiguous: env e -> teacher e*T//n (65.536 envs per teacher at T=1000: ragged tiles)")
 args = ap.parse_args()
 
 device = l2f.Device()
@@ -31,9 +34,12 @@ sh.vector.rollout(device, sh.env, sh.params, sh.state, sh.policy, sh.rng, args.s
 rng = np.random.default_rng(0)
 H = args.hidden
 W = (rng.standard_normal((args.teachers, parameter_count(22, H, H))) * 0.1).astype(np.float32)
-ids = (np.arange(args.envs) * args.teachers // args.envs).astype(np.uint32)     # contiguous groups, one teacher each
+if args.assignment == "balanced":
+    ids = balanced_teacher_assignment(args.envs, args.teachers)
+else:
+    ids = (np.arange(args.envs) * args.teachers // args.envs).astype(np.uint32)
 flop = 2 * (22 * H + H * H + H * 4) * args.envs * args.steps
-out = {"envs": args.envs, "steps": args.steps, "teachers": args.teachers, "topology": f"22-{H}-{H}-4",
+out = {"envs": args.envs, "steps": args.steps, "teachers": args.teachers, "assignment": args.assignment, "topology": f"22-{H}-{H}-4",
        "flop_per_label": 2 * (22 * H + H * H + H * 4)}
 for prec, peak in (("fp32", 157.3), ("bf16", 2500.0), ("f16x2", 2500.0)):    # f16x2: useful FLOP; 3x as many are issued
     bank = TeacherBank(device, W, 22, H, H, "relu", "identity", precision=prec)
