@@ -301,7 +301,8 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
 RQ_API int rq_policy_destroy(rq_policy* pol);
 RQ_API int rq_policy_set_precision(rq_policy* pol, int precision);
 /* Host only (no GPU involved): the per-lane register image the actor kernels of `precision` keep their operands in,
- * `*floats` = its size in 4-byte words (64 lanes x registers; layout: raptor_amd/csrc/rq_kernels.hpp QW_ / BW_ / FW_).
+ * `*floats` = its size in 4-byte words (64 lanes x registers; layout: raptor_amd/csrc/rq_kernels.hpp QW_ / BW_ / FW_;
+ * the f32 image is stored in quads of registers, rq::qw_slot, so that a lane fetches four with one 16-byte load).
  * `image` may be NULL to query the size.  A diagnostic: it lets the packing (pre-scaled gate rows, bf16 rounding,
  * the f16 hi / lo split) be checked without a device. */
 RQ_API int rq_policy_pack_image(const float* weights, size_t n_weights, int precision, float* image, size_t capacity,

@@ -677,8 +677,16 @@ struct ActorF32T {
             rd[t] = stage + (16 * t + (lane & 15)) * kLdsRow + (lane >> 4);
             asm volatile("" : "+v"(rd[t]));       // not to be recomputed inside the MFMA batches
         }
+        // 18 16-byte loads per lane (round 3; 70 single ones before: the prologue's loads no longer fill the 63-deep
+        // memory counter twice over)
+        const f32x4* quads = reinterpret_cast<const f32x4*>(packed) + lane;
 #pragma unroll
-        for (int v = 0; v < QW_REGS; ++v) W[v] = packed[v * 64 + lane];
+        for (int g = 0; g < QW_QUADS; ++g) {
+            const f32x4 x = quads[g * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < QW_REGS) W[4 * g + e] = x[e];
+        }
         // The 30 images that are only ever an MFMA's A operand (layer_0, W_input, W_hidden) live in ACCUMULATION
         // registers: the matrix instructions read A / B from either file, the VALU only from the architected 256,
         // and with one wave per SIMD the other 256 sit idle - parked there, the operands leave the VALU's file to

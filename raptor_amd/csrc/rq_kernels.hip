@@ -457,8 +457,6 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     // (one record per wave, no atomics: 128 waves of a die updating one word cost the launch 8 us)
     unsigned long long t_in = 0;
     if (span != nullptr) t_in = (unsigned long long)wall_clock64();
-    ACTOR actor;
-    actor.template load<kFusedBlock / 64>(packed);
     const uint32_t i0 = env_index();
     const uint32_t wave_base = i0 & ~63u;
     const uint32_t i = i0 < b.n ? i0 : b.n - 1;
@@ -475,18 +473,28 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
     load_hidden_q(hidden, ld, wave_base, b.n, hQ);
+    Stats s = load_stats(st, i);
+    float last_r = st.last_reward[i];
+    const uint8_t last_t_raw = st.last_terminated[i];
+    uint8_t last_d = st.last_done[i];
+    const uint8_t frozen_raw = st.frozen[i];
+    bool any_end = false, dist_changed = false;
+    uint32_t ep = AUTORESET ? st.episode[i] : 0u;
+    // the operand image (L2-resident after a die's first wave) is asked for AFTER the env's own fields: those come from
+    // HBM / the memory-side cache and their latency is the long one
+    ACTOR actor;
+    actor.template load<kFusedBlock / 64>(packed);
     float h0Q[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h0Q[t][r] = actor.h0(r);
-    Stats s = load_stats(st, i);
-    float last_r = st.last_reward[i];
-    bool last_t = st.last_terminated[i] != 0;
-    uint8_t last_d = st.last_done[i];
-    const bool was_frozen = st.frozen[i] != 0;
-    bool any_end = false, dist_changed = false;
-    uint32_t ep = AUTORESET ? st.episode[i] : 0u;
+    // looked at only now (the empty asm keeps the compares from drifting up between the image's loads, where they
+    // made those wait for every load before them)
+    uint32_t last_t_bits = last_t_raw, frozen_bits = frozen_raw;
+    asm volatile("" : "+v"(last_t_bits), "+v"(frozen_bits));
+    bool last_t = last_t_bits != 0;
+    const bool was_frozen = frozen_bits != 0;
     // sample_initial_state for this lane's env, episode counter ep (out of line: rare, see rq_device_math.hpp)
     auto resample = [&]() {
         float fresh[27];

@@ -187,7 +187,11 @@ enum {
 
 // Host-side packing of the 2 084 checkpoint parameters into the per-lane VGPR image the actor's
 // v_mfma_f32_16x16x4_f32 instructions read as A / C operands (layout: rq_device_math.hpp "actor").
-enum { RQ_PACKED_FLOATS = QW_REGS * 64, RQ_PACKED_BF16_FLOATS = BW_REGS * 64, RQ_PACKED_F16X2_FLOATS = FW_REGS * 64 };
+// the f32 image is stored in quads: images 4g .. 4g+3 of lane l at floats 256 g + 4 l .. + 3, one 16-byte load per lane
+// and quad (qw_slot); the last quad is padded
+enum { QW_QUADS = (QW_REGS + 3) / 4 };
+constexpr int qw_slot(int v, int lane) { return (v >> 2) * 256 + lane * 4 + (v & 3); }
+enum { RQ_PACKED_FLOATS = QW_QUADS * 256, RQ_PACKED_BF16_FLOATS = BW_REGS * 64, RQ_PACKED_F16X2_FLOATS = FW_REGS * 64 };
 void pack_policy(const float* weights, float* packed);
 // the same for the bf16 actor (v_mfma_f32_16x16x32_bf16): 36 dword images of bf16 pairs + 24 fp32 images
 void pack_policy_bf16(const float* weights, float* packed);

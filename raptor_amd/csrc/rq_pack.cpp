@@ -15,7 +15,7 @@ void pack_policy(const float* w, float* packed) {
     for (int i = 0; i < RQ_PACKED_FLOATS; ++i) packed[i] = 0.0f;
     for (int l = 0; l < 64; ++l) {
         const int q = l >> 4, j = l & 15;
-        auto img = [&](int v) -> float& { return packed[v * 64 + l]; };
+        auto img = [&](int v) -> float& { return packed[qw_slot(v, l)]; };
         for (int s = 0; s < 6; ++s) {
             const int f = 4 * s + q;     // input feature of k-slot q in K-step s
             img(QW_L0 + s) = f < 22 ? w[W0 + j * 22 + f] : (f == 22 ? w[B0 + j] : 0.0f);

@@ -170,7 +170,7 @@ def test_split_f16_operand_image_reconstructs_the_weights():
         _lib.call("rq_policy_pack_image", w.ctypes.data, w.size, precision, img.ctypes.data, img.size, C.byref(need))
         return img.reshape(-1, 64)
 
-    assert image(_lib.POLICY_FP32).shape[0] == 70 and image(_lib.POLICY_BF16_MFMA).shape[0] == 60
+    assert image(_lib.POLICY_FP32).shape[0] == 72 and image(_lib.POLICY_BF16_MFMA).shape[0] == 60     # f32: 18 quads of 70 + 2 padding images
     img = image(_lib.POLICY_F16X2_MFMA)
     assert img.shape == (96, 64)
     halves = img[:72].view(np.uint32)

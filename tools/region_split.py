@@ -18,7 +18,13 @@ from bench import Shard                            # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--reps", type=int, default=2000)
+ap.add_argument("--spin", action="store_true", help="hipSetDeviceFlags(hipDeviceScheduleSpin) before anything runs")
 args = ap.parse_args()
+import ctypes                                      # noqa: E402
+hip = ctypes.CDLL("libamdhip64.so")
+if args.spin:
+    torch.cuda.init()
+    print("hipSetDeviceFlags(hipDeviceScheduleSpin) ->", hip.hipSetDeviceFlags(1))
 device = l2f.Device()
 sh = Shard(device, 65536, 0)
 sh.rollout(5000, "fused")
@@ -30,14 +36,18 @@ def med(xs):
     return float(np.median(xs)) * 1e6
 
 
-for variant in ("lib+torch", "torch only", "lib only"):
+stream = ctypes.c_void_p(int(device.stream))
+for variant in ("lib+torch", "torch only", "lib only", "query spin"):
     call, s1, s2, tot = [], [], [], []
     for _ in range(args.reps):
         torch.cuda.synchronize()
         t0 = pc()
         sh.rollout(args.steps, "fused")
         t1 = pc()
-        if variant != "torch only":
+        if variant == "query spin":
+            while hip.hipStreamQuery(stream) != 0:
+                pass
+        elif variant != "torch only":
             device.synchronize()
         t2 = pc()
         if variant != "lib only":
