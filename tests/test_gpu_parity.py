@@ -450,13 +450,18 @@ def test_host_transfers_small_and_large_batch_paths(device, oracle, weights, n):
 
 @pytest.mark.parametrize("n", [8, 1000, 1100])
 def test_random_api_sequences_against_a_shadow_model(device, oracle, weights, n):
-    """Model-based fuzz of the API-granular calls: 150 random operations mixing host arrays and the
+    """Model-based fuzz of the API-granular calls: 250 random operations mixing host arrays and the
     device-resident buffers (both sides of the 1 024-env switch between the pinned mailbox and the GPU layout
     kernels), back-to-back asynchronous steps, in-place steps and getters in between.  A shadow model driven
     by the oracle holds what every buffer must contain; env data is compared bit for bit, actions to ACTOR_TOL."""
-    w = World(device, oracle, n, seed=11 + n)
+    for round_ in range(int(os.environ.get("RQ_FUZZ_ROUNDS", "3"))):       # more rounds: a soak of the host logic
+        _one_random_api_sequence(device, oracle, weights, n, n + 7919 * round_)
+
+
+def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
+    w = World(device, oracle, n, seed=11 + fuzz_seed)
     w.sync_oracle_to_gpu_state()
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(fuzz_seed)
     S, NS = w.S.copy(), w.S.copy()                    # shadow of state / next_state
     w.next_state._ensure(w.env)
     assert np.all(w.next_state.numpy() == 0)          # a fresh VectorState is all zeros
@@ -467,9 +472,12 @@ def test_random_api_sequences_against_a_shadow_model(device, oracle, weights, n)
     epoch = 0
     w.policy.reset()
     obs_host = np.zeros((n, 26), np.float32)
-    for it in range(150):
+    held = None                                       # (a copy of the state taken earlier, what it held then)
+    for it in range(250):
         op = rng.choice(["observe_host", "observe_dev", "eval_host_host", "eval_dev_dev", "step_host", "step_dev",
-                         "step_inplace", "assign", "get_obs", "get_act", "set_act", "get_state", "stats"])
+                         "step_inplace", "assign", "get_obs", "get_act", "set_act", "get_state", "stats",
+                         "readme_iteration", "readme_iteration", "eval_observed", "state_set", "state_copy",
+                         "assign_back", "policy_reset", "view_write"])
         if op == "observe_host":
             w.vector.observe(device, w.env, w.params, w.state, obs_host, w.rng)
             obs_dev = oracle.observe(w.cfg, w.seed, epoch, w.offset, w.P, S); epoch += 1
@@ -524,7 +532,49 @@ def test_random_api_sequences_against_a_shadow_model(device, oracle, weights, n)
         elif op == "stats":
             assert np.array_equal(w.env.returns(), w.st.returns) and np.array_equal(w.env.episode_steps(), w.st.steps)
             assert np.array_equal(w.env.finished_counts(), w.st.fin_counts)
+        elif op == "readme_iteration":
+            # README.md:96-99 as written: the path the observation cache, the speculative policy step and the shared
+            # state buffers (round 3) serve - here with everything else of the API in between
+            for _ in range(int(rng.integers(1, 4))):
+                w.vector.observe(device, w.env, w.params, w.state, obs_host, w.rng)
+                obs_dev = oracle.observe(w.cfg, w.seed, epoch, w.offset, w.P, S); epoch += 1
+                assert np.array_equal(obs_host, obs_dev), (it, op)
+                a = w.policy.evaluate_step(obs_host[:, :22])
+                ref = oracle.actor_batch_step(weights, np.ascontiguousarray(obs_host[:, :22]), H)
+                assert np.max(np.abs(a - ref)) < 10 * ACTOR_TOL, (it, op)
+                w.vector.step(device, w.env, w.params, w.state, a, w.next_state, w.rng)
+                NS, r, term = oracle.step(w.cfg, w.P, S, a)          # the GPU's own action: env data stays bit-exact
+                oracle.stats_update(w.cfg, r, term, w.st)
+                assert np.array_equal(w.env.rewards(), r) and np.array_equal(w.env.terminated(), term), (it, op)
+                w.state.assign(w.next_state)
+                S = NS.copy()
+                act_dev = a
+        elif op == "eval_observed":
+            a = w.policy.evaluate_step(obs_host[:, :22])
+            ref = oracle.actor_batch_step(weights, np.ascontiguousarray(obs_host[:, :22]), H)
+            assert np.max(np.abs(a - ref)) < 10 * ACTOR_TOL, (it, op)
+        elif op == "state_set":
+            S = S.copy()
+            S[:, 0:3] += rng.uniform(-0.01, 0.01, (n, 3)).astype(np.float32)
+            w.state.set(S)
+        elif op == "state_copy":
+            import copy
+            if held is not None:
+                assert np.array_equal(held[0].numpy(), held[1]), (it, op)     # untouched by whatever happened since
+            held = (copy.copy(w.state), S.copy())
+        elif op == "assign_back":
+            w.next_state.assign(w.state)
+            NS = S.copy()
+        elif op == "policy_reset":
+            w.policy.reset()
+            H[:] = weights[2000:2016]
+        elif op == "view_write":
+            w.state.states[n // 2].position[1] += np.float32(0.125)            # README.md:74
+            S = S.copy()
+            S[n // 2, 1] += np.float32(0.125)
     assert np.array_equal(w.state.numpy(), S) and np.array_equal(w.next_state.numpy(), NS)
+    if held is not None:
+        assert np.array_equal(held[0].numpy(), held[1])
 
 
 def test_step_in_place_equals_out_of_place(device, oracle):
