@@ -93,6 +93,7 @@ _SIGNATURES = {
     "rq_device_launch_floor": [_vp, C.c_uint32, C.c_uint32, _fp],
     "rq_device_set_rollout_timing": [_vp, C.c_int],
     "rq_device_last_rollout_ms": [_vp, _fp],
+    "rq_device_last_rollout_waves": [_vp, C.c_void_p, C.c_uint32, _u32p],
     "rq_device_stream": [_vp, C.POINTER(_vp)],
     "rq_rng_create": [_vp, C.POINTER(_vp)],
     "rq_rng_destroy": [_vp],

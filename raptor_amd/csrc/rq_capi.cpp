@@ -637,6 +637,20 @@ RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
     return RQ_OK;
 }
 
+RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint32_t capacity, uint32_t* n_waves) {
+    RQ_REQUIRE(dev && n_waves, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(dev->k_timed, RQ_ERR_NOT_INITIALIZED,
+               "no fused rollout was launched on this device with rq_device_set_rollout_timing enabled");
+    *n_waves = dev->k_span_used;
+    if (records == nullptr) return RQ_OK;                 // size query
+    RQ_REQUIRE(capacity >= dev->k_span_used, RQ_ERR_SHAPE_MISMATCH, "records holds fewer than *n_waves entries");
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "tick records are 64-bit");
+    RQ_HIP(hipMemcpyAsync(records, dev->k_span, (size_t)dev->k_span_used * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, dev->stream));
+    RQ_HIP(hipStreamSynchronize(dev->stream));
+    return RQ_OK;
+}
+
 RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, float* us_per_launch) {
     RQ_REQUIRE(dev && us_per_launch, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(n > 0 && reps > 0, RQ_ERR_INVALID_ARGUMENT, "n and reps must be positive");

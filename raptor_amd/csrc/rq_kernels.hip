@@ -495,16 +495,42 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     asm volatile("" : "+v"(last_t_bits), "+v"(frozen_bits));
     bool last_t = last_t_bits != 0;
     const bool was_frozen = frozen_bits != 0;
-    // sample_initial_state for this lane's env, episode counter ep (out of line: rare, see rq_device_math.hpp)
-    auto resample = [&]() {
-        float fresh[27];
-        sample_state_outlined(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i],
-                              field(params, RQ_P_HOVER_RPM, ld)[i], field(params, RQ_P_ROTOR_POS, ld)[i],
-                              field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh);
-        y.load([&](int j) { return fresh[j]; });
-        LA01 = f32x2{fresh[17], fresh[18]}; LA23 = f32x2{fresh[19], fresh[20]};
+    // The next episode's initial state, sampled AHEAD of the episode end (round 3).  sample_initial_state of an env depends
+    // on (seed, episode counter, global env id, a few parameters) and on nothing the running episode computes, so it need
+    // not wait for the end: the 19 values that are not constants (position .. angular velocity, the disturbance) are kept
+    // in ACCUMULATION registers for every lane, and an env whose episode ends takes them with 19 register reads.  The
+    // sampler itself (six Philox blocks, sin / cos, Box-Muller: ~1 000 instructions, and at an episode end it used to run
+    // for the one or two lanes concerned while the other 62 waited - the slowest wave of a 20-step launch paid it three
+    // times, tools/wave_timeline.py) runs for ALL 64 lanes at once, and only when an ending env finds its values used
+    // up: `pre_mask` has a bit per lane whose parked values are for its current episode counter.  Lanes that still hold
+    // valid ones get the same values again (same counter, same function), so the refill is unconditional.
+    constexpr int kPre = 19;
+    float pre[kPre];
+    uint64_t pre_mask = 0;                       // wave-uniform
+    float hover_rpm = 0.0f;
+    if (AUTORESET) {
+        hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) f6[j] = fresh[21 + j];
+        for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(pre[j]));
+    }
+    auto refill = [&]() {                        // every lane: sample_initial_state for its episode counter ep
+        float fresh[27];
+        sample_state_outlined(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
+                              field(params, RQ_P_ROTOR_POS, ld)[i], field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[j]) : "v"(fresh[j]));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[13 + j]) : "v"(fresh[21 + j]));
+        pre_mask = ~0ull;
+    };
+    auto take_presampled = [&]() {               // this lane's env starts its next episode (its parked values are valid)
+        float fr[kPre];
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fr[j]) : "a"(pre[j]));
+        y.load([&](int j) { return j < 13 ? fr[j] : hover_rpm; });
+        LA01 = f32x2{0.0f, 0.0f}; LA23 = f32x2{0.0f, 0.0f};       // sample_state: last action 0, rotors at hover
+#pragma unroll
+        for (int j = 0; j < 6; ++j) f6[j] = fr[13 + j];
         ep += 1;
         dist_changed = true;
     };
@@ -512,9 +538,13 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         // An env left frozen by an earlier rollout WITHOUT auto-reset (its episode is over) starts its next
         // episode here, as every episode end under auto-reset does: re-sampled, policy state reset.  The
         // chained mode does the same before its first step (k_thaw_frozen).
-        if (was_frozen) resample();
         const uint64_t thaw = __builtin_amdgcn_ballot_w64(was_frozen);
-        if (thaw != 0) select_hidden_q(thaw, h0Q, hQ);
+        if (thaw != 0) {
+            refill();
+            if (was_frozen) take_presampled();
+            pre_mask &= ~thaw;
+            select_hidden_q(thaw, h0Q, hQ);
+        }
     }
     typename ACTOR::Carry carry;          // what the actor carries from one step into the next (ActorF32T::Carry)
     actor.prime(hQ, carry);
@@ -593,12 +623,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             last_d = done_code;
             if (ended) {
                 any_end = true;
-                if (AUTORESET) {
-                    resample();
-                    ds = make_disturbance(k, c.gravity, f6);
-                } else {
-                    frozen = true;
-                }
+                if (!AUTORESET) frozen = true;         // under auto-reset the next episode starts below
             }
         }
         if (RECORD) {   // reward and done code of this transition (the observation and action went out above)
@@ -608,9 +633,15 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rr, valid ? i * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8(done_code, rd, valid ? i : 0xFFFFFFFFu, 0, 0);
         }
-        if (AUTORESET) {   // policy reset of the envs whose episode ended: h <- initial_hidden_state
+        if (AUTORESET) {   // the envs whose episode ended: next initial state, h <- initial_hidden_state
             const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
             if (ended_mask != 0) {
+                if ((ended_mask & ~pre_mask) != 0) refill();          // wave-uniform; rare (see above)
+                if (ended) {
+                    take_presampled();
+                    ds = make_disturbance(k, c.gravity, f6);
+                }
+                pre_mask &= ~ended_mask;
                 select_hidden_q(ended_mask, h0Q, hQ);
                 actor.reset_carry(ended_mask, carry);
             }

@@ -71,7 +71,7 @@ class Device:
         return float(ms.value)
 
     def set_rollout_timing(self, enable):
-        """Kernel-level timing of fused rollouts (begin/end timestamps of the kernel itself; ~8 us per launch)."""
+        """Kernel-level timing of fused rollouts: every wave records the wall-clock ticks at which it came in and went out."""
         _lib.call("rq_device_set_rollout_timing", self._h, 1 if enable else 0)
 
     def last_rollout_ms(self):
@@ -79,6 +79,15 @@ class Device:
         ms = C.c_float()
         _lib.call("rq_device_last_rollout_ms", self._h, C.byref(ms))
         return float(ms.value)
+
+    def last_rollout_waves(self):
+        """(t_in, t_out, xcd) per wave of the most recent timed fused rollout; 100 MHz ticks, comparable within a die."""
+        n = C.c_uint32()
+        _lib.call("rq_device_last_rollout_waves", self._h, None, 0, C.byref(n))
+        rec = np.zeros((n.value, 2), np.uint64)
+        _lib.call("rq_device_last_rollout_waves", self._h, rec.ctypes.data, n.value, C.byref(n))
+        mask = np.uint64(0x0FFFFFFFFFFFFFFF)
+        return rec[:, 0] & mask, rec[:, 1] & mask, (rec[:, 1] >> np.uint64(60)).astype(np.int64) & 7
 
     def launch_floor(self, n, reps=200):
         """Average us per launch of back-to-back near-empty kernels on an n-thread grid (diagnostic)."""
