@@ -478,20 +478,22 @@ __device__ __forceinline__ void sample_state(const SampleCfg& c, uint64_t seed, 
     }
 }
 
-// Out-of-line variant for the fused kernel: an episode end is rare (about once per 500 steps per
-// env), so the re-sampling code (6 Philox blocks, sin/cos, Box-Muller) is kept out of the hot
-// loop's register allocation; out = [y(17), last_action(4), disturbance(6)].
-__device__ __attribute__((noinline)) void sample_state_outlined(const SampleCfg c, uint64_t seed, uint32_t episode,
+// What the fused kernel parks ahead of an episode end (k_rollout_fused): the 19 sampled values of sample_state that are
+// not constants - s[0..12] and the disturbance.  Out of line: the sampler (six Philox blocks, sin / cos, Box-Muller,
+// ~2 000 instructions) is kept out of the hot loop's register allocation; the result comes back in registers (a vector
+// return type - an out pointer or a struct goes through scratch memory: 7 KB written and read back per call of a wave).
+typedef float PreSample __attribute__((ext_vector_type(32)));       // a vector type: returned in v0..v31, no memory
+__device__ __attribute__((noinline)) PreSample sample_state_ahead(const SampleCfg c, uint64_t seed, uint32_t episode,
                                                                  uint64_t genv, float mass, float hover_rpm,
-                                                                 float pos0x, float pos0y, float* __restrict__ out) {
+                                                                 float pos0x, float pos0y) {
     float s[17], la[4], f[6];
     sample_state(c, seed, episode, genv, mass, hover_rpm, pos0x, pos0y, s, la, f);
+    PreSample out = {};
 #pragma unroll
-    for (int i = 0; i < 17; ++i) out[i] = s[i];
+    for (int i = 0; i < 13; ++i) out[i] = s[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[17 + i] = la[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) out[21 + i] = f[i];
+    for (int i = 0; i < 6; ++i) out[13 + i] = f[i];
+    return out;
 }
 
 // ------------------------------------------------------------------ actor --------------

@@ -514,13 +514,10 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(pre[j]));
     }
     auto refill = [&]() {                        // every lane: sample_initial_state for its episode counter ep
-        float fresh[27];
-        sample_state_outlined(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
-                              field(params, RQ_P_ROTOR_POS, ld)[i], field(params, (RQ_P_ROTOR_POS + 1), ld)[i], fresh);
+        const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
+                                                   field(params, RQ_P_ROTOR_POS, ld)[i], field(params, (RQ_P_ROTOR_POS + 1), ld)[i]);
 #pragma unroll
-        for (int j = 0; j < 13; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[j]) : "v"(fresh[j]));
-#pragma unroll
-        for (int j = 0; j < 6; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[13 + j]) : "v"(fresh[21 + j]));
+        for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[j]) : "v"(fresh[j]));
         pre_mask = ~0ull;
     };
     auto take_presampled = [&]() {               // this lane's env starts its next episode (its parked values are valid)
