@@ -192,9 +192,10 @@ RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
  * that dominate a 1-step launch).  Round 2 used hipExtLaunchKernel's begin / end events: they read ~8 us long. */
 RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
 RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
-/* The records themselves (a diagnostic: tools/wave_timeline.py): per wave of the most recent timed fused rollout,
- * records[2 w] = tick at which wave w came in, records[2 w + 1] = tick at which it went out in bits 0..59 and the die
- * (XCD) it ran on in bits 60..62; 100 MHz ticks, comparable within one die only.  `records` = NULL: *n_waves only. */
+/* The records themselves (a diagnostic: tools/wave_timeline.py): per wave w of the most recent timed fused rollout four
+ * ticks, records[4 w + 0] = the wave came in, [4 w + 1] = it went out (bits 0..59; bits 60..62 = the die (XCD) it ran on),
+ * [4 w + 2] = its first step was about to start, [4 w + 3] = its last step was done; 100 MHz, comparable within one die
+ * only.  `records` = NULL: *n_waves only; otherwise it holds 4 * capacity values. */
 RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint32_t capacity, uint32_t* n_waves);
 /* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
  * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves

@@ -60,7 +60,7 @@ struct rq_device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    unsigned long long* k_span = nullptr;        // device [k_span_waves][2]: per wave, in / out ticks of the last timed fused rollout
+    unsigned long long* k_span = nullptr;        // device [k_span_waves][4]: per wave, in / out / loop begin / loop end ticks of the last timed fused rollout
     uint32_t k_span_waves = 0, k_span_used = 0;
     double k_ticks_per_ms = 1e5;                 // wall clock rate (100 MHz on gfx950)
     bool k_timing = false;         // rq_device_set_rollout_timing
@@ -620,13 +620,13 @@ RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
                "no fused rollout was launched on this device with rq_device_set_rollout_timing enabled");
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     std::vector<unsigned long long> span;
-    try { span.resize((size_t)dev->k_span_used * 2); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    try { span.resize((size_t)dev->k_span_used * 4); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     RQ_HIP(hipMemcpyAsync(span.data(), dev->k_span, span.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, dev->stream));
     RQ_HIP(hipStreamSynchronize(dev->stream));
     unsigned long long first[8], last[8], longest = 0;
     for (int x = 0; x < 8; ++x) { first[x] = ~0ull; last[x] = 0; }
     for (uint32_t w = 0; w < dev->k_span_used; ++w) {
-        const unsigned long long in = span[2 * (size_t)w] & 0x0FFFFFFFFFFFFFFFull, out = span[2 * (size_t)w + 1];
+        const unsigned long long in = span[4 * (size_t)w] & 0x0FFFFFFFFFFFFFFFull, out = span[4 * (size_t)w + 1];
         const int x = (int)(out >> 60) & 7;
         first[x] = std::min(first[x], in);
         last[x] = std::max(last[x], out & 0x0FFFFFFFFFFFFFFFull);
@@ -646,7 +646,7 @@ RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint3
     RQ_REQUIRE(capacity >= dev->k_span_used, RQ_ERR_SHAPE_MISMATCH, "records holds fewer than *n_waves entries");
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "tick records are 64-bit");
-    RQ_HIP(hipMemcpyAsync(records, dev->k_span, (size_t)dev->k_span_used * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, dev->stream));
+    RQ_HIP(hipMemcpyAsync(records, dev->k_span, (size_t)dev->k_span_used * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, dev->stream));
     RQ_HIP(hipStreamSynchronize(dev->stream));
     return RQ_OK;
 }
@@ -1455,7 +1455,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
             if (dev->k_span_waves < waves) {
                 RQ_HIP(hipStreamSynchronize(dev->stream));
                 if (dev->k_span) { RQ_HIP(hipFree(dev->k_span)); dev->k_span = nullptr; dev->k_span_waves = 0; }
-                RQ_HIP(hipMalloc(&dev->k_span, (size_t)waves * 2 * sizeof(unsigned long long)));
+                RQ_HIP(hipMalloc(&dev->k_span, (size_t)waves * 4 * sizeof(unsigned long long)));
                 dev->k_span_waves = waves;
             }
             dev->k_span_used = waves;

@@ -645,8 +645,11 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         }
     }
     };
+    unsigned long long t_loop = 0, t_done = 0;
+    if (span != nullptr) t_loop = (unsigned long long)wall_clock64();
     if (sym_tau) rollout_loop(std::true_type{});
     else         rollout_loop(std::false_type{});
+    if (span != nullptr) t_done = (unsigned long long)wall_clock64();
 
     const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
     if (valid && commit) {
@@ -673,8 +676,11 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         __builtin_amdgcn_s_waitcnt(0);                // the wave's stores have left
         if (threadIdx.x == 0) {
             const unsigned long long xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;        // HW_REG_XCC_ID[3:0]
-            span[2 * (size_t)blockIdx.x] = t_in;
-            span[2 * (size_t)blockIdx.x + 1] = ((unsigned long long)wall_clock64() & 0x0FFFFFFFFFFFFFFFull) | (xcd << 60);
+            unsigned long long* rec = span + 4 * (size_t)blockIdx.x;
+            rec[0] = t_in;
+            rec[1] = ((unsigned long long)wall_clock64() & 0x0FFFFFFFFFFFFFFFull) | (xcd << 60);
+            rec[2] = t_loop;          // prologue issued (its loads may still be in flight), first step about to start
+            rec[3] = t_done;          // last step done, the epilogue's stores not yet issued
         }
     }
 }
@@ -827,7 +833,7 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
     if (b.n == 0 || n_steps == 0) return hipSuccess;
     const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
-    // span != nullptr: every wave leaves its (in, out | xcd << 60) wall-clock ticks at span[2 * workgroup]
+    // span != nullptr: every wave leaves (in, out | xcd << 60, loop begin, loop end) wall-clock ticks at span[4 * workgroup]
     // (rq_device_last_rollout_ms).  Round 2 took the kernel's begin / end from hipExtLaunchKernel events; calibrated under
     // rocprofv3 in one process, an event-carrying launch itself runs ~4 us longer than a plain one and the events read
     // ~4 us more on top.

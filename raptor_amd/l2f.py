@@ -81,13 +81,15 @@ class Device:
         return float(ms.value)
 
     def last_rollout_waves(self):
-        """(t_in, t_out, xcd) per wave of the most recent timed fused rollout; 100 MHz ticks, comparable within a die."""
+        """(t_in, t_out, xcd, t_first_step, t_last_step_done) per wave of the most recent timed fused rollout; 100 MHz
+        ticks, comparable within a die."""
         n = C.c_uint32()
         _lib.call("rq_device_last_rollout_waves", self._h, None, 0, C.byref(n))
-        rec = np.zeros((n.value, 2), np.uint64)
+        rec = np.zeros((n.value, 4), np.uint64)
         _lib.call("rq_device_last_rollout_waves", self._h, rec.ctypes.data, n.value, C.byref(n))
         mask = np.uint64(0x0FFFFFFFFFFFFFFF)
-        return rec[:, 0] & mask, rec[:, 1] & mask, (rec[:, 1] >> np.uint64(60)).astype(np.int64) & 7
+        return (rec[:, 0] & mask, rec[:, 1] & mask, (rec[:, 1] >> np.uint64(60)).astype(np.int64) & 7,
+                rec[:, 2] & mask, rec[:, 3] & mask)
 
     def launch_floor(self, n, reps=200):
         """Average us per launch of back-to-back near-empty kernels on an n-thread grid (diagnostic)."""

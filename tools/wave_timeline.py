@@ -28,18 +28,22 @@ for n_steps in args.steps:
     rows = []
     for _ in range(args.reps):
         sh.rollout(n_steps, "fused")
-        t_in, t_out, xcd = device.last_rollout_waves()
+        t_in, t_out, xcd, t_l0, t_l1 = device.last_rollout_waves()
         per = []
         for x in range(8):
             m = xcd == x
             if not m.any():
                 continue
             a, b = t_in[m].astype(np.int64), t_out[m].astype(np.int64)
+            l0, l1 = t_l0[m].astype(np.int64), t_l1[m].astype(np.int64)
             t0 = a.min()
             per.append((a.max() - t0, np.median(b - a), (b - a).min(), (b - a).max(), b.max() - b.min(), b.max() - t0,
-                        np.median(a - t0), int(m.sum())))
+                        np.median(a - t0), int(m.sum()), np.median(l0 - a), np.median(l1 - l0), np.median(b - l1),
+                        (l1 - l0).max() - np.median(l1 - l0)))
         rows.append(np.mean(per, axis=0))
     r = np.median(np.array(rows), axis=0)
     print(f"n_steps {n_steps:3d}: waves/die {r[7]:.0f} | arrival spread {r[0] * US:6.2f} us (median wave arrives {r[6] * US:5.2f} us after the first)"
           f" | one wave runs {r[1] * US:6.2f} us (min {r[2] * US:6.2f}, max {r[3] * US:6.2f}) | finish spread {r[4] * US:6.2f} us"
-          f" | first in -> last out {r[5] * US:6.2f} us")
+          f" | first in -> last out {r[5] * US:6.2f} us\n"
+          f"             median wave: prologue {r[8] * US:5.2f} us, steps {r[9] * US:6.2f} us, epilogue {r[10] * US:5.2f} us;"
+          f" slowest wave's steps take {r[11] * US:5.2f} us longer than the median's")
