@@ -504,12 +504,16 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     // times, tools/wave_timeline.py) runs for ALL 64 lanes at once, and only when an ending env finds its values used
     // up: `pre_mask` has a bit per lane whose parked values are for its current episode counter.  Lanes that still hold
     // valid ones get the same values again (same counter, same function), so the refill is unconditional.
+    // Only the builds with one wave per SIMD do this: the two-waves-per-SIMD builds have 256 registers per wave in all,
+    // every one of them an architected register; asking for accumulation registers splits that budget 128 + 128 and the
+    // hot loop spills (262 144 envs: 0.70 -> 0.55 of the peak).  There the second wave fills the time one spends sampling.
+    constexpr bool kAhead = AUTORESET && WavesPerSimd<ACTOR>::value == 1;
     constexpr int kPre = 19;
     float pre[kPre];
     uint64_t pre_mask = 0;                       // wave-uniform
     float hover_rpm = 0.0f;
-    if (AUTORESET) {
-        hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
+    if (AUTORESET) hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
+    if (kAhead) {
 #pragma unroll
         for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(pre[j]));
     }
@@ -522,8 +526,16 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     };
     auto take_presampled = [&]() {               // this lane's env starts its next episode (its parked values are valid)
         float fr[kPre];
+        if constexpr (kAhead) {
 #pragma unroll
-        for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fr[j]) : "a"(pre[j]));
+            for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fr[j]) : "a"(pre[j]));
+        } else {                                 // sampled here and now, for the lanes whose episode ended
+            const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
+                                                       field(params, RQ_P_ROTOR_POS, ld)[i],
+                                                       field(params, (RQ_P_ROTOR_POS + 1), ld)[i]);
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) fr[j] = fresh[j];
+        }
         y.load([&](int j) { return j < 13 ? fr[j] : hover_rpm; });
         LA01 = f32x2{0.0f, 0.0f}; LA23 = f32x2{0.0f, 0.0f};       // sample_state: last action 0, rotors at hover
 #pragma unroll
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         // chained mode does the same before its first step (k_thaw_frozen).
         const uint64_t thaw = __builtin_amdgcn_ballot_w64(was_frozen);
         if (thaw != 0) {
-            refill();
+            if constexpr (kAhead) refill();
             if (was_frozen) take_presampled();
             pre_mask &= ~thaw;
             select_hidden_q(thaw, h0Q, hQ);
@@ -633,7 +645,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         if (AUTORESET) {   // the envs whose episode ended: next initial state, h <- initial_hidden_state
             const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
             if (ended_mask != 0) {
-                if ((ended_mask & ~pre_mask) != 0) refill();          // wave-uniform; rare (see above)
+                if constexpr (kAhead) {
+                    if ((ended_mask & ~pre_mask) != 0) refill();      // wave-uniform; rare (see above)
+                }
                 if (ended) {
                     take_presampled();
                     ds = make_disturbance(k, c.gravity, f6);
