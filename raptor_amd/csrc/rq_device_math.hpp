@@ -755,6 +755,12 @@ struct ActorF32T {
                        "=&a"(c.g0[6]), "=&a"(c.g0[7]), "=&a"(c.g0[8]), "=&a"(c.g0[9]), "=&a"(c.g0[10]), "=&a"(c.g0[11])
                      : "v"(g[0][0]), "v"(g[0][1]), "v"(g[0][2]), "v"(g[0][3]), "v"(g[1][0]), "v"(g[1][1]), "v"(g[1][2]),
                        "v"(g[1][3]), "v"(g[2][0]), "v"(g[2][1]), "v"(g[2][2]), "v"(g[2][3]));
+        // The carried chains end here too, and what follows prime() is a branch (a loop's guard, the timing hook): the
+        // compiler counts the wait states an MFMA result needs along the fall-through path only - with the consumer (a
+        // register move of c.gnh) sunk behind the branch, the taken path read the result 4 wait states after the MFMA
+        // instead of 11, and tile 0's first step was garbage (round 3, noise + auto-reset build).  So the results are
+        // made final here, whatever comes next.
+        asm volatile("s_nop 15" : "+v"(c.gr), "+v"(c.gz), "+v"(c.gnh));
     }
     // envs of `mask` (bit 16 t + j) had their hidden state replaced by the initial one after the carry was computed
     __device__ __forceinline__ void reset_carry(uint64_t mask, Carry& c) const {

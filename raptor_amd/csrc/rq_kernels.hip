@@ -619,6 +619,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         f32x2 A01, A23;
         bool term;
         const float r = step_inplace<SYM>(c, k, ds, yn, a, A01, A23, term);
+        // the reward is wanted HERE: left to itself its arithmetic sinks below the episode-end block, which overwrites the
+        // state it reads - and the state then lives twice, nine copies per step
+        asm volatile("" :: "v"(r));
         bool ended = false;
         uint8_t done_code = 4;          // frozen: computed on a scratch copy, not committed
         if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)

@@ -840,6 +840,25 @@ def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle
 
 
 @pytest.mark.parametrize("autoreset", [False, True])
+@pytest.mark.parametrize("noise", ["position", "orientation", "linear_velocity", "angular_velocity", "all"])
+def test_first_fused_step_equals_chained_in_every_noise_build(device, oracle, noise, autoreset):
+    """One step from a fresh state, fused against chained, in the kernel builds the other tests reach only after many
+    steps.  The first step is the one that consumes what the fused kernel's prologue computes ahead (tile 0's recurrent
+    accumulators, ActorF32T::prime): round 3 had a build - noise + auto-reset - in which a register move of those
+    accumulators was scheduled behind the branch that follows the prologue, 4 wait states after the MFMA instead of 11,
+    and the first step of the 16 envs of every wave's tile 0 was garbage while every later step was right."""
+    groups = ["position", "orientation", "linear_velocity", "angular_velocity"] if noise == "all" else [noise]
+    kw = {"noise_" + g: 0.01 for g in groups}
+    for n in (64, 777):
+        a = World(device, oracle, n, seed=8, episode_step_limit=40, **kw)
+        b = World(device, oracle, n, seed=8, episode_step_limit=40, **kw)
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 1, "fused", autoreset)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 1, "chained", autoreset)
+        assert np.array_equal(a.state.numpy(), b.state.numpy()), n
+        assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n)), n
+
+
+@pytest.mark.parametrize("autoreset", [False, True])
 def test_rollout_fused_equals_chained_bit_exact(device, oracle, autoreset):
     kw = dict(seed=8, episode_step_limit=40, noise_position=0.01, noise_angular_velocity=0.05)
     a = World(device, oracle, 777, **kw)
