@@ -80,7 +80,10 @@ __device__ __forceinline__ void box_muller_fast(float u1, float u2, float& n0, f
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RQ_PK_MUL(d, a, b, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
 #define RQ_PK_FMA(d, a, b, c, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#define RQ_PK_ADD(d, a, b) asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+// d += b in place: the destination is a register pair the COMPILER last wrote (a load's return, a copy).  Used right
+// behind an MFMA batch, where a fresh asm destination may be given registers a just-issued MFMA still reads as its C operand
+// (7 wait states, which the compiler inserts for the instructions it can see - a load's return, a copy - and not for asm).
+#define RQ_PK_ACC(d, b) asm("v_pk_add_f32 %0, %0, %1" : "+v"(d) : "v"(b))
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat(float s) { return f32x2{s, s}; }
 // a pair whose low half is s and whose high half is never read (no instruction spent on it)
@@ -959,13 +962,14 @@ struct ActorF32T {
         if constexpr (PIPE) asm volatile("" : : "v"(c.gr), "v"(c.gz), "v"(c.gnh));
         // (a_0, a_1) and (a_2, a_3): (p@0 + p@1) + (p@2 + p@3), six packed adds (written out: the compiler split two of
         // them into scalar adds; the operands come out of LDS loads, whose waits the compiler places for asm as well)
-        f32x2 A01, A23, T01, T23;
-        RQ_PK_ADD(A01, (f32x2{R[0][0], R[0][1]}), (f32x2{R[1][0], R[1][1]}));
-        RQ_PK_ADD(A23, (f32x2{R[0][2], R[0][3]}), (f32x2{R[1][2], R[1][3]}));
-        RQ_PK_ADD(T01, (f32x2{R[2][0], R[2][1]}), (f32x2{R[3][0], R[3][1]}));
-        RQ_PK_ADD(T23, (f32x2{R[2][2], R[2][3]}), (f32x2{R[3][2], R[3][3]}));
-        RQ_PK_ADD(A01, A01, T01);
-        RQ_PK_ADD(A23, A23, T23);
+        // each sum accumulates IN PLACE on a pair the LDS load returned (RQ_PK_ACC): no asm destination is a fresh register
+        f32x2 A01 = {R[0][0], R[0][1]}, A23 = {R[0][2], R[0][3]}, T01 = {R[2][0], R[2][1]}, T23 = {R[2][2], R[2][3]};
+        RQ_PK_ACC(A01, (f32x2{R[1][0], R[1][1]}));
+        RQ_PK_ACC(A23, (f32x2{R[1][2], R[1][3]}));
+        RQ_PK_ACC(T01, (f32x2{R[3][0], R[3][1]}));
+        RQ_PK_ACC(T23, (f32x2{R[3][2], R[3][3]}));
+        RQ_PK_ACC(A01, T01);
+        RQ_PK_ACC(A23, T23);
         a[0] = A01[0]; a[1] = A01[1]; a[2] = A23[0]; a[3] = A23[1];
     }
 };
