@@ -72,3 +72,23 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+
+
+def listings(out_dir=None):
+    """gfx950 assembly listings of the kernel sources (hipcc -S, same flags as the build) -> [paths]; cached by the
+    sources' modification times.  What tools/mfma_hazard_lint.py and the instruction-mix tools read."""
+    out_dir = out_dir or os.path.join(CSRC, "_obj")
+    os.makedirs(out_dir, exist_ok=True)
+    newest = max(os.path.getmtime(os.path.join(CSRC, h) if not os.path.isabs(h) else h) for h in HEADERS + SOURCES)
+    out = []
+    for src in SOURCES:
+        if not src.endswith(".hip"):
+            continue
+        lst = os.path.join(out_dir, os.path.splitext(src)[0] + ".s")
+        if not os.path.exists(lst) or os.path.getmtime(lst) < newest:
+            cmd = [_hipcc()] + DEVICE_FLAGS + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", lst]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        out.append(lst)
+    return out

@@ -206,3 +206,18 @@ def test_split_f16_operand_image_reconstructs_the_weights():
             want = float(W2[i & 3, 4 * q + e - 4]) if (e >= 4 and (i >> 2) == 2) else 0.0
             got = float(hi[lane, e]) + float(lo[lane, e])
             assert abs(got - want) <= max(2.0 ** -21 * abs(want), 2.0 ** -25), (lane, e)
+
+
+def test_no_mfma_result_is_touched_before_it_is_final():
+    """tools/mfma_hazard_lint.py over the listings of both kernel sources: no instruction - inline asm or the compiler's
+    own, on any path out of the MFMA, a taken branch included - reads or overwrites an MFMA's destination earlier than
+    the wait states hipcc itself leaves on straight-line code.  Round 3 shipped (for two commits, caught by the GPU
+    tests) a build in which a register move of the fused kernel's carried accumulators sat behind the branch that follows
+    the prologue, 4 wait states after the MFMA: hipcc pads along the fall-through path only."""
+    import subprocess
+    import sys
+    from raptor_amd import build
+    paths = build.listings()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_hazard_lint.py")] + paths, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 hazard(s)" in r.stdout
