@@ -839,6 +839,29 @@ def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle
     assert a.env.finished_counts().min() >= 1                      # episodes ended and restarted on the way
 
 
+def test_kernel_level_timing_records_and_leaves_results_alone(device, oracle):
+    """rq_device_set_rollout_timing / rq_device_last_rollout_ms / rq_device_last_rollout_waves: every wave of a timed fused
+    rollout leaves four ticks in order (in <= first step <= last step done <= out) and the die it ran on; the duration is
+    plausible; the rollout's results are those of an untimed one."""
+    n = 70001                                        # the two-waves-per-SIMD build; 1 094 waves
+    a, b = World(device, oracle, n, seed=3), World(device, oracle, n, seed=3)
+    device.set_rollout_timing(True)
+    try:
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 20, "fused", True)
+        ms = device.last_rollout_ms()
+        t_in, t_out, xcd, t_first, t_last = device.last_rollout_waves()
+    finally:
+        device.set_rollout_timing(False)
+    b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 20, "fused", True)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert len(t_in) == (n + 63) // 64
+    assert np.all(t_in <= t_first) and np.all(t_first <= t_last) and np.all(t_last <= t_out)
+    assert xcd.min() >= 0 and xcd.max() <= 7 and len(np.unique(xcd)) == 8
+    assert 0.02 < ms < 2.0, ms
+    per_wave_us = (t_out - t_in).astype(np.float64) / 100.0          # 100 MHz ticks
+    assert per_wave_us.max() <= ms * 1e3 + 0.5 and per_wave_us.min() > 10.0
+
+
 @pytest.mark.parametrize("autoreset", [False, True])
 @pytest.mark.parametrize("noise", ["position", "orientation", "linear_velocity", "angular_velocity", "all"])
 def test_first_fused_step_equals_chained_in_every_noise_build(device, oracle, noise, autoreset):
