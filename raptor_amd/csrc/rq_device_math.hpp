@@ -81,8 +81,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RQ_PK_MUL(d, a, b, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
 #define RQ_PK_FMA(d, a, b, c, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(d) : "v"(a), "v"(b), "v"(c))
 // d += b in place: the destination is a register pair the COMPILER last wrote (a load's return, a copy).  Used right
-// behind an MFMA batch, where a fresh asm destination may be given registers a just-issued MFMA still reads as its C operand
-// (7 wait states, which the compiler inserts for the instructions it can see - a load's return, a copy - and not for asm).
+// behind an MFMA batch, where a fresh asm destination may be given registers a just-issued MFMA still reads as its C
+// operand.  (hipcc's own code overwrites such registers 0 .. 6 wait states behind a 16x16x4 f32 MFMA - the matrix unit has
+// read C by then - so this is tidiness, not a fix: tools/mfma_hazard_lint.py --notes.)
 #define RQ_PK_ACC(d, b) asm("v_pk_add_f32 %0, %0, %1" : "+v"(d) : "v"(b))
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat(float s) { return f32x2{s, s}; }

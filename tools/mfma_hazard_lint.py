@@ -8,7 +8,8 @@ the rule asks and reports
   RAW/WAW  a non-MFMA instruction (inline asm or not) that reads or writes the MFMA's destination earlier than
            PASSES + 2 wait states after it (8-pass 16x16 MFMAs: 10, what hipcc itself pads to);
   WAR      (with --notes; informational) a VALU instruction that writes a register the MFMA reads as its C operand
-           (C != D) earlier than 7 wait states after it (LLVM: SMFMA16x16ReadVgprVALUWarWaitStates).
+           (C != D) earlier than 7 wait states after it.  hipcc's own code does this at 0 .. 6 wait states in these very
+           listings (it pads this case for other MFMA shapes only), so it is not counted as a hazard.
 
 Wait states: one per instruction, N + 1 for `s_nop N`; `s_waitcnt` counts one (what it may stall for is not relied on).
     python tools/mfma_hazard_lint.py file.s [more.s]        exit status 1 when something is reported
