@@ -221,3 +221,14 @@ def test_no_mfma_result_is_touched_before_it_is_final():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_hazard_lint.py")] + paths, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "0 hazard(s)" in r.stdout
+
+
+def test_the_hazard_lint_sees_a_move_behind_a_taken_branch():
+    """The lint on a reduced rendition of the build it was written for: the move on the taken path (4 and 5 wait states behind
+    the MFMA) is reported, the padded variant is not."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_hazard_lint.py"),
+                        os.path.join(ROOT, "tests", "golden", "mfma_hazard_bad.s")], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "2 hazard(s)" in r.stdout and "bad_prime" in r.stdout and "good_prime" not in r.stdout
