@@ -257,6 +257,11 @@ def kernel_probe(device, n, reps):
                                      "data_phase_GBps": round(nb / (data_us * 1e-6) / 1e9, 1),
                                      "working_set_MB": round(nb / 1e6, 1),
                                      "resident_in_infinity_cache": bool(nb < 256 * 2 ** 20)}
+        if nb < 256 * 2 ** 20:
+            out[name]["note"] = ("launch-latency-bound at this size: the working set sits in the 256 MiB memory-side cache and "
+                                 f"{floor_us:.1f} of the {out[name]['us_per_launch']:.1f} us are what any launch on this grid costs; "
+                                 "`frac` is not a bandwidth statement here - the HBM-bound figure is kernels.n2097152."
+                                 + name + " (north_star's >= 0.6 of HBM on the step kernel holds there)")
     return out
 
 
