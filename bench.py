@@ -508,8 +508,10 @@ class GpuEngine:
         return Shard(self.device, n, offset, precision=self.precision)
 
     def synchronize(self):
-        self.device.synchronize()
-        self.torch.cuda.synchronize()     # hipDeviceSynchronize: every stream of the device, the library's own included
+        # hipDeviceSynchronize: every stream of the device, the library's own included - one wait, not two (a stream
+        # synchronize in front of it made the timed region 2.6 us longer: tools/region_split.py, "torch only" against
+        # "lib+torch")
+        self.torch.cuda.synchronize()
 
     def native_unique_id(self):
         from raptor_amd.distributed import NativeReturnsExchange
