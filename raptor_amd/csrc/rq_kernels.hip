@@ -670,26 +670,33 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     if (span != nullptr) t_done = (unsigned long long)wall_clock64();
 
     const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
+    // The stores go to the addresses the prologue loaded from, and left alone the compiler keeps those ~55 64-bit
+    // addresses alive through the whole loop - parked in accumulation registers: ~110 moves in, ~110 out, per launch.
+    // An env index it cannot see through makes it compute them again here (55 adds).
+    uint32_t ie = i;
+    asm volatile("" : "+v"(ie));
+    size_t lde = ld;                                  // likewise the field rows' scalar bases (they were kept in VGPR lanes)
+    asm volatile("" : "+s"(lde));
     if (valid && commit) {
-        y.store([&](int j, float v) { field(state, j, ld)[i] = v; });
-        field(state, (RQ_S_LAST_ACTION + 0), ld)[i] = LA01[0]; field(state, (RQ_S_LAST_ACTION + 1), ld)[i] = LA01[1];
-        field(state, (RQ_S_LAST_ACTION + 2), ld)[i] = LA23[0]; field(state, (RQ_S_LAST_ACTION + 3), ld)[i] = LA23[1];
+        y.store([&](int j, float v) { field(state, j, lde)[ie] = v; });
+        field(state, (RQ_S_LAST_ACTION + 0), lde)[ie] = LA01[0]; field(state, (RQ_S_LAST_ACTION + 1), lde)[ie] = LA01[1];
+        field(state, (RQ_S_LAST_ACTION + 2), lde)[ie] = LA23[0]; field(state, (RQ_S_LAST_ACTION + 3), lde)[ie] = LA23[1];
         if (dist_changed) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), ld)[i] = f6[j];
+            for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), lde)[ie] = f6[j];
         }
-        store_stats(st, i, s, any_end);
-        st.last_reward[i] = last_r;
-        st.last_terminated[i] = last_t ? 1 : 0;
-        st.last_done[i] = last_d;
+        store_stats(st, ie, s, any_end);
+        st.last_reward[ie] = last_r;
+        st.last_terminated[ie] = last_t ? 1 : 0;
+        st.last_done[ie] = last_d;
         if (AUTORESET) {
-            st.episode[i] = ep;
-            if (was_frozen) st.frozen[i] = 0;
+            st.episode[ie] = ep;
+            if (was_frozen) st.frozen[ie] = 0;
         }
-        if (frozen) st.frozen[i] = 1;
+        if (frozen) st.frozen[ie] = 1;
     }
-    if (valid && !commit && n_steps > 0) st.last_done[i] = 4;   // not stepped by this rollout (as k_step reports it)
-    store_hidden_q(hidden, ld, wave_base, __builtin_amdgcn_ballot_w64(valid && commit), hQ);
+    if (valid && !commit && n_steps > 0) st.last_done[ie] = 4;   // not stepped by this rollout (as k_step reports it)
+    store_hidden_q(hidden, lde, wave_base, __builtin_amdgcn_ballot_w64(valid && commit), hQ);
     if (span != nullptr) {
         __builtin_amdgcn_s_waitcnt(0);                // the wave's stores have left
         if (threadIdx.x == 0) {
