@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     if (AUTORESET) hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
     if (kAhead) {
 #pragma unroll
-        for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(pre[j]));
+        for (int j = 0; j < kPre; ++j) asm volatile("" : "=a"(pre[j]));    // named, not written: pre_mask = 0 says none is valid
     }
     auto refill = [&]() {                        // every lane: sample_initial_state for its episode counter ep
         const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
