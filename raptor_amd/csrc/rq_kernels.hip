@@ -473,12 +473,14 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
     load_hidden_q(hidden, ld, wave_base, b.n, hQ);
-    Stats s = load_stats(st, i);
+    // the running episode's return and length ride in registers; a FINISHED episode's record goes straight to memory when
+    // it ends (below): four values less to carry through the loop, five instructions less per step
+    float ep_ret = st.returns[i];
+    uint32_t ep_steps = st.steps[i];
     float last_r = st.last_reward[i];
     const uint8_t last_t_raw = st.last_terminated[i];
     uint8_t last_d = st.last_done[i];
     const uint8_t frozen_raw = st.frozen[i];
-    bool any_end = false, dist_changed = false;
     uint32_t ep = AUTORESET ? st.episode[i] : 0u;
     // the operand image (L2-resident after a die's first wave) is asked for AFTER the env's own fields: those come from
     // HBM / the memory-side cache and their latency is the long one
@@ -509,6 +511,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     // hot loop spills (262 144 envs: 0.70 -> 0.55 of the peak).  There the second wave fills the time one spends sampling.
     // (The two-wave bf16 build has the room: 6.45 -> 5.7 us per step of 262 144 envs with it.)
     constexpr bool kAhead = AUTORESET && (WavesPerSimd<ACTOR>::value == 1 || std::is_same<ACTOR, ActorBF16Lean>::value);
+    // the env index as the rare paths see it: opaque, so that the addresses they form are computed there and then instead of
+    // being kept through the loop (see the epilogue)
+    auto rare_index = [&]() { uint32_t r = i; asm volatile("" : "+v"(r)); return r; };
     constexpr int kPre = 19;
     float pre[kPre];
     uint64_t pre_mask = 0;                       // wave-uniform
@@ -519,8 +524,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         for (int j = 0; j < kPre; ++j) asm volatile("" : "=a"(pre[j]));    // named, not written: pre_mask = 0 says none is valid
     }
     auto refill = [&]() {                        // every lane: sample_initial_state for its episode counter ep
-        const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
-                                                   field(params, RQ_P_ROTOR_POS, ld)[i], field(params, (RQ_P_ROTOR_POS + 1), ld)[i]);
+        const uint32_t ir = rare_index();
+        const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[ir], hover_rpm,
+                                                   field(params, RQ_P_ROTOR_POS, ld)[ir], field(params, (RQ_P_ROTOR_POS + 1), ld)[ir]);
 #pragma unroll
         for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[j]) : "v"(fresh[j]));
         pre_mask = ~0ull;
@@ -541,8 +547,12 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         LA01 = f32x2{0.0f, 0.0f}; LA23 = f32x2{0.0f, 0.0f};       // sample_state: last action 0, rotors at hover
 #pragma unroll
         for (int j = 0; j < 6; ++j) f6[j] = fr[13 + j];
+        if (valid) {                                 // the new episode's disturbance: written now, not carried to the end
+            const uint32_t ir = rare_index();
+#pragma unroll
+            for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), ld)[ir] = fr[13 + j];
+        }
         ep += 1;
-        dist_changed = true;
     };
     if (AUTORESET) {
         // An env left frozen by an earlier rollout WITHOUT auto-reset (its episode is over) starts its next
@@ -631,11 +641,21 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
                 LA01 = f32x2{a[0], a[1]}; LA23 = f32x2{a[2], a[3]};
             }
             last_r = r; last_t = term;
-            ended = stats_update(c.episode_step_limit, r, term, s);
+            ep_ret += r;
+            ep_steps += 1;
+            ended = term || ep_steps >= c.episode_step_limit;
             done_code = term ? 1 : (ended ? 2 : 0);
             last_d = done_code;
             if (ended) {
-                any_end = true;
+                if (valid) {                           // lanes past the batch shadow env n - 1: they must not count twice
+                    const uint32_t ir = rare_index();
+                    st.fin_returns[ir] = ep_ret;
+                    st.fin_lengths[ir] = ep_steps;
+                    (void)__hip_atomic_fetch_add(&st.fin_counts[ir], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (term) (void)__hip_atomic_fetch_add(&st.fin_terminated[ir], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ep_ret = 0.0f;
+                ep_steps = 0;
                 if (!AUTORESET) frozen = true;         // under auto-reset the next episode starts below
             }
         }
@@ -681,11 +701,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         y.store([&](int j, float v) { field(state, j, lde)[ie] = v; });
         field(state, (RQ_S_LAST_ACTION + 0), lde)[ie] = LA01[0]; field(state, (RQ_S_LAST_ACTION + 1), lde)[ie] = LA01[1];
         field(state, (RQ_S_LAST_ACTION + 2), lde)[ie] = LA23[0]; field(state, (RQ_S_LAST_ACTION + 3), lde)[ie] = LA23[1];
-        if (dist_changed) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), lde)[ie] = f6[j];
-        }
-        store_stats(st, ie, s, any_end);
+        st.returns[ie] = ep_ret;
+        st.steps[ie] = ep_steps;
         st.last_reward[ie] = last_r;
         st.last_terminated[ie] = last_t ? 1 : 0;
         st.last_done[ie] = last_d;
