@@ -839,6 +839,35 @@ def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle
     assert a.env.finished_counts().min() >= 1                      # episodes ended and restarted on the way
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_fused_equals_chained_over_random_settings(device, oracle, case):
+    """Random batch size, episode limit, thresholds, noise, disturbance, precision-independent settings and chunking -
+    every one with many episode ends per env (the fused kernel's ahead-of-time sampling, its episode-end records written
+    from inside the loop and its rare-path addressing are what this is after): state, policy state and all episode
+    statistics agree bit for bit with the chain of API-granular kernels."""
+    r = np.random.default_rng(1000 + case)
+    n = int(r.choice([1, 63, 64, 65, 777, 4097, 20000]))
+    kw = dict(seed=int(r.integers(1, 1000)), episode_step_limit=int(r.integers(3, 60)),
+              termination_position=float(r.choice([0.2, 0.5, 1.0])))
+    if r.random() < 0.5:
+        kw.update(noise_position=0.01, noise_angular_velocity=0.05)
+    if r.random() < 0.5:
+        kw.update(disturbance_force_std=0.0, disturbance_torque_std=0.0)
+    autoreset = bool(r.random() < 0.8)
+    a, b = World(device, oracle, n, **kw), World(device, oracle, n, **kw)
+    total = 0
+    for _ in range(int(r.integers(2, 6))):
+        chunk = int(r.choice([1, 2, 3, 7, 20, 61, 150]))
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", autoreset)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", autoreset)
+        total += chunk
+    assert np.array_equal(a.state.numpy(), b.state.numpy()), (n, kw, total)
+    assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
+    for name in ("returns", "episode_steps", "finished_returns", "finished_lengths", "finished_counts",
+                 "finished_terminated", "rewards", "terminated", "done_codes", "frozen", "episode_index"):
+        assert np.array_equal(getattr(a.env, name)(), getattr(b.env, name)()), (name, n, kw, total)
+
+
 def test_kernel_level_timing_records_and_leaves_results_alone(device, oracle):
     """rq_device_set_rollout_timing / rq_device_last_rollout_ms / rq_device_last_rollout_waves: every wave of a timed fused
     rollout leaves four ticks in order (in <= first step <= last step done <= out) and the die it ran on; the duration is
