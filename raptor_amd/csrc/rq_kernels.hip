@@ -570,6 +570,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     actor.prime(hQ, carry);
     Disturbance ds = make_disturbance(k, c.gravity, f6);
     bool frozen = AUTORESET ? false : was_frozen;
+    uint32_t last_step = n_steps;                      // without auto-reset: the last step of this launch the env took
     // wave-uniform: no env of this wave distinguishes rotor spin-up from spin-down (see dynamics<SYM_TAU>)
     const bool sym_tau = __builtin_amdgcn_ballot_w64(k.itr != k.itf) == 0;
 
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             ended = term || ep_steps >= c.episode_step_limit;
             done_code = term ? 1 : (ended ? 2 : 0);
             last_d = done_code;
+            if (!AUTORESET) last_step = t;             // (an env that froze earlier in the launch reports 4: see below)
             if (ended) {
                 if (valid) {                           // lanes past the batch shadow env n - 1: they must not count twice
                     const uint32_t ir = rare_index();
@@ -690,6 +692,9 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     if (span != nullptr) t_done = (unsigned long long)wall_clock64();
 
     const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
+    // an env whose episode ended BEFORE the launch's last step sat out the rest of it: its last transition of this rollout is
+    // "not stepped" (4), as the chain of k_step launches reports it (found by the random-settings test, round 3)
+    if (!AUTORESET && n_steps > 0 && last_step + 1 != n_steps) last_d = 4;
     // The stores go to the addresses the prologue loaded from, and left alone the compiler keeps those ~55 64-bit
     // addresses alive through the whole loop - parked in accumulation registers: ~110 moves in, ~110 out, per launch.
     // An env index it cannot see through makes it compute them again here (55 adds).

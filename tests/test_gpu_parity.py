@@ -839,7 +839,7 @@ def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle
     assert a.env.finished_counts().min() >= 1                      # episodes ended and restarted on the way
 
 
-@pytest.mark.parametrize("case", range(8))
+@pytest.mark.parametrize("case", range(int(os.environ.get("RQ_RANDOM_CASES", "32"))))
 def test_fused_equals_chained_over_random_settings(device, oracle, case):
     """Random batch size, episode limit, thresholds, noise, disturbance, precision-independent settings and chunking -
     every one with many episode ends per env (the fused kernel's ahead-of-time sampling, its episode-end records written
