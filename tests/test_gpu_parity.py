@@ -841,7 +841,7 @@ def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("RQ_RANDOM_CASES", "32"))))
 def test_fused_equals_chained_over_random_settings(device, oracle, case):
-    """Random batch size, episode limit, thresholds, noise, disturbance, precision-independent settings and chunking -
+    """Random batch size, episode limit, thresholds, noise, disturbance, action history, actor precision, recording and chunking -
     every one with many episode ends per env (the fused kernel's ahead-of-time sampling, its episode-end records written
     from inside the loop and its rare-path addressing are what this is after): state, policy state and all episode
     statistics agree bit for bit with the chain of API-granular kernels."""
@@ -853,15 +853,29 @@ def test_fused_equals_chained_over_random_settings(device, oracle, case):
         kw.update(noise_position=0.01, noise_angular_velocity=0.05)
     if r.random() < 0.5:
         kw.update(disturbance_force_std=0.0, disturbance_torque_std=0.0)
+    if r.random() < 0.25:
+        kw.update(action_history_raw=1)
     autoreset = bool(r.random() < 0.8)
+    precision = str(r.choice(["fp32", "fp32", "bf16", "f16x2"]))
+    record = bool(r.random() < 0.4)
+    chunks = [int(r.choice([1, 2, 3, 7, 20, 61, 150])) for _ in range(int(r.integers(2, 6)))]
     a, b = World(device, oracle, n, **kw), World(device, oracle, n, **kw)
+    a.policy.set_precision(precision); b.policy.set_precision(precision)
+    ta = a.vector.Trajectory(a.env, sum(chunks)) if record else None
+    tb = b.vector.Trajectory(b.env, sum(chunks)) if record else None
     total = 0
-    for _ in range(int(r.integers(2, 6))):
-        chunk = int(r.choice([1, 2, 3, 7, 20, 61, 150]))
-        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", autoreset)
-        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", autoreset)
+    for chunk in chunks:
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", autoreset, trajectory=ta)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", autoreset, trajectory=tb)
         total += chunk
+    kw = dict(kw, precision=precision, record=record, autoreset=autoreset, chunks=chunks)
     assert np.array_equal(a.state.numpy(), b.state.numpy()), (n, kw, total)
+    if record:
+        A, B = ta.numpy(), tb.numpy()
+        assert np.array_equal(A["done"], B["done"]), (n, kw)
+        live = A["done"] != 4
+        for key in ("obs", "act", "rew"):
+            assert np.array_equal(A[key][live], B[key][live]), (key, n, kw)
     assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
     for name in ("returns", "episode_steps", "finished_returns", "finished_lengths", "finished_counts",
                  "finished_terminated", "rewards", "terminated", "done_codes", "frozen", "episode_index"):
