@@ -1138,6 +1138,37 @@ def test_trajectory_vs_oracle(device, oracle, weights):
     assert np.abs(w.state.numpy()[:, :13] - w.S[:, :13]).max() < 1e-4
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_resampled_states_follow_the_oracle_through_many_episodes(device, oracle, weights, case):
+    """Episode limits of 1 .. 4 steps over a 12-step recorded fused rollout: every env starts 3 .. 12 episodes, and the
+    state an episode starts from depends on (seed, episode counter, global env id) only - not on the actor - so the
+    observation recorded right after every episode end must be the oracle's: position and velocities bit for bit, the
+    rotation matrix to the sin / cos tolerance.  This is the ahead-of-time sampler's episode counter (refill, take, refill
+    again inside one launch and across launches) against the reference restatement, not against the chained kernels."""
+    r = np.random.default_rng(50 + case)
+    n = int(r.choice([64, 200, 777]))
+    limit = int(r.integers(1, 5))
+    seed = int(r.integers(1, 500))
+    w = World(device, oracle, n, seed=seed, episode_step_limit=limit, termination_enabled=0)
+    w.sync_oracle_to_gpu_state()
+    chunks = [int(c) for c in r.choice([1, 2, 3, 4, 6], size=4)]
+    T = sum(chunks)
+    tr = w.vector.Trajectory(w.env, T)
+    for c in chunks:
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, c, "fused", True, trajectory=tr)
+    ref = oracle.rollout_record(w.cfg, weights, seed, 0, 0, w.P, w.S, w.H, T, 1, w.st, 4)
+    G = tr.numpy()
+    assert np.array_equal(G["done"], ref["done"])
+    starts = np.nonzero(ref["done"][:-1, 0] >= 1)[0] + 1            # steps whose observation is of a fresh state
+    assert len(starts) >= T // limit - 1
+    for t in starts:
+        assert np.array_equal(G["obs"][t][:, 0:3], ref["obs"][t][:, 0:3]), t          # position
+        assert np.array_equal(G["obs"][t][:, 12:18], ref["obs"][t][:, 12:18]), t      # linear, angular velocity
+        assert np.abs(G["obs"][t][:, 3:12] - ref["obs"][t][:, 3:12]).max() < INIT_TOL * 4, t
+        assert np.array_equal(G["obs"][t][:, 18:22], np.zeros((n, 4), np.float32)), t  # previous action of a new episode
+    assert np.array_equal(w.env.episode_index(), w.st.episode)
+
+
 # ------------------------------------------------------------------------------ scale ------
 def test_sharding_invariance_and_determinism_at_full_size(device, oracle):
     """65 536 envs (BASELINE config 2): one batch == two half batches with global offsets,
