@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <mutex>
@@ -56,6 +57,13 @@ bool policy_registry(const void* pol, int op) {
 }  // namespace
 
 // ---------------------------------------------------------------------------- objects ---
+// Versions of params / state / policy objects and the ids of envs come from ONE counter: the caches below are keyed by
+// (address, version), and an address that is freed and handed out again must never meet a version it has carried before.
+static uint64_t fresh_version() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1, std::memory_order_relaxed) + 1;
+}
+
 struct rq_device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -92,6 +100,7 @@ struct rq_device {
     uint64_t oc_params_version = 0;
     const rq_state* oc_state[2] = {nullptr, nullptr};   // the state k_step wrote, and the one it was assigned to
     uint64_t oc_version[2] = {0, 0};
+    uint64_t oc_env_uid = 0;
     uint32_t oc_seq = 0;           // mailbox sequence number of the launch that fills the cache
     bool oc_in_alt = false;        // the field-major copy still sits in the env's obs_alt (not yet swapped in)
     // speculative policy step of the small-batch loop (round 3): the reference's loop hands the observation it was just
@@ -117,6 +126,7 @@ struct rq_rng {
 
 struct rq_env {
     rq_device* dev = nullptr;
+    uint64_t uid = fresh_version();   // what the device's caches know this env by, beside its address
     int ordinal = 0;            // copy: destruction must not dereference the parent (GC order is arbitrary)
     uint32_t n = 0, ld = 0;
     uint64_t offset = 0;
@@ -144,11 +154,11 @@ struct rq_env {
 
 // version: bumped by every library call that writes the buffer; exposed: the raw device pointer was handed out, the
 // library no longer knows when it is written (the observation cache then never applies)
-struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; uint64_t version = 1; bool exposed = false; };
+struct rq_params { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; uint64_t version = fresh_version(); bool exposed = false; };
 // rq_state buffers are copy-on-write (round 3): state.assign(next_state) makes the two objects SHARE one buffer, and the
 // next call that overwrites one of them (the following step writes next_state in full) gives it a fresh buffer from the
 // env's pool instead - the README loop's assign costs no copy command.  `refs` counts the objects on a buffer.
-struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; uint64_t version = 1; bool exposed = false;
+struct rq_state { rq_env* env = nullptr; int ordinal = 0; float* d = nullptr; uint64_t version = fresh_version(); bool exposed = false;
                   int* refs = nullptr; };
 
 struct rq_trajectory {
@@ -181,7 +191,7 @@ struct rq_policy {
     bool needs_reset = true;      // hidden must be (re)filled with initial_hidden_state before use
     float* hidden = nullptr;      // [16][ld]
     float* hidden_alt = nullptr;  // [16][ld]: where a speculative step leaves the next hidden state (swapped in on a hit)
-    uint64_t version = 1;         // bumped by every call that reads-and-writes or reconfigures the policy's state
+    uint64_t version = fresh_version();   // renewed by every call that reads-and-writes or reconfigures the policy's state
     float* obs = nullptr;         // [22][ld] staging for host observations
     float* act = nullptr;         // [4][ld]
 };
@@ -319,7 +329,7 @@ int ensure_mailbox(rq_device* dev) {
 void obs_cache_drop(rq_device* dev) { dev->oc_env = nullptr; dev->oc_state[0] = dev->oc_state[1] = nullptr; }
 
 bool obs_cache_holds(const rq_device* dev, const rq_env* env, const rq_params* params, const rq_state* state) {
-    if (dev->oc_env != env || env->obs_exposed || dev->oc_params != params || params->exposed || params->version != dev->oc_params_version ||
+    if (dev->oc_env != env || dev->oc_env_uid != env->uid || env->obs_exposed || dev->oc_params != params || params->exposed || params->version != dev->oc_params_version ||
         state->exposed)
         return false;
     for (int k = 0; k < 2; ++k)
@@ -420,7 +430,7 @@ const float* packed_of(const rq_policy* pol) {
 // batch, README.md:24) and apply a pending reset(): h <- initial_hidden_state.
 int policy_size(rq_policy* pol, uint32_t batch) {
     DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
-    pol->version += 1;            // every user of the hidden state comes through here: a speculation based on it is void
+    pol->version = fresh_version();            // every user of the hidden state comes through here: a speculation based on it is void
     if (pol->batch != batch || !pol->hidden) {
         RQ_REQUIRE(pol->batch == 0 || pol->needs_reset, RQ_ERR_SHAPE_MISMATCH,
                    "batch size changed without reset (hidden state is per batch element)");
@@ -862,7 +872,7 @@ RQ_API int rq_params_get(const rq_params* p, float* host_out) {
 }
 RQ_API int rq_params_set(rq_params* p, const float* host_in) {
     RQ_REQUIRE(p && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    p->version += 1;
+    p->version = fresh_version();
     return host_to_soa(p->env->dev, host_in, p->env->n, RQ_PARAM_DIM, p->env->ld, RQ_PARAM_DIM, p->d);
 }
 RQ_API int rq_params_device_ptr(const rq_params* p, float** dev_ptr) {
@@ -912,7 +922,7 @@ RQ_API int rq_state_assign(rq_state* dst, const rq_state* src) {
         state_release_buffer(dst);
         dst->d = src->d; dst->refs = src->refs; ++*dst->refs;
     }
-    dst->version += 1;
+    dst->version = fresh_version();
     rq_device* dev = dst->env->dev;                   // the cached observation of src is the observation of dst now
     if (dev->oc_state[0] == src && dev->oc_version[0] == src->version && !src->exposed) {
         dev->oc_state[1] = dst; dev->oc_version[1] = dst->version;
@@ -927,7 +937,7 @@ RQ_API int rq_state_set(rq_state* s, const float* host_in) {
     RQ_REQUIRE(s && host_in, RQ_ERR_INVALID_ARGUMENT, "null argument");
     { DeviceScope on_device(s->env->dev); int rc = on_device.rc; if (rc) return rc;
       rc = state_make_private(s, false); if (rc) return rc; }
-    s->version += 1;
+    s->version = fresh_version();
     return host_to_soa(s->env->dev, host_in, s->env->n, RQ_STATE_DIM, s->env->ld, RQ_STATE_DIM, s->d);
 }
 RQ_API int rq_state_device_ptr(const rq_state* s, float** dev_ptr) {
@@ -946,7 +956,7 @@ RQ_API int rq_sample_initial_parameters(rq_device* dev, rq_env* env, rq_params* 
     DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
     RQ_HIP(rq::launch_sample_params(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed,
                                     rng->param_epoch, params->d));
-    params->version += 1;
+    params->version = fresh_version();
     rng->param_epoch += 1;
     return RQ_OK;
 }
@@ -959,7 +969,7 @@ RQ_API int rq_sample_initial_state(rq_device* dev, rq_env* env, const rq_params*
     rc = state_make_private(state, false); if (rc) return rc;
     RQ_HIP(rq::launch_sample_state(dev->stream, batch_of(env), rq::sample_cfg(env->cfg), rng->seed, params->d,
                                    state->d, env->st));
-    state->version += 1;
+    state->version = fresh_version();
     return RQ_OK;
 }
 
@@ -1029,12 +1039,12 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
         if (rc) return rc;
     }
     obs_cache_drop(dev);
-    next_state->version += 1;
+    next_state->version = fresh_version();
     RQ_HIP_MB(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
                               next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
                               nullptr, nullptr, mb, cache_obs ? env->obs_alt : nullptr, rq::NoiseCfg{}, false, 0u, nullptr), dev, mb);
     if (cache_obs) {
-        dev->oc_env = env; dev->oc_params = params; dev->oc_params_version = params->version;
+        dev->oc_env = env; dev->oc_env_uid = env->uid; dev->oc_params = params; dev->oc_params_version = params->version;
         dev->oc_state[0] = next_state; dev->oc_version[0] = next_state->version;
         dev->oc_state[1] = nullptr;
         dev->oc_seq = mb.seq;
@@ -1109,7 +1119,7 @@ RQ_API int rq_env_reset_statistics(rq_env* env) {
 // ---------------------------------------------------------------------------- Policy ----
 // (re)build the effective parameters and both MFMA operand images, and upload them
 static int policy_upload(rq_policy* p) {
-    p->version += 1;
+    p->version = fresh_version();
     std::memcpy(p->w_eff, p->w_host, sizeof(p->w_eff));
     if (p->standardize) {
         // Standardize (x - mean) / std followed by Dense folds into the Dense:
@@ -1198,7 +1208,7 @@ RQ_API int rq_policy_pack_image(const float* weights, size_t n_weights, int prec
 
 RQ_API int rq_policy_set_precision(rq_policy* pol, int precision) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    pol->version += 1;
+    pol->version = fresh_version();
     RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA || precision == RQ_POLICY_F16X2_MFMA,
                RQ_ERR_INVALID_ARGUMENT, "unknown precision");
     pol->precision = precision;
@@ -1221,7 +1231,7 @@ RQ_API int rq_policy_set_standardize(rq_policy* pol, const float* mean, const fl
 
 RQ_API int rq_policy_set_squash(rq_policy* pol, int enable) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    pol->version += 1;
+    pol->version = fresh_version();
     pol->sas_mode = enable ? RQ_SAS_MEAN : RQ_SAS_OFF;
     return RQ_OK;
 }
@@ -1229,7 +1239,7 @@ RQ_API int rq_policy_set_squash(rq_policy* pol, int enable) {
 RQ_API int rq_policy_set_sample_and_squash(rq_policy* pol, int mode, const float* log_std_weights, const float* log_std_bias,
                                     uint64_t seed) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    pol->version += 1;
+    pol->version = fresh_version();
     RQ_REQUIRE(mode == RQ_SAS_OFF || mode == RQ_SAS_MEAN || mode == RQ_SAS_SAMPLE, RQ_ERR_INVALID_ARGUMENT, "unknown mode");
     if (mode == RQ_SAS_SAMPLE) {
         DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
@@ -1247,7 +1257,7 @@ RQ_API int rq_policy_set_sample_and_squash(rq_policy* pol, int mode, const float
 
 RQ_API int rq_policy_reset(rq_policy* pol) {
     RQ_REQUIRE(pol, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    pol->version += 1;
+    pol->version = fresh_version();
     DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
     pol->needs_reset = true;   // applied (h <- initial_hidden_state, checkpoint.h:123) on the next use
     pol->sas_counter = 0;
@@ -1280,7 +1290,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
                 rc = mailbox_wait(dev, dev->sp_seq); if (rc) return rc;
                 std::memcpy(action, dev->mb_act, (size_t)batch * RQ_ACTION_DIM * sizeof(float));
                 std::swap(pol->hidden, pol->hidden_alt);       // the speculated step becomes the policy's state
-                pol->version += 1;
+                pol->version = fresh_version();
                 dev->sp_policy = nullptr;
                 dev->last_policy = pol;
                 return RQ_OK;
@@ -1533,7 +1543,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
     }
     rng->epoch += n_steps;
     if (traj) traj->length += n_steps;
-    if (n_steps) state->version += 1;
+    if (n_steps) state->version = fresh_version();
     return RQ_OK;
 }
 

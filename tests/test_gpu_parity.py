@@ -738,6 +738,31 @@ def test_observation_cache_of_the_small_batch_loop(device, oracle):
     assert np.array_equal(w.env.observation(), O.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S))
 
 
+def test_caches_do_not_survive_their_objects(device, oracle, weights):
+    """The small-batch loop's observation cache and speculative policy step are keyed by object identity and version.  A
+    destroyed env / state / policy frees its address for the next one: a fresh world built after an old one died must never
+    be answered from the old one's cache (versions are drawn from one global counter, so an address that comes back never
+    carries a version that was seen before)."""
+    import gc
+    for round_ in range(40):
+        w = World(device, oracle, 8, seed=100 + round_)
+        w.sync_oracle_to_gpu_state()
+        obs = np.zeros((8, 26), np.float32)
+        w.policy.reset()
+        H = np.tile(weights[2000:2016], (8, 1)).astype(np.float32)
+        for it in range(2):                                   # the second iteration is served from the cache and by speculation
+            w.vector.observe(device, w.env, w.params, w.state, obs, w.rng)
+            assert np.array_equal(obs, oracle.observe(w.cfg, w.seed, 0, w.offset, w.P, w.S)), (round_, it)
+            act = w.policy.evaluate_step(obs[:, :22])
+            ref = oracle.actor_batch_step(weights, np.ascontiguousarray(obs[:, :22]), H)
+            assert np.abs(act - ref).max() < 10 * ACTOR_TOL, (round_, it)
+            w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+            w.S, _, _ = oracle.step(w.cfg, w.P, w.S, act)
+            w.state.assign(w.next_state)
+        del w
+        gc.collect()
+
+
 def test_speculative_policy_step_is_invisible(device, oracle, weights):
     """Round 3: in the small-batch loop rq_step also launches the policy the device last evaluated on the observation
     it cached, and evaluate_step takes that result when it is called with bit-identical rows, the same policy and an
