@@ -490,14 +490,19 @@ void state_release_buffer(rq_state* s) {          // s lets go of its buffer
 // shared contents; otherwise (the call overwrites every field) any buffer will do.
 int state_make_private(rq_state* s, bool keep) {
     if (!s->refs || *s->refs == 1) return RQ_OK;
+    int* own = new (std::nothrow) int(1);              // everything that can fail first: s is untouched until it cannot
+    if (!own) return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     float* fresh = nullptr;
-    int rc = state_fresh_buffer(s->env, &fresh); if (rc) return rc;
-    if (keep)
-        RQ_HIP(hipMemcpyAsync(fresh, s->d, (size_t)RQ_STATE_DIM * s->env->ld * sizeof(float), hipMemcpyDeviceToDevice,
-                              s->env->dev->stream));
+    int rc = state_fresh_buffer(s->env, &fresh);
+    if (rc) { delete own; return rc; }
+    if (keep && hipMemcpyAsync(fresh, s->d, (size_t)RQ_STATE_DIM * s->env->ld * sizeof(float), hipMemcpyDeviceToDevice,
+                               s->env->dev->stream) != hipSuccess) {
+        delete own;
+        try { s->env->state_pool.push_back(fresh); } catch (...) { (void)hipFree(fresh); }
+        return fail(RQ_ERR_HIP, "state copy failed");
+    }
     --*s->refs;
-    s->refs = new (std::nothrow) int(1);
-    if (!s->refs) { s->env->state_pool.push_back(fresh); return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    s->refs = own;
     s->d = fresh;
     return RQ_OK;
 }
