@@ -66,7 +66,8 @@
 extern "C" {
 #endif
 
-#define RQ_ABI_VERSION 2   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m and the entry points added in round 2 */
+#define RQ_ABI_VERSION 2   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
+                              rounds 2 and 3 (the latter: rq_device_last_rollout_waves) */
 
 #if defined(__GNUC__)
 #define RQ_API __attribute__((visibility("default")))
