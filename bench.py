@@ -895,13 +895,77 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
     return result
 
 
+def engine_device_count(spec):
+    """GPUs this node offers the engine `spec` ('hip': rq_device_count of libraptor_quad.so - the HIP runtime's own
+    count, no torch involved; a stand-in module: its device_count())."""
+    if spec == "hip":
+        from raptor_amd import _lib
+        import ctypes
+        count = ctypes.c_int(0)
+        _lib.check(_lib.load().rq_device_count(ctypes.byref(count)))
+        return int(count.value)
+    import importlib
+    return int(importlib.import_module(spec).device_count())
+
+
+def spawn_local_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no RANK in the environment): this process
+    becomes the launcher - N copies of the same command line, one rank per GPU of this node (RANK = LOCAL_RANK = 0 ..
+    N-1, WORLD_SIZE = N, rendezvous on 127.0.0.1 at a free port), what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...` does.  Rank 0 inherits this process's stdout,
+    so its ONE JSON line stays the last line of stdout; the other ranks' stdout (RCCL / gloo banners) is sent to
+    stderr.  Any rank dying takes the job down (the others are killed by PID) and the exit status is non-zero.
+    More ranks than GPUs is an error, not a fallback - except under RQ_BENCH_DEVICE (tests: every rank on one
+    device).  -> exit status"""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = engine_device_count(args.engine)
+    if "RQ_BENCH_DEVICE" not in os.environ and n > have:
+        raise SystemExit(f"bench.py --gpus {n}: this node has {have} GPU(s) (engine '{args.engine}'); there is no "
+                         "fallback to fewer ranks")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+    status, alive = 0, set(range(n))
+    try:
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return status
+
+
 def main(argv=None):
     args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_local_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (launch with "
+                         f"`python bench.py --gpus {args.gpus}` or torch.distributed.run --nproc-per-node {args.gpus})")
     engine = make_engine(args.engine, local_rank, args)
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)

@@ -178,6 +178,30 @@ _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
+ABI_VERSION = 2
+
+
+class _EnvConfigAbi1(C.Structure):
+    """rq_env_config as ABI 1 (round 2) declared it: without the trailing action_history_raw"""
+    _fields_ = EnvConfig._fields_[:-1]
+    _field_names = frozenset(n for n, _ in EnvConfig._fields_[:-1])
+    __setattr__ = EnvConfig.__setattr__
+    as_dict = EnvConfig.as_dict
+
+
+_CONFIG_BY_ABI = {1: _EnvConfigAbi1, 2: EnvConfig}
+_config_type = EnvConfig
+
+
+def env_config_type():
+    """The rq_env_config struct of the LOADED library: EnvConfig, or - under RAPTOR_QUAD_ABI_ANY with an older build -
+    that ABI's struct; an ABI whose struct this package does not know is refused rather than handed a struct of the
+    wrong size."""
+    load()
+    if _config_type is None:
+        raise RaptorQuadError(-1, f"rq_env_config of ABI {_lib.rq_abi_version()} is unknown to this package (ABI "
+                                  f"{ABI_VERSION}): the environment configuration cannot be read or written")
+    return _config_type
 
 
 def _share_hip_runtime_with_torch():
@@ -215,13 +239,24 @@ def load():
                                       "(there is no fallback implementation)")
         _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
+        # RAPTOR_QUAD_ABI_ANY: same-box timing of an OLDER build (tools/ab_run.sh).  Only calls both versions share work:
+        # entry points the older library lacks are left unbound (calling one raises AttributeError at the call), and the
+        # rq_env_*_config calls, whose struct differs between ABI versions, are refused (_config_abi_guard)
+        any_abi = bool(os.environ.get("RAPTOR_QUAD_ABI_ANY"))
         for name, argtypes in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None:
+                if any_abi:
+                    continue
+                raise RaptorQuadError(-1, f"{LIB_PATH} does not export {name}: rebuild it (python -m raptor_amd.build)")
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
-        # RAPTOR_QUAD_ABI_ANY: same-box timing of an OLDER build (tools/ab_run.sh); only calls both versions share work
-        if lib.rq_abi_version() != 2 and not os.environ.get("RAPTOR_QUAD_ABI_ANY"):
-            raise RaptorQuadError(-1, "ABI version mismatch between raptor_amd and libraptor_quad.so")
+        abi = lib.rq_abi_version()
+        if abi != ABI_VERSION:
+            if not any_abi:
+                raise RaptorQuadError(-1, f"ABI version mismatch: raptor_amd speaks {ABI_VERSION}, {LIB_PATH} is {abi}")
+            global _config_type
+            _config_type = _CONFIG_BY_ABI.get(abi)      # None: the rq_env_*_config calls are refused (env_config_type)
         _lib = lib
     return _lib
 

@@ -232,7 +232,7 @@ class VectorModule:
             # --- configuration (the MDP constants initialize_environment fills) ---
             @property
             def config(self):
-                cfg = EnvConfig()
+                cfg = _lib.env_config_type()()
                 _lib.call("rq_env_get_config", self._require("environment"), C.byref(cfg))
                 return cfg
 

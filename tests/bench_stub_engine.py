@@ -81,6 +81,8 @@ class StubEngine:
     def __init__(self, local_rank, args):
         self.local_rank = local_rank
         self.rank = int(os.environ.get("RANK", "0"))
+        if os.environ.get("RQ_STUB_DIE_RANK") == str(self.rank):      # a rank that dies before the rendezvous
+            raise SystemExit(7)
         self.last_ms = 0.0
         self.timing = False
         self.t0 = 0.0
@@ -130,6 +132,11 @@ class StubEngine:
 
     def describe(self):
         return {"device": "stub (no GPU)", "hip_runtime": None}
+
+
+def device_count():
+    """GPUs the stand-in pretends this node has (bench.spawn_local_ranks refuses more ranks than that)"""
+    return int(os.environ.get("RQ_STUB_DEVICES", "8"))
 
 
 def create_engine(local_rank, args):

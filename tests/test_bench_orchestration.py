@@ -96,6 +96,48 @@ def test_single_process_has_nothing_to_gather():
     assert d["timing"]["statistic"] == "median"
 
 
+def _plain(args, extra_env=None, timeout=240):
+    """`python bench.py ...` as a user (or a driver that does not wrap the command) types it: no RANK / WORLD_SIZE"""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "tests.bench_stub_engine", "--backend", "gloo",
+                           "--no-cpu-baseline", "--envs-per-gpu", "64", *args], env=env, cwd=ROOT, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(300)
+def test_plain_command_with_gpus_2_launches_two_ranks_itself():
+    out = _plain(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-config4"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _json_line(out.stdout)                      # ONE record, the last line of the launcher's stdout
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 128 and d["config"]["gathered_returns"] == 128
+    assert d["config"]["exchange"].startswith("native RCCL")
+
+
+@pytest.mark.timeout(300)
+def test_plain_command_refuses_more_ranks_than_gpus():
+    out = _plain(["--gpus", "4", "--steps", "20", "--warmup", "5"], {"RQ_STUB_DEVICES": "2"})
+    assert out.returncode != 0 and "{" not in out.stdout
+    assert "this node has 2 GPU(s)" in out.stderr
+
+
+@pytest.mark.timeout(300)
+def test_plain_command_fails_when_a_rank_dies():
+    out = _plain(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-config4"], {"RQ_STUB_DIE_RANK": "1"}, timeout=120)
+    assert out.returncode != 0 and "rank 1 exited with status 7" in out.stderr
+    assert not [l for l in out.stdout.split("\n") if l.lstrip().startswith("{")]        # no record of a broken job
+
+
+def test_gpus_flag_must_match_the_launchers_world_size():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--engine", "tests.bench_stub_engine"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
 def test_effective_region_charges_the_exchange_share():
     import bench
     walls = [1.0] * 24 + [3.0] + [1.0] * 24 + [3.0] + [1.0] * 24 + [3.0]

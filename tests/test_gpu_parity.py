@@ -2091,6 +2091,42 @@ def test_bench_py_with_two_ranks_on_one_gpu(device, tmp_path):
           f"exchange share {d['timing']['exchange_share']}")
 
 
+@pytest.mark.timeout(900)
+def test_plain_bench_command_launches_its_own_ranks_on_the_gpu(device, tmp_path):
+    """`python bench.py --gpus 2` typed as is - no RANK / WORLD_SIZE, no torch.distributed.run around it (round 4): the command
+    re-executes itself as two local ranks (free port, LOCAL_RANK = rank), rank 0's record is the one line on the launcher's
+    stdout and says n_gpus 2.  Both ranks share this box's one GPU (RQ_BENCH_DEVICE) with the tests-only RCCL; without
+    RQ_BENCH_DEVICE the same command is an ERROR on a one-GPU box, not a silent one-rank run."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", os.path.join(root, "tests", "fake_rccl.cpp"), "-o", fake, "-lrt"],
+                   check=True, capture_output=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "5",
+           "--no-cpu-baseline", "--no-config4", "--envs-per-gpu", "8192"]
+    out = subprocess.run(cmd, env=dict(env, RQ_BENCH_DEVICE="0", RQ_RCCL_LIBRARY=fake), cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().split("\n") if l.strip()]
+    records = [l for l in lines if l.lstrip().startswith("{")]
+    assert len(records) == 1 and lines[-1] == records[0], lines[-5:]
+    d = json.loads(records[0])
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 16384 and d["config"]["engine"] == "hip"
+    assert d["config"]["exchange"].startswith("native RCCL") and d["config"]["gathered_returns"] == 16384
+    from raptor_amd import _lib
+    import ctypes
+    count = ctypes.c_int(0)
+    _lib.call("rq_device_count", ctypes.byref(count))
+    if count.value < 2:
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and f"this node has {count.value} GPU(s)" in out.stderr and "{" not in out.stdout
+
+
 # ------------------------------------------------------------------------------ teacher bank -
 def _teacher_weights(rng, n_teachers, in_dim, h1, h2):
     from raptor_amd.teachers import parameter_count
