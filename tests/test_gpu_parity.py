@@ -1619,10 +1619,12 @@ def test_closed_loop_statistics_against_the_reference_training_log_on_the_gpu(de
 
 
 def test_nominal_crazyflie_statistics_on_the_gpu(device, oracle):
-    """The second record of the reference's log (tests/test_closed_loop.py::REFERENCE_LOG_CRAZYFLIE) on the HIP path:
-    65 536 nominal Crazyflies, shipped policy.  The specification's own figures (about 1 % terminated after ~52 steps,
-    the log: 5 % after ~48) - a stated mismatch, DESIGN.md section 2 - and one of the single-constant candidates that
-    would close it (initial tilt up to 1.9 rad) as the HIP kernels compute them."""
+    """The second record of the reference's log (tests/test_closed_loop.py::REFERENCE_LOG_CRAZYFLIE: the pool of the last
+    100 epochs of the crazyflie/* tags, tests/golden/reference_log.json) on the HIP path: 65 536 nominal Crazyflies, shipped
+    policy.  The specification's own figures (about 1 % terminated after ~52 steps; the log: 3.4 % after 57) - a stated
+    mismatch, DESIGN.md section 2 - and the two single-constant candidates that survive the log's time-to-failure (round 4:
+    initial tilt up to 1.83 rad, force disturbance 0.16 m g) as the HIP kernels compute them; a tighter position threshold
+    reproduces the share and fails the time to failure here as in the oracle."""
     from test_closed_loop import REFERENCE_LOG_CRAZYFLIE as LOG
 
     def stats(**over):
@@ -1638,10 +1640,15 @@ def test_nominal_crazyflie_statistics_on_the_gpu(device, oracle):
     print(f"[nominal Crazyflie, HIP path] share terminated {share:.4f} (log {LOG['share_terminated']}), length {length:.1f} "
           f"(log {LOG['episode_length']}), terminated after {len_term:.1f} steps (log implies {LOG['terminated_episode_length_implied']})")
     assert 0.006 < share < 0.014 and 494.0 < length < 497.5, (share, length)
-    assert abs(len_term - LOG["terminated_episode_length_implied"]) < 10.0, len_term
-    assert abs(share - LOG["share_terminated"]) > 0.03          # the stated mismatch, on this path as well
-    share, length, _ = stats(init_max_angle=1.9)
-    assert abs(share - LOG["share_terminated"]) < 0.008 and abs(length - LOG["episode_length"]) < 4.0, (share, length)
+    assert abs(len_term - LOG["terminated_episode_length_implied"]) < 9.0, len_term
+    assert abs(share - LOG["share_terminated"]) > 0.015          # the stated mismatch, on this path as well
+    for over in (dict(init_max_angle=1.83), dict(disturbance_force_std=0.16)):
+        share, length, len_term = stats(**over)
+        print(f"[nominal Crazyflie, HIP path, {over}] {share:.4f} / {length:.1f} / terminated after {len_term:.1f}")
+        assert abs(share - LOG["share_terminated"]) < 0.009 and abs(length - LOG["episode_length"]) < 4.5, (over, share, length)
+        assert abs(len_term - LOG["terminated_episode_length_implied"]) < 6.0, (over, len_term)
+    share, length, len_term = stats(termination_position=0.8)
+    assert abs(share - LOG["share_terminated"]) < 0.009 and abs(len_term - LOG["terminated_episode_length_implied"]) > 12.0, (share, len_term)
 
 
 def test_action_history_raw_on_the_gpu(device, oracle):
