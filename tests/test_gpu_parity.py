@@ -1331,6 +1331,39 @@ def test_policy_from_checkpoint_header(device, weights, kat, tmp_path):
     assert pol.selftest(*pol.example, tolerance=ACTOR_TOL) < ACTOR_TOL
 
 
+def test_policy_from_the_references_own_hdf5_checkpoint(device, weights, tmp_path):
+    """SURVEY.md section 8(f) row 3 on the GPU (round 4): the reference's own `checkpoint.h5` (tests/golden/checkpoint.h5,
+    byte-identical to the file in the reference's tarball) is read by the dependency-free HDF5 reader
+    (h5:/actor/layers/{0,1,2}/*/parameters), runs on the HIP actor and reproduces the file's OWN known-answer pair
+    (h5:/example/{input,output}, 500 recurrent steps x 2) below 1e-5; saved and reloaded - as .h5 and as .h - the weights are
+    bit-identical and the reloaded policy computes bit-identical actions; `evaluate_sequence` on the example (the tensor
+    layout rl-tools evaluates) meets the same bar."""
+    from raptor_amd.foundation_policy import Raptor
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint.h5")
+    pol = Raptor.from_checkpoint(path, device)
+    assert np.array_equal(pol.weights, weights)                   # the .bin the other tests use was extracted from this file
+    x, y = pol.example
+    assert x.shape == (500, 2, 22) and y.shape == (500, 2, 4)
+    err = pol.selftest(x, y, tolerance=ACTOR_TOL)
+    assert err < ACTOR_TOL, err
+    pol.reset()
+    seq = pol.evaluate_sequence(x)
+    assert np.abs(seq - y).max() < ACTOR_TOL
+    pol.reset()
+    first = np.stack([pol.evaluate_step(x[t]) for t in range(25)])
+    assert np.abs(first - y[:25]).max() < ACTOR_TOL
+    for name in ("again.h5", "again.h"):
+        out = str(tmp_path / name)
+        pol.save_checkpoint(out)
+        back = Raptor.from_checkpoint(out, device)
+        assert np.array_equal(back.weights, pol.weights) and back.weights.tobytes() == pol.weights.tobytes()
+        assert np.array_equal(back.example[0], x) and np.array_equal(back.example[1], y)
+        back.reset()
+        again = np.stack([back.evaluate_step(x[t]) for t in range(25)])
+        assert np.array_equal(again, first), name
+    print(f"[checkpoint.h5 on the GPU] /example known-answer error {err:.2e}")
+
+
 # ------------------------------------------------------------------------------ errors -----
 def test_error_codes(device, oracle):
     import raptor_amd.l2f as l2f
