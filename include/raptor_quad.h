@@ -66,8 +66,9 @@
 extern "C" {
 #endif
 
-#define RQ_ABI_VERSION 2   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
-                              rounds 2 and 3 (the latter: rq_device_last_rollout_waves) */
+#define RQ_ABI_VERSION 3   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
+                              rounds 2 and 3 (the latter: rq_device_last_rollout_waves)
+                              3 (round 4): rq_device_{set,get}_speculation; no struct changed */
 
 #if defined(__GNUC__)
 #define RQ_API __attribute__((visibility("default")))
@@ -202,6 +203,18 @@ RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint3
  * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves
  * its own data (bench.py reports it beside the API-granular kernels' HBM fractions). */
 RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, float* us_per_launch);
+/* The small-batch loop's speculative policy step (README.md:96-99 at N < 1024 with host arrays): after a host-array
+ * evaluate_step, every rq_step with a host action ALSO launches the policy the device last evaluated on the observation
+ * the step just cached - next hidden state into a spare buffer of the policy, action rows into pinned memory - and the
+ * following evaluate_step takes that result iff it is handed bit-identical rows, the same policy and an untouched policy
+ * state.  Side effects a caller may see: one extra kernel launch per step on the device's stream, and the policy's
+ * device-side action buffer overwritten by the speculated step.  A caller whose loop has another shape (perturbed
+ * observations, alternating policies, env-only stepping) pays launches nobody uses: after 4 unused ones in a row the device
+ * suspends speculation by itself and resumes when evaluate_step is again handed exactly the cached rows; enable = 0
+ * switches it off for this device (RQ_NO_SPECULATION in the environment: off at rq_device_create), 1 on again.
+ * rq_device_get_speculation: any out pointer may be NULL. */
+RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
+RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* suspended, uint32_t* consecutive_misses);
 /* raw hipStream_t of the device, for callers that enqueue their own work behind ours */
 RQ_API int rq_device_stream(rq_device* dev, void** hip_stream);
 

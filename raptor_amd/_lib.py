@@ -94,6 +94,8 @@ _SIGNATURES = {
     "rq_device_set_rollout_timing": [_vp, C.c_int],
     "rq_device_last_rollout_ms": [_vp, _fp],
     "rq_device_last_rollout_waves": [_vp, C.c_void_p, C.c_uint32, _u32p],
+    "rq_device_set_speculation": [_vp, C.c_int],
+    "rq_device_get_speculation": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p],
     "rq_device_stream": [_vp, C.POINTER(_vp)],
     "rq_rng_create": [_vp, C.POINTER(_vp)],
     "rq_rng_destroy": [_vp],
@@ -178,7 +180,7 @@ _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class _EnvConfigAbi1(C.Structure):
@@ -189,7 +191,7 @@ class _EnvConfigAbi1(C.Structure):
     as_dict = EnvConfig.as_dict
 
 
-_CONFIG_BY_ABI = {1: _EnvConfigAbi1, 2: EnvConfig}
+_CONFIG_BY_ABI = {1: _EnvConfigAbi1, 2: EnvConfig, 3: EnvConfig}
 _config_type = EnvConfig
 
 

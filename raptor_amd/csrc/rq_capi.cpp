@@ -102,6 +102,7 @@ struct rq_device {
     uint64_t oc_version[2] = {0, 0};
     uint64_t oc_env_uid = 0;
     uint32_t oc_seq = 0;           // mailbox sequence number of the launch that fills the cache
+    uint32_t oc_n = 0;             // rows in the cache (the env itself may be gone by the time this is looked at)
     bool oc_in_alt = false;        // the field-major copy still sits in the env's obs_alt (not yet swapped in)
     // speculative policy step of the small-batch loop (round 3): the reference's loop hands the observation it was just
     // given straight to Raptor.evaluate_step (README.md:96-97).  rq_step therefore also launches the policy this device
@@ -113,8 +114,15 @@ struct rq_device {
     uint64_t sp_policy_version = 0;      // ... at this hidden-state version
     uint32_t sp_batch = 0, sp_seq = 0, sp_oc_seq = 0;
     float* mb_act = nullptr;             // pinned host rows [n][4] of the speculated action
-    bool speculate = true;               // RQ_NO_SPECULATION in the environment switches it off
+    bool speculate = true;               // rq_device_set_speculation; RQ_NO_SPECULATION in the environment: off at creation
+    // A speculated step nobody takes is a wasted launch on the latency-bound path (the caller perturbs the observation,
+    // alternates policies, only steps the env): after kSpeculationMissLimit of them in a row the device stops speculating,
+    // and resumes when evaluate_step is again called with exactly the rows the step cached (what a hit would have been).
+    bool sp_outstanding = false;         // a speculated step was launched and not taken (yet)
+    bool sp_suspended = false;
+    uint32_t sp_misses = 0;
 };
+constexpr uint32_t kSpeculationMissLimit = 4;
 
 struct rq_rng {
     rq_device* dev = nullptr;
@@ -321,8 +329,14 @@ int ensure_mailbox(rq_device* dev) {
     dev->mb_out = static_cast<float*>(out);
     dev->mb_obs = static_cast<float*>(obs);
     dev->mb_act = static_cast<float*>(actrows);
-    dev->speculate = std::getenv("RQ_NO_SPECULATION") == nullptr;
     return RQ_OK;
+}
+
+// a speculated policy step that was launched is about to be superseded or was passed over: count it
+void speculation_unused(rq_device* dev) {
+    if (!dev->sp_outstanding) return;
+    dev->sp_outstanding = false;
+    if (++dev->sp_misses >= kSpeculationMissLimit) dev->sp_suspended = true;
 }
 
 // ---- observation cache (rq_device::oc_*) ------------------------------------------------------------------
@@ -472,7 +486,12 @@ namespace {
 // whatever still reads it was enqueued before whatever will write it.
 int state_fresh_buffer(rq_env* env, float** out) {
     if (!env->state_pool.empty()) { *out = env->state_pool.back(); env->state_pool.pop_back(); return RQ_OK; }
-    RQ_HIP(hipMalloc(out, (size_t)RQ_STATE_DIM * env->ld * sizeof(float)));
+    const size_t bytes = (size_t)RQ_STATE_DIM * env->ld * sizeof(float);
+    RQ_HIP(hipMalloc(out, bytes));
+    // zeroed like rq_state_create's: the kernels write lanes < n only, and the padding lanes n .. ld-1 are visible to
+    // whoever holds rq_state_device_ptr (a torch view over [27][ld])
+    const hipError_t e = hipMemsetAsync(*out, 0, bytes, env->dev->stream);
+    if (e != hipSuccess) { (void)hipFree(*out); *out = nullptr; return fail(RQ_ERR_HIP, "state_fresh_buffer: hipMemsetAsync failed"); }
     return RQ_OK;
 }
 
@@ -568,7 +587,24 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
         delete d;
         return fail(RQ_ERR_HIP, "rq_device_create: stream/event creation failed");
     }
+    d->speculate = std::getenv("RQ_NO_SPECULATION") == nullptr;
     *out = d;
+    return RQ_OK;
+}
+
+RQ_API int rq_device_set_speculation(rq_device* dev, int enable) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    dev->speculate = enable != 0;
+    dev->sp_suspended = false; dev->sp_misses = 0;
+    if (!dev->speculate) { dev->sp_policy = nullptr; dev->sp_outstanding = false; }
+    return RQ_OK;
+}
+
+RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* suspended, uint32_t* consecutive_misses) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (enabled) *enabled = dev->speculate ? 1 : 0;
+    if (suspended) *suspended = dev->sp_suspended ? 1 : 0;
+    if (consecutive_misses) *consecutive_misses = dev->sp_misses;
     return RQ_OK;
 }
 
@@ -1052,10 +1088,11 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
         dev->oc_env = env; dev->oc_env_uid = env->uid; dev->oc_params = params; dev->oc_params_version = params->version;
         dev->oc_state[0] = next_state; dev->oc_version[0] = next_state->version;
         dev->oc_state[1] = nullptr;
-        dev->oc_seq = mb.seq;
+        dev->oc_seq = mb.seq; dev->oc_n = env->n;
         dev->oc_in_alt = true;
         // speculative policy step on the observation just cached (see rq_device::sp_*): never an error of this call
-        rq_policy* pol = dev->speculate && action ? dev->last_policy : nullptr;
+        speculation_unused(dev);             // the previous step's, if nobody took it
+        rq_policy* pol = dev->speculate && !dev->sp_suspended && action ? dev->last_policy : nullptr;
         dev->sp_policy = nullptr;
         if (pol && policy_registry(pol, 0) && pol->dev == dev && pol->batch == env->n && pol->ld == env->ld && pol->hidden &&
             pol->hidden_alt && !pol->needs_reset && pol->sas_mode != RQ_SAS_SAMPLE) {
@@ -1066,6 +1103,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             if (e == hipSuccess) {
                 dev->sp_policy = pol; dev->sp_policy_version = pol->version; dev->sp_batch = env->n;
                 dev->sp_seq = smb.seq; dev->sp_oc_seq = dev->oc_seq;
+                dev->sp_outstanding = true;
             } else {
                 mailbox_abort(dev, smb);
             }
@@ -1298,8 +1336,20 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
                 pol->version = fresh_version();
                 dev->sp_policy = nullptr;
                 dev->last_policy = pol;
+                dev->sp_outstanding = false; dev->sp_misses = 0;
                 return RQ_OK;
             }
+        }
+        speculation_unused(dev);
+        if (dev->sp_suspended && dev->speculate && dev->last_policy == pol && dev->oc_env && batch == dev->oc_n &&
+            mailbox_wait(dev, dev->oc_seq) == RQ_OK) {
+            // suspended after a run of misses: this call is what a hit looks like (the rows the last step cached, handed
+            // to the policy that was evaluated before it) - the loop is back in the reference's shape, speculate again
+            bool same = true;
+            for (uint32_t i = 0; i < batch && same; ++i)
+                same = std::memcmp(observation + (size_t)i * obs_stride, dev->mb_obs + (size_t)i * RQ_OBSERVATION_DIM,
+                                   RQ_POLICY_INPUT_DIM * sizeof(float)) == 0;
+            if (same) { dev->sp_suspended = false; dev->sp_misses = 0; }
         }
         dev->sp_policy = nullptr;
         dev->last_policy = pol;         // the policy rq_step will speculate with

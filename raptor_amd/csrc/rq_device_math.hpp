@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void sample_and_squash(const SasArgs& sas, uint32_t e
 
 // Q-layout addressing helpers for a wave whose first env is wave_base: tile t of lane (q,j) is
 // env wave_base + 16 t + j (clamped to the batch), hidden feature 4q + r.
-__device__ __forceinline__ void load_hidden_q(const float* __restrict__ hidden, size_t ld, uint32_t wave_base,
+__device__ __forceinline__ void load_hidden_q(const float* hidden, size_t ld, uint32_t wave_base,
                                               uint32_t n, float (&hQ)[4][4]) {
     const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
 #pragma unroll
@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void load_hidden_q(const float* __restrict__ hidden, 
     }
 }
 // commit_mask: bit (16 t + j) set = env (t, j) of this wave may be written
-__device__ __forceinline__ void store_hidden_q(float* __restrict__ hidden, size_t ld, uint32_t wave_base,
+__device__ __forceinline__ void store_hidden_q(float* hidden, size_t ld, uint32_t wave_base,
                                                uint64_t commit_mask, const float (&hQ)[4][4]) {
     const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
 #pragma unroll

@@ -131,7 +131,7 @@ template <typename ACTOR>
 __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
                                                        const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
-                                                       const float* __restrict__ hidden_in, float* __restrict__ hidden,
+                                                       const float* hidden_in, float* hidden,   // the same buffer unless speculative
                                                        uint32_t ld_h, float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen, SasArgs sas,
                                                        Mailbox mb) {

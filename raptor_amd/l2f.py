@@ -97,6 +97,17 @@ class Device:
         _lib.call("rq_device_launch_floor", self._h, int(n), int(reps), C.byref(us))
         return float(us.value)
 
+    def set_speculation(self, enable):
+        """The small-batch loop's speculative policy step (rq_device_set_speculation, include/raptor_quad.h): off / on
+        for this device.  Left on, the device suspends it by itself after four speculated steps in a row nobody took."""
+        _lib.call("rq_device_set_speculation", self._h, 1 if enable else 0)
+
+    def speculation(self):
+        """-> {"enabled", "suspended", "consecutive_misses"}"""
+        e, s, m = C.c_int(), C.c_int(), C.c_uint32()
+        _lib.call("rq_device_get_speculation", self._h, C.byref(e), C.byref(s), C.byref(m))
+        return {"enabled": bool(e.value), "suspended": bool(s.value), "consecutive_misses": int(m.value)}
+
     @property
     def stream(self):
         s = C.c_void_p()

@@ -477,8 +477,11 @@ def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
         op = rng.choice(["observe_host", "observe_dev", "eval_host_host", "eval_dev_dev", "step_host", "step_dev",
                          "step_inplace", "assign", "get_obs", "get_act", "set_act", "get_state", "stats",
                          "readme_iteration", "readme_iteration", "eval_observed", "state_set", "state_copy",
-                         "assign_back", "policy_reset", "view_write"])
-        if op == "observe_host":
+                         "assign_back", "policy_reset", "view_write", "speculation_toggle"])
+        if op == "speculation_toggle":                 # round 4: rq_device_set_speculation, in every state of the mechanism
+            device.set_speculation(bool(rng.integers(0, 2)))
+            assert device.speculation()["consecutive_misses"] == 0
+        elif op == "observe_host":
             w.vector.observe(device, w.env, w.params, w.state, obs_host, w.rng)
             obs_dev = oracle.observe(w.cfg, w.seed, epoch, w.offset, w.P, S); epoch += 1
             assert np.array_equal(obs_host, obs_dev), (it, op)
@@ -575,6 +578,7 @@ def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
     assert np.array_equal(w.state.numpy(), S) and np.array_equal(w.next_state.numpy(), NS)
     if held is not None:
         assert np.array_equal(held[0].numpy(), held[1])
+    device.set_speculation(True)
 
 
 def test_step_in_place_equals_out_of_place(device, oracle):
@@ -825,6 +829,48 @@ def test_speculative_policy_step_is_invisible(device, oracle, weights):
         b.vector.step_device(device, b.env, b.params, b.state, b.state, b.rng)
     assert np.array_equal(a.state.numpy(), b.state.numpy())
     assert np.array_equal(a.policy.hidden_state(8), b.policy.hidden_state(8))
+
+
+def test_speculation_backs_off_when_nobody_takes_it_and_resumes(device, oracle):
+    """Round 4 (advisor finding): a caller whose loop is not the reference's - here: it perturbs the observation before the
+    policy sees it - used to pay one speculated policy launch per step for nothing.  After four unused speculations in a row
+    the device suspends them; the first evaluate_step that is again handed exactly the cached rows resumes them, and the one
+    after that is a hit.  rq_device_set_speculation switches the mechanism per device.  Whatever state the mechanism is in,
+    the numbers are those of a twin driven with the same inputs on a device that never speculates, bit for bit."""
+    import raptor_amd.l2f as l2f
+    plain = l2f.Device(0)
+    plain.set_speculation(False)
+    assert plain.speculation() == {"enabled": False, "suspended": False, "consecutive_misses": 0}
+    device.set_speculation(True)
+    a, b = World(device, oracle, 8, seed=41), World(plain, oracle, 8, seed=41)
+    a.policy.reset(); b.policy.reset()
+    oa, ob = np.zeros((8, 26), np.float32), np.zeros((8, 26), np.float32)
+    states = []
+    for it in range(20):
+        perturb = 4 <= it < 11
+        acts = []
+        for w, o in ((a, oa), (b, ob)):
+            w.vector.observe(w.device, w.env, w.params, w.state, o, w.rng)
+            x = np.ascontiguousarray(o[:, :22])
+            if perturb:
+                x[it % 8, it % 22] += np.float32(1e-3)
+            act = w.policy.evaluate_step(x)
+            w.vector.step(w.device, w.env, w.params, w.state, act, w.next_state, w.rng)
+            w.state.assign(w.next_state)
+            acts.append(act)
+        assert np.array_equal(acts[0], acts[1]), it
+        states.append(device.speculation())
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(8), b.policy.hidden_state(8))
+    assert all(not st["suspended"] and st["consecutive_misses"] == 0 for st in states[1:4]), states[:4]
+    assert [st["consecutive_misses"] for st in states[4:8]] == [1, 2, 3, 4] and states[7]["suspended"], states[4:8]
+    assert all(st["suspended"] for st in states[7:11]), states[7:11]            # no further launches, no further misses
+    assert states[10]["consecutive_misses"] == 4
+    assert not states[11]["suspended"] and states[11]["consecutive_misses"] == 0       # the cached rows again: resumed
+    assert all(not st["suspended"] and st["consecutive_misses"] == 0 for st in states[12:]), states[12:]
+    device.set_speculation(False)
+    assert device.speculation()["enabled"] is False
+    device.set_speculation(True)
 
 
 def test_device_resident_chain_equals_host_chain(device, oracle):
