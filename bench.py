@@ -127,16 +127,34 @@ class Shard:
                             autoreset=True)
 
 
+def actor_groups_per_wave(n):
+    """raptor_amd/csrc/rq_kernels.hpp actor_groups_per_wave: 64-env groups per wave of k_actor_step at n envs"""
+    groups = (n + 63) // 64
+    return 32 if groups >= 16384 else (4 if groups >= 4096 else 1)
+
+
+def actor_step_kernel_name(n, actor="rq::ActorF32T<true>"):
+    """The k_actor_step instantiation launch_actor_step picks at n envs, as rocprofv3 prints it (the streaming form - several
+    groups per wave - and the one-group form are two kernels: their names tell a 2 097 152-env launch from a 65 536-env one
+    even where the grids coincide)."""
+    return f"rq::k_actor_step<{actor}, {'true' if actor_groups_per_wave(n) > 1 else 'false'}>"
+
+
 def launch_grid(kernel, n):
-    """Threads in the grid the launcher picks for `kernel` at n envs (raptor_amd/csrc/rq_kernels.hip): the committed
-    PMC tables are keyed by grid size, which is not the env count for k_actor_step (several 64-env groups per wave)."""
+    """Threads in the grid the launcher picks for `kernel` at n envs (raptor_amd/csrc/rq_kernels.hip)."""
     if kernel.startswith("rq::k_actor_step"):
         groups = (n + 63) // 64
-        gpw = 8 if groups >= 16384 else (4 if groups >= 4096 else 1)
+        gpw = actor_groups_per_wave(n)
         return ((groups + gpw - 1) // gpw * 64 + 255) // 256 * 256
     if kernel.startswith(("rq::k_rollout_fused", "rq::k_actor_sequence", "rq::k_actor_relabel")):
         return (n + 63) // 64 * 64
     return (n + 255) // 256 * 256
+
+
+def pmc_key(kernel, n):
+    """Key of a kernel's entry in profiles/*_pmc.json: (instantiation, env count) - round 4; rounds 1-3 keyed by grid size,
+    which is not the env count for k_actor_step and made the launch shape part of the bookkeeping."""
+    return f"{kernel.replace(' ', '')}#n{n}"          # no blanks: demanglers differ in "> >" against ">>"
 
 
 def pmc_traffic(kernel, n):
@@ -152,7 +170,10 @@ def pmc_traffic(kernel, n):
             table = json.load(open(path))
         except Exception:
             continue
-        d = table.get(f"{kernel}@{launch_grid(kernel, n)}")
+        d = table.get(pmc_key(kernel, n))
+        if d is None:                                     # rounds 1-3: "<name as printed>@<grid>"
+            legacy = f"{kernel}@{launch_grid(kernel, n)}".replace(" ", "")
+            d = next((v for k, v in table.items() if k.replace(" ", "") == legacy and v.get("envs", n) == n), None)
         if d and d.get("hbm_bytes_per_launch_corrected"):
             return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"],
                     "bytes_per_env": round(d["hbm_bytes_per_launch_corrected"] / n, 2), "source": os.path.basename(path),
@@ -236,7 +257,7 @@ def kernel_probe(device, n, reps):
     ):
         us, us_min, us_max = timed(fn)
         gbps = nbytes * n / (us * 1e-6) / 1e9
-        tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": "rq::k_actor_step<rq::ActorF32T<true> >",
+        tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": actor_step_kernel_name(n),
                           "k_step": "rq::k_step<false>"}[name], n)
         out[name] = {"bound": "hbm", "us_per_launch": round(us, 3),
                      "us_per_launch_min_max": [round(us_min, 3), round(us_max, 3)], "statistic": "median of 20 batches",

@@ -23,8 +23,11 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"--offload-arch={ARCH}",
                 "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 DEVICE_FLAGS += os.environ.get("RQ_EXTRA_HIPCC_FLAGS", "").split()      # compiler-flag experiments only
-SOURCES = ["rq_kernels.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
-HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_host.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
+SOURCES = ["rq_kernels.hip", "rq_kernels_16bit.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
+HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_rollout.hpp", "rq_host.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
+# per-source flags: the 16-bit actors' fused rollout loop is scheduled for instruction-level parallelism (a lone wave
+# stalls ~3 cycles when an instruction reads the result of the one right before it: tools/lonewave.hip, rq_rollout.hpp)
+SOURCE_FLAGS = {"rq_kernels_16bit.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc():
@@ -41,37 +44,47 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src, force, obj_dir=OBJ, extra=()):
+    obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src)] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if not force and not _stale(obj, deps):
         return obj, False
-    cmd = [_hipcc()] + DEVICE_FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc()] + DEVICE_FLAGS + SOURCE_FLAGS.get(src, []) + list(extra) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
     return obj, True
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, variant=None, extra_flags=()):
+    """variant: an experiment build beside the product's - same sources compiled with `extra_flags` (-D switches of an
+    A/B) into scratch/variants/libraptor_quad_<variant>.so; RAPTOR_QUAD_LIB=<that path> makes raptor_amd load it."""
+    obj_dir, lib = OBJ, LIB
+    if variant:
+        vdir = os.path.join(os.path.dirname(PKG), "scratch", "variants")
+        obj_dir, lib = os.path.join(vdir, "_obj_" + variant), os.path.join(vdir, f"libraptor_quad_{variant}.so")
+    os.makedirs(obj_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, force, obj_dir, extra_flags), SOURCES))
     objs = [o for o, _ in results]
-    if force or any(c for _, c in results) or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
+    LIB_ = lib
+    if force or any(c for _, c in results) or _stale(LIB_, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         if verbose:
-            print("built", LIB)
+            print("built", LIB_)
     elif verbose:
-        print("up to date:", LIB)
-    return LIB
+        print("up to date:", LIB_)
+    return LIB_
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    # python -m raptor_amd.build [--force] [--variant NAME -DFLAG ...]
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    _extra = [a for a in sys.argv[1:] if a not in ("--force", "--variant", _variant)]
+    build(force="--force" in sys.argv, verbose=True, variant=_variant, extra_flags=_extra)
 
 
 def listings(out_dir=None):
@@ -86,7 +99,7 @@ def listings(out_dir=None):
             continue
         lst = os.path.join(out_dir, os.path.splitext(src)[0] + ".s")
         if not os.path.exists(lst) or os.path.getmtime(lst) < newest:
-            cmd = [_hipcc()] + DEVICE_FLAGS + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", lst]
+            cmd = [_hipcc()] + DEVICE_FLAGS + SOURCE_FLAGS.get(src, []) + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", lst]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)

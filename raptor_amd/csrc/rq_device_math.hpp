@@ -305,19 +305,18 @@ __device__ __forceinline__ float step_inplace(const StepCfg& c, const EnvConsts&
     // unless a member is NaN - and then the maximum over all 17 components is NaN and the finite test
     // fires, exactly as the per-component form does.  8 maxima + 4 compares instead of 26 compares plus
     // the i1 bit-vector code the compiler builds for a 26-term OR (measured: ~75 VALU instructions).
-    bool t = false;
-    if (c.termination_enabled) {
-        const float mp = amax3(y.P01[0], y.P01[1], y.p2);
-        const float mv = amax3(y.V01[0], y.V01[1], y.VW[0]);
-        const float mw = amax3(y.Wa[0], y.Wa[1], y.VW[1]);
-        float m = amax3(y.Q1[0], y.Q2[0], y.Q2[1]);
-        m = amax3(m, y.Q1[1], y.R01[0]);
-        m = amax3(m, y.R01[1], y.R23[0]);
-        m = amax3(m, y.R23[1], mp);
-        m = amax3(m, mv, mw);
-        t = (mp > c.termination_position) | (mv > c.termination_linear_velocity) |
-            (mw > c.termination_angular_velocity) | !finite_(m);
-    }
+    // (evaluated whether or not termination is enabled and masked afterwards: as a wave-uniform branch around these nine
+    // instructions it cost the loop ten scalar instructions of mask bookkeeping per step)
+    const float mp = amax3(y.P01[0], y.P01[1], y.p2);
+    const float mv = amax3(y.V01[0], y.V01[1], y.VW[0]);
+    const float mw = amax3(y.Wa[0], y.Wa[1], y.VW[1]);
+    float m = amax3(y.Q1[0], y.Q2[0], y.Q2[1]);
+    m = amax3(m, y.Q1[1], y.R01[0]);
+    m = amax3(m, y.R01[1], y.R23[0]);
+    m = amax3(m, y.R23[1], mp);
+    m = amax3(m, mv, mw);
+    const bool t = ((mp > c.termination_position) | (mv > c.termination_linear_velocity) |
+                    (mw > c.termination_angular_velocity) | !finite_(m)) & (c.termination_enabled != 0);
     term = t;
     const float pc = fmaf(y.p2, y.p2, fmaf(y.P01[1], y.P01[1], y.P01[0] * y.P01[0]));
     const float oc = fmaf(-y.Q1[0], y.Q1[0], 1.0f);
@@ -767,7 +766,7 @@ struct ActorF32T {
         asm volatile("s_nop 15" : "+v"(c.gr), "+v"(c.gz), "+v"(c.gnh));
     }
     // envs of `mask` (bit 16 t + j) had their hidden state replaced by the initial one after the carry was computed
-    __device__ __forceinline__ void reset_carry(uint64_t mask, Carry& c) const {
+    __device__ __forceinline__ void reset_carry(uint64_t mask, const float (&)[4][4], Carry& c) const {
         if constexpr (!kPipelined) return;
         const bool take = (mask >> (threadIdx.x & 15)) & 1ull;         // the carry covers tile 0
         float g[12];
@@ -1027,23 +1026,57 @@ struct ActorBF16 {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 
-    // the fused rollout's interface (ActorF32T pipelines across the step boundary; nothing to carry here)
-    struct Carry {};
-    struct Saved {};
-    __device__ __forceinline__ void prime(const float (&)[4][4], Carry&) const {}
-    __device__ __forceinline__ void reset_carry(uint64_t, Carry&) const {}
-    __device__ __forceinline__ Saved carry_of(const Carry&) const { return Saved{}; }
-    __device__ __forceinline__ void hold_carry(uint64_t, const Saved&, Carry&) const {}
+    // What the fused loops carry from one step into the next (round 4): the hidden state ALREADY rounded and packed to
+    // bf16 pairs.  layer_2 packs the new hidden state as its B operand, and the next step's gate MFMAs need exactly
+    // those dwords again (k-slots 4..7 of their operand): carried, they are converted once per step instead of twice
+    // (8 v_cvt_pk_bf16_f32 of a wave-step's ~520 vector instructions).  Same bits as packing again (RNE of the same values).
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t pk(float lo, float hi) {            // one v_cvt_pk_bf16_f32 (RNE)
+        const f32x2 in = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(in, bf16x2));
+    }
+    struct Carry { uint32_t hp[4][2]; };
+    struct Saved { uint32_t hp[4][2]; };
+    static __device__ __forceinline__ void pack_hidden(const float (&hQ)[4][4], uint32_t (&hp)[4][2]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { hp[t][0] = pk(hQ[t][0], hQ[t][1]); hp[t][1] = pk(hQ[t][2], hQ[t][3]); }
+    }
+    __device__ __forceinline__ void prime(const float (&hQ)[4][4], Carry& c) const { pack_hidden(hQ, c.hp); }
+    // envs of `mask` had their hidden state replaced (hQ holds the new one already): pack again (rare path: all of it)
+    __device__ __forceinline__ void reset_carry(uint64_t, const float (&hQ)[4][4], Carry& c) const { pack_hidden(hQ, c.hp); }
+    __device__ __forceinline__ Saved carry_of(const Carry& c) const {
+        Saved s;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { s.hp[t][0] = c.hp[t][0]; s.hp[t][1] = c.hp[t][1]; }
+        return s;
+    }
+    // envs of `mask` (bit 16 t + j) did not take the step just evaluated: what is carried for them is what it was before
+    __device__ __forceinline__ void hold_carry(uint64_t mask, const Saved& before, Carry& c) const {
+        const uint32_t j = threadIdx.x & 15;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool take = (mask >> (16 * t + j)) & 1ull;
+            c.hp[t][0] = take ? before.hp[t][0] : c.hp[t][0];
+            c.hp[t][1] = take ? before.hp[t][1] : c.hp[t][1];
+        }
+    }
     template <int N_STORES, class HOOK>
-    __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry&, HOOK early_stores) const {
-        step<N_STORES>(o, hQ, a, early_stores);
+    __device__ __forceinline__ void step_fused(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], Carry& c, HOOK early_stores) const {
+        early_stores();           // the bf16 MFMAs co-execute with everything else: no placement needed
+        run(o, hQ, a, c.hp);
     }
     template <int N_STORES, class HOOK>
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], HOOK early_stores) const {
-        early_stores();           // the bf16 MFMAs co-execute with everything else: no placement needed
+        early_stores();
         step(o, hQ, a);
     }
     __device__ __forceinline__ void step(const float (&o)[22], float (&hQ)[4][4], float (&a)[4]) const {
+        uint32_t hp[4][2];
+        pack_hidden(hQ, hp);
+        run(o, hQ, a, hp);
+    }
+    // hp: the packed hidden state BEFORE the step on entry, after it on return
+    __device__ __forceinline__ void run(const float (&o)[22], float (&hQ)[4][4], float (&a)[4], uint32_t (&hp)[4][2]) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         // observation -> B operands of layer_0.  The operand is bf16 anyway, so the features are rounded and packed
         // in pairs BEFORE the layout change: dword d of a tile's operand holds k-slots 2d, 2d+1 = features 8d + q and
@@ -1051,7 +1084,6 @@ struct ActorBF16 {
         // lane-group transpose runs on 12 packed dwords instead of 24 floats (12 permlane swaps instead of 24, and
         // no copies of the state registers the swaps would otherwise destroy); feature 22 is the constant 1 that
         // carries the bias, 23 is padding.  Same rounding, same bits as packing after the transpose.
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         float P[3][4];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -1085,10 +1117,6 @@ struct ActorBF16 {
         // (negative -> +0) in 8 instructions instead of 16.  layer_2 reuses the SAME tuple with the h half replaced by
         // the new hidden state - its A operands are zero in k-slots 0..3 (rq_pack.cpp), so the y0 half needs no zeroing.
         typedef short s16x2 __attribute__((ext_vector_type(2)));
-        auto pk = [](float lo, float hi) {            // one v_cvt_pk_bf16_f32 (RNE)
-            const f32x2 in = {lo, hi};
-            return __builtin_bit_cast(uint32_t, __builtin_convertvector(in, bf16x2));
-        };
         auto relu_pk = [](uint32_t u) {
             const s16x2 z = {0, 0};
             return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), z));
@@ -1098,7 +1126,7 @@ struct ActorBF16 {
         for (int t = 0; t < 4; ++t) {
             yp[t][0] = relu_pk(pk(y0[t][0], y0[t][1]));
             yp[t][1] = relu_pk(pk(y0[t][2], y0[t][3]));
-            const dwordx4 u = {yp[t][0], yp[t][1], pk(hQ[t][0], hQ[t][1]), pk(hQ[t][2], hQ[t][3])};
+            const dwordx4 u = {yp[t][0], yp[t][1], hp[t][0], hp[t][1]};
             const bf16x8 xh = __builtin_bit_cast(bf16x8, u);
             gr[t] = mfma(wr, xh, cbr);
             gz[t] = mfma(wz, xh, cbz);
@@ -1111,7 +1139,8 @@ struct ActorBF16 {
         f32x4 d0 = cb2, d1 = zero;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const dwordx4 u = {yp[t][0], yp[t][1], pk(hQ[t][0], hQ[t][1]), pk(hQ[t][2], hQ[t][3])};
+            hp[t][0] = pk(hQ[t][0], hQ[t][1]); hp[t][1] = pk(hQ[t][2], hQ[t][3]);
+            const dwordx4 u = {yp[t][0], yp[t][1], hp[t][0], hp[t][1]};
             const bf16x8 hb = __builtin_bit_cast(bf16x8, u);
             if (t & 1) d1 = mfma(a_op(BW_L2 + 4 * t), hb, d1);
             else       d0 = mfma(a_op(BW_L2 + 4 * t), hb, d0);
@@ -1190,7 +1219,7 @@ struct ActorF16X2 {
     struct Carry {};
     struct Saved {};
     __device__ __forceinline__ void prime(const float (&)[4][4], Carry&) const {}
-    __device__ __forceinline__ void reset_carry(uint64_t, Carry&) const {}
+    __device__ __forceinline__ void reset_carry(uint64_t, const float (&)[4][4], Carry&) const {}
     __device__ __forceinline__ Saved carry_of(const Carry&) const { return Saved{}; }
     __device__ __forceinline__ void hold_carry(uint64_t, const Saved&, Carry&) const {}
     template <int N_STORES, class HOOK>

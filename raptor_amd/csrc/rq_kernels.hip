@@ -19,20 +19,12 @@
 // Below 1024 envs k_observe / k_actor_step / k_step exchange host rows through a pinned mailbox (Mailbox).
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
 #include <type_traits>
 
-#include "rq_device_math.hpp"
+#include "rq_rollout.hpp"      // k_rollout_fused and what it shares with the kernels below (field(), block sizes, ...)
 
 namespace rq {
-
-static constexpr int kBlock = 256;      // 4 waves; streaming kernels
-static constexpr int kFusedBlock = 64;  // 1 wave per workgroup: spreads 65 536 envs as 1024 WGs over 256 CUs
-
-__device__ __forceinline__ uint32_t env_index() { return blockIdx.x * blockDim.x + threadIdx.x; }
-
-// Field f of a field-major SoA buffer: env i of the batch is element i of this row.
-template <typename T>
-__device__ __forceinline__ T* field(T* base, uint32_t f, uint32_t ld) { return base + (size_t)f * ld; }
 
 // Publish completion of this launch in the host mailbox: every workgroup makes its stores visible at system
 // scope and counts itself; the last one resets the counter and writes seq to the pinned flag.
@@ -127,7 +119,12 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 // wave-uniform control flow with all 64 lanes holding valid data: lanes past the end of the
 // batch (and frozen envs) compute on a clamped index and only their STORES are predicated —
 // no lane leaves early.
-template <typename ACTOR>
+// STREAM: a wave works through groups_per_wave consecutive 64-env groups with the next group's inputs in flight (large
+// batches: the 18 KB operand image per wave is amortised and memory and matrix phases overlap); !STREAM: one group per wave,
+// no loop and no prefetch (up to 262 144 envs - round 4: the streaming form's unconditional prefetch re-read the wave's only
+// group).  Two instantiations, two kernel names: a profile tells the 2 097 152-env launch from the 65 536-env one even
+// where their grids coincide (32 groups per wave at 2 M envs = the 1 024 waves of 65 536 envs).
+template <typename ACTOR, bool STREAM>
 __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
                                                        const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
@@ -155,7 +152,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
         fz = frozen != nullptr ? (uint32_t)frozen[i] : 0u;
     };
     if (first >= n) { mailbox_signal(mb); return; }          // wave-uniform
-    const uint32_t n_groups = min(groups_per_wave, (n - first + 63u) / 64u);
+    const uint32_t n_groups = STREAM ? min(groups_per_wave, (n - first + 63u) / 64u) : 1u;
     float x[22], hQ[4][4];
     uint32_t fz;
     load_group(first, x, hQ, fz);
@@ -169,7 +166,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
         // flag along - a load consumed right here would wait for everything issued before it, the prefetch included.
         float xn[22], hn[4][4];
         uint32_t fzn;
-        load_group(g + 1 < n_groups ? wave_base + 64 : wave_base, xn, hn, fzn);
+        if constexpr (STREAM) load_group(g + 1 < n_groups ? wave_base + 64 : wave_base, xn, hn, fzn);
         const uint32_t i0 = wave_base + lane;
         const uint32_t i = i0 < n ? i0 : n - 1;
         const bool commit = (i0 < n) && fz == 0;
@@ -187,24 +184,18 @@ __global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t g
                 for (int k = 0; k < 4; ++k) mb.rows_out[(size_t)i * 4 + k] = a[k];
             }
         }
+        if constexpr (STREAM) {
 #pragma unroll
-        for (int k = 0; k < 22; ++k) x[k] = xn[k];
+            for (int k = 0; k < 22; ++k) x[k] = xn[k];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hQ[t][r] = hn[t][r];
-        fz = fzn;
+                for (int r = 0; r < 4; ++r) hQ[t][r] = hn[t][r];
+            fz = fzn;
+        }
     }
     mailbox_signal(mb);
 }
-
-// register budget of a kernel built around an actor type: waves per SIMD it is compiled for
-template <typename A> struct WavesPerSimd { static constexpr int value = 1; static constexpr bool bf16 = false; };
-template <> struct WavesPerSimd<ActorF32Lean> { static constexpr int value = 2; static constexpr bool bf16 = false; };
-template <> struct WavesPerSimd<ActorBF16> { static constexpr int value = 1; static constexpr bool bf16 = true; };
-template <> struct WavesPerSimd<ActorBF16Lean> { static constexpr int value = 2; static constexpr bool bf16 = true; };
-// the split-f16 actor: its MFMAs co-execute with the VALU like the bf16 ones; one build, the 512-register budget
-template <> struct WavesPerSimd<ActorF16X2> { static constexpr int value = 1; static constexpr bool bf16 = true; };
 
 // Raptor evaluated over a whole observation SEQUENCE in one launch (rl-tools evaluates [seq, batch, feature]
 // tensors: the known-answer example of the checkpoint is one, checkpoint.h:197-215): obs [T][n][stride]
@@ -308,7 +299,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_act
         const uint64_t ended = __builtin_amdgcn_ballot_w64(d == 1 || d == 2);
         if (ended != 0) {                                                       // episode end: policy reset
             select_hidden_q(ended, h0Q, hQ);
-            actor.reset_carry(ended, carry);
+            actor.reset_carry(ended, hQ, carry);
         }
         if (valid) {
 #pragma unroll
@@ -433,305 +424,6 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
         step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb, on);
     mailbox_signal(mb);
 }
-// ------------------------------------------------------------------ fused rollout ------
-// K iterations of observe -> evaluate_step -> step -> assign with the env state, the GRU
-// hidden state, the per-env constants, the policy weights and the episode statistics resident
-// in VGPRs; HBM is touched once before and once after the K steps.
-// Control flow is wave-uniform around the MFMAs (see k_actor_step): lanes past the end of the
-// batch shadow env n-1, frozen envs keep stepping a scratch copy that is never committed; only
-// the rare auto-reset branch (no MFMA inside) diverges.
-
-template <bool NOISE, bool AUTORESET, bool RECORD, bool SAS, typename ACTOR>
-__global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rollout_fused(Batch b, StepCfg c, NoiseCfg nc, SampleCfg sc,
-                                                               uint64_t seed, uint32_t epoch0, uint32_t n_steps,
-                                                               const float* __restrict__ params,
-                                                               float* __restrict__ state,
-                                                               float* __restrict__ hidden,
-                                                               const float* __restrict__ w,
-                                                               const float* __restrict__ packed, StatsPtrs st,
-                                                               TrajPtrs traj, SasArgs sas,
-                                                               unsigned long long* __restrict__ span) {
-    // kernel-level timing (rq_device_set_rollout_timing): every wave leaves the wall-clock ticks (constant rate) at which it
-    // came in and went out, and its XCD: the eight dies' counters are offset against one another by microseconds, one die's
-    // are consistent - the host takes first-in / last-out per die
-    // (one record per wave, no atomics: 128 waves of a die updating one word cost the launch 8 us)
-    unsigned long long t_in = 0;
-    if (span != nullptr) t_in = (unsigned long long)wall_clock64();
-    const uint32_t i0 = env_index();
-    const uint32_t wave_base = i0 & ~63u;
-    const uint32_t i = i0 < b.n ? i0 : b.n - 1;
-    const bool valid = i0 < b.n;
-    const size_t ld = b.ld;
-    const uint64_t genv = b.env_offset + i;
-    const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
-    QuadState y;
-    f32x2 LA01, LA23;
-    float f6[6], hQ[4][4];
-    y.load([&](int j) { return field(state, j, ld)[i]; });
-    LA01 = f32x2{field(state, (RQ_S_LAST_ACTION + 0), ld)[i], field(state, (RQ_S_LAST_ACTION + 1), ld)[i]};
-    LA23 = f32x2{field(state, (RQ_S_LAST_ACTION + 2), ld)[i], field(state, (RQ_S_LAST_ACTION + 3), ld)[i]};
-#pragma unroll
-    for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
-    load_hidden_q(hidden, ld, wave_base, b.n, hQ);
-    // the running episode's return and length ride in registers; a FINISHED episode's record goes straight to memory when
-    // it ends (below): four values less to carry through the loop, five instructions less per step
-    float ep_ret = st.returns[i];
-    uint32_t ep_steps = st.steps[i];
-    float last_r = st.last_reward[i];
-    const uint8_t last_t_raw = st.last_terminated[i];
-    uint8_t last_d = st.last_done[i];
-    const uint8_t frozen_raw = st.frozen[i];
-    uint32_t ep = AUTORESET ? st.episode[i] : 0u;
-    // the operand image (L2-resident after a die's first wave) is asked for AFTER the env's own fields: those come from
-    // HBM / the memory-side cache and their latency is the long one
-    ACTOR actor;
-    actor.template load<kFusedBlock / 64>(packed);
-    float h0Q[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h0Q[t][r] = actor.h0(r);
-    // looked at only now (the empty asm keeps the compares from drifting up between the image's loads, where they
-    // made those wait for every load before them)
-    uint32_t last_t_bits = last_t_raw, frozen_bits = frozen_raw;
-    asm volatile("" : "+v"(last_t_bits), "+v"(frozen_bits));
-    bool last_t = last_t_bits != 0;
-    const bool was_frozen = frozen_bits != 0;
-    // The next episode's initial state, sampled AHEAD of the episode end (round 3).  sample_initial_state of an env depends
-    // on (seed, episode counter, global env id, a few parameters) and on nothing the running episode computes, so it need
-    // not wait for the end: the 19 values that are not constants (position .. angular velocity, the disturbance) are kept
-    // in ACCUMULATION registers for every lane, and an env whose episode ends takes them with 19 register reads.  The
-    // sampler itself (six Philox blocks, sin / cos, Box-Muller: ~1 000 instructions, and at an episode end it used to run
-    // for the one or two lanes concerned while the other 62 waited - the slowest wave of a 20-step launch paid it three
-    // times, tools/wave_timeline.py) runs for ALL 64 lanes at once, and only when an ending env finds its values used
-    // up: `pre_mask` has a bit per lane whose parked values are for its current episode counter.  Lanes that still hold
-    // valid ones get the same values again (same counter, same function), so the refill is unconditional.
-    // Only the builds with one wave per SIMD do this: the two-waves-per-SIMD builds have 256 registers per wave in all,
-    // every one of them an architected register; asking for accumulation registers splits that budget 128 + 128 and the
-    // hot loop spills (262 144 envs: 0.70 -> 0.55 of the peak).  There the second wave fills the time one spends sampling.
-    // (The two-wave bf16 build has the room: 6.45 -> 5.7 us per step of 262 144 envs with it.)
-    constexpr bool kAhead = AUTORESET && (WavesPerSimd<ACTOR>::value == 1 || std::is_same<ACTOR, ActorBF16Lean>::value);
-    // the env index as the rare paths see it: opaque, so that the addresses they form are computed there and then instead of
-    // being kept through the loop (see the epilogue)
-    auto rare_index = [&]() { uint32_t r = i; asm volatile("" : "+v"(r)); return r; };
-    constexpr int kPre = 19;
-    float pre[kPre];
-    uint64_t pre_mask = 0;                       // wave-uniform
-    float hover_rpm = 0.0f;
-    if (AUTORESET) hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
-    if (kAhead) {
-#pragma unroll
-        for (int j = 0; j < kPre; ++j) asm volatile("" : "=a"(pre[j]));    // named, not written: pre_mask = 0 says none is valid
-    }
-    auto refill = [&]() {                        // every lane: sample_initial_state for its episode counter ep
-        const uint32_t ir = rare_index();
-        const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[ir], hover_rpm,
-                                                   field(params, RQ_P_ROTOR_POS, ld)[ir], field(params, (RQ_P_ROTOR_POS + 1), ld)[ir]);
-#pragma unroll
-        for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[j]) : "v"(fresh[j]));
-        pre_mask = ~0ull;
-    };
-    auto take_presampled = [&]() {               // this lane's env starts its next episode (its parked values are valid)
-        float fr[kPre];
-        if constexpr (kAhead) {
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fr[j]) : "a"(pre[j]));
-        } else {                                 // sampled here and now, for the lanes whose episode ended
-            const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm,
-                                                       field(params, RQ_P_ROTOR_POS, ld)[i],
-                                                       field(params, (RQ_P_ROTOR_POS + 1), ld)[i]);
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) fr[j] = fresh[j];
-        }
-        y.load([&](int j) { return j < 13 ? fr[j] : hover_rpm; });
-        LA01 = f32x2{0.0f, 0.0f}; LA23 = f32x2{0.0f, 0.0f};       // sample_state: last action 0, rotors at hover
-#pragma unroll
-        for (int j = 0; j < 6; ++j) f6[j] = fr[13 + j];
-        if (valid) {                                 // the new episode's disturbance: written now, not carried to the end
-            const uint32_t ir = rare_index();
-#pragma unroll
-            for (int j = 0; j < 6; ++j) field(state, (RQ_S_FORCE + j), ld)[ir] = fr[13 + j];
-        }
-        ep += 1;
-    };
-    if (AUTORESET) {
-        // An env left frozen by an earlier rollout WITHOUT auto-reset (its episode is over) starts its next
-        // episode here, as every episode end under auto-reset does: re-sampled, policy state reset.  The
-        // chained mode does the same before its first step (k_thaw_frozen).
-        const uint64_t thaw = __builtin_amdgcn_ballot_w64(was_frozen);
-        if (thaw != 0) {
-            if constexpr (kAhead) refill();
-            if (was_frozen) take_presampled();
-            pre_mask &= ~thaw;
-            select_hidden_q(thaw, h0Q, hQ);
-        }
-    }
-    typename ACTOR::Carry carry;          // what the actor carries from one step into the next (ActorF32T::Carry)
-    actor.prime(hQ, carry);
-    Disturbance ds = make_disturbance(k, c.gravity, f6);
-    bool frozen = AUTORESET ? false : was_frozen;
-    uint32_t last_step = n_steps;                      // without auto-reset: the last step of this launch the env took
-    // wave-uniform: no env of this wave distinguishes rotor spin-up from spin-down (see dynamics<SYM_TAU>)
-    const bool sym_tau = __builtin_amdgcn_ballot_w64(k.itr != k.itf) == 0;
-
-    // The loop exists twice, once per dynamics variant (round 3): with the wave-uniform choice inside the loop the two
-    // variants met in a join that cost the state's registers a copy per step (~8 moves) plus the branch itself.
-    auto rollout_loop = [&](auto sym_choice) {
-    constexpr bool SYM = decltype(sym_choice)::value;
-    for (uint32_t t = 0; t < n_steps; ++t) {
-        const uint64_t live = AUTORESET ? ~0ull : __builtin_amdgcn_ballot_w64(!frozen);
-        if (!AUTORESET && live == 0) break;   // wave-uniform exit: every env of the wave is frozen
-        float o[22], a[4];
-        observe_head<NOISE>(y, LA01, LA23, nc, seed, epoch0 + t, genv, o);
-        float hn[4][4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hn[tt][r] = hQ[tt][r];
-        // Trajectory stores (RECORD): one coalesced 256-byte store per field per wave; buffer stores: resource = this
-        // step's block of the trajectory (base moved on the SALU), scalar offset = field row, vector offset = the
-        // lane's env - no per-lane 64-bit address arithmetic, no per-lane pointers kept alive across the loop; lanes
-        // past the batch are sent out of range (the hardware drops out-of-range buffer stores).  The 22 observation
-        // stores are handed to the actor, which places them between the MFMAs of its first GRU pass; the action
-        // follows the actor, reward and done code the env step.
-        const uint32_t row = (uint32_t)ld * 4u;                     // bytes per field row (ld < 2^30)
-        const uint32_t lane_off = valid ? i * 4u : 0xFFFFFFFFu;
-        if (RECORD) {
-            const size_t tt = traj.t0 + t;
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(traj.obs + tt * 22 * ld, 0, 22u * row, 0x00020000);
-            actor.template step_fused<22>(o, hn, a, carry, [&] {
-#pragma unroll
-                for (int j = 0; j < 22; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, 0);
-            });
-        } else {
-            actor.template step_fused<0>(o, hn, a, carry, [] {});
-        }
-        if (SAS) sample_and_squash(sas, epoch0 + t, genv, hn, a);        // SampleAndSquash output stage (rare)
-        if (RECORD) {
-            const size_t tt = traj.t0 + t;
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(traj.act + tt * 4 * ld, 0, 4u * row, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a[j]), ra, lane_off, (uint32_t)j * row, 0);
-        }
-        if (AUTORESET) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hQ[tt][r] = hn[tt][r];
-        } else {
-            select_hidden_q(live, hn, hQ);    // frozen envs keep their hidden state
-        }
-        // everything above belongs to the actor (MFMA results consumed, transposes done); the env step below
-        // contains hand-placed packed instructions the compiler's hazard tracking does not see through
-        __builtin_amdgcn_sched_barrier(0);
-        QuadState yn = y;
-        f32x2 A01, A23;
-        bool term;
-        const float r = step_inplace<SYM>(c, k, ds, yn, a, A01, A23, term);
-        // the reward is wanted HERE: left to itself its arithmetic sinks below the episode-end block, which overwrites the
-        // state it reads - and the state then lives twice, nine copies per step
-        asm volatile("" :: "v"(r));
-        bool ended = false;
-        uint8_t done_code = 4;          // frozen: computed on a scratch copy, not committed
-        if (AUTORESET || !frozen) {     // commit (AUTORESET never freezes: the test folds away)
-            y = yn;
-            LA01 = A01; LA23 = A23;
-            if (__builtin_expect(c.action_history_raw != 0, 0)) {      // wave-uniform (kernel argument)
-                LA01 = f32x2{a[0], a[1]}; LA23 = f32x2{a[2], a[3]};
-            }
-            last_r = r; last_t = term;
-            ep_ret += r;
-            ep_steps += 1;
-            ended = term || ep_steps >= c.episode_step_limit;
-            done_code = term ? 1 : (ended ? 2 : 0);
-            last_d = done_code;
-            if (!AUTORESET) last_step = t;             // (an env that froze earlier in the launch reports 4: see below)
-            if (ended) {
-                if (valid) {                           // lanes past the batch shadow env n - 1: they must not count twice
-                    const uint32_t ir = rare_index();
-                    st.fin_returns[ir] = ep_ret;
-                    st.fin_lengths[ir] = ep_steps;
-                    (void)__hip_atomic_fetch_add(&st.fin_counts[ir], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (term) (void)__hip_atomic_fetch_add(&st.fin_terminated[ir], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                ep_ret = 0.0f;
-                ep_steps = 0;
-                if (!AUTORESET) frozen = true;         // under auto-reset the next episode starts below
-            }
-        }
-        if (RECORD) {   // reward and done code of this transition (the observation and action went out above)
-            const size_t tt = traj.t0 + t;
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(traj.rew + tt * ld, 0, row, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(traj.done + tt * ld, 0, (uint32_t)ld, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rr, valid ? i * 4u : 0xFFFFFFFFu, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b8(done_code, rd, valid ? i : 0xFFFFFFFFu, 0, 0);
-        }
-        if (AUTORESET) {   // the envs whose episode ended: next initial state, h <- initial_hidden_state
-            const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
-            if (ended_mask != 0) {
-                if constexpr (kAhead) {
-                    if ((ended_mask & ~pre_mask) != 0) refill();      // wave-uniform; rare (see above)
-                }
-                if (ended) {
-                    take_presampled();
-                    ds = make_disturbance(k, c.gravity, f6);
-                }
-                pre_mask &= ~ended_mask;
-                select_hidden_q(ended_mask, h0Q, hQ);
-                actor.reset_carry(ended_mask, carry);
-            }
-        }
-    }
-    };
-    unsigned long long t_loop = 0, t_done = 0;
-    if (span != nullptr) t_loop = (unsigned long long)wall_clock64();
-    if (sym_tau) rollout_loop(std::true_type{});
-    else         rollout_loop(std::false_type{});
-    if (span != nullptr) t_done = (unsigned long long)wall_clock64();
-
-    const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
-    // an env whose episode ended BEFORE the launch's last step sat out the rest of it: its last transition of this rollout is
-    // "not stepped" (4), as the chain of k_step launches reports it (found by the random-settings test, round 3)
-    if (!AUTORESET && n_steps > 0 && last_step + 1 != n_steps) last_d = 4;
-    // The stores go to the addresses the prologue loaded from, and left alone the compiler keeps those ~55 64-bit
-    // addresses alive through the whole loop - parked in accumulation registers: ~110 moves in, ~110 out, per launch.
-    // An env index it cannot see through makes it compute them again here (55 adds).
-    uint32_t ie = i;
-    asm volatile("" : "+v"(ie));
-    size_t lde = ld;                                  // likewise the field rows' scalar bases (they were kept in VGPR lanes)
-    asm volatile("" : "+s"(lde));
-    if (valid && commit) {
-        y.store([&](int j, float v) { field(state, j, lde)[ie] = v; });
-        field(state, (RQ_S_LAST_ACTION + 0), lde)[ie] = LA01[0]; field(state, (RQ_S_LAST_ACTION + 1), lde)[ie] = LA01[1];
-        field(state, (RQ_S_LAST_ACTION + 2), lde)[ie] = LA23[0]; field(state, (RQ_S_LAST_ACTION + 3), lde)[ie] = LA23[1];
-        st.returns[ie] = ep_ret;
-        st.steps[ie] = ep_steps;
-        st.last_reward[ie] = last_r;
-        st.last_terminated[ie] = last_t ? 1 : 0;
-        st.last_done[ie] = last_d;
-        if (AUTORESET) {
-            st.episode[ie] = ep;
-            if (was_frozen) st.frozen[ie] = 0;
-        }
-        if (frozen) st.frozen[ie] = 1;
-    }
-    if (valid && !commit && n_steps > 0) st.last_done[ie] = 4;   // not stepped by this rollout (as k_step reports it)
-    store_hidden_q(hidden, lde, wave_base, __builtin_amdgcn_ballot_w64(valid && commit), hQ);
-    if (span != nullptr) {
-        __builtin_amdgcn_s_waitcnt(0);                // the wave's stores have left
-        if (threadIdx.x == 0) {
-            const unsigned long long xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;        // HW_REG_XCC_ID[3:0]
-            unsigned long long* rec = span + 4 * (size_t)blockIdx.x;
-            rec[0] = t_in;
-            rec[1] = ((unsigned long long)wall_clock64() & 0x0FFFFFFFFFFFFFFFull) | (xcd << 60);
-            rec[2] = t_loop;          // prologue issued (its loads may still be in flight), first step about to start
-            rec[3] = t_done;          // last step done, the epilogue's stores not yet issued
-        }
-    }
-}
-
 // Chained-mode counterpart of the fused kernel's prologue under auto-reset: envs left frozen by an earlier
 // rollout start their next episode (sample_initial_state with the env's episode counter, policy state reset).
 __global__ __launch_bounds__(kBlock) void k_thaw_frozen(Batch b, SampleCfg c, uint64_t seed,
@@ -806,16 +498,20 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     if (n == 0) return hipSuccess;
     // enough waves to fill the 1024 SIMDs first, then several 64-env groups per wave so that the
     // per-wave operand-image load (18 KB, more than a group's own 14.8 KB of data) is amortised
+    // (2 097 152 envs, groups per wave 2 / 4 / 8 / 11 / 16 / 32: 125.9 / 119.6 / 116.6 / 116.2 / 122.2 / 110.8 us)
     const uint32_t groups = (n + 63) / 64;
-    const uint32_t gpw = groups >= 16384 ? 8 : (groups >= 4096 ? 4 : 1);
+    static const uint32_t forced = [] { const char* e = std::getenv("RQ_ACTOR_GROUPS_PER_WAVE"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    const uint32_t gpw = forced ? forced : actor_groups_per_wave(n);       // the override: launch-shape sweeps (tools/)
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
-    if (precision == RQ_POLICY_F16X2_MFMA)
-        k_actor_step<ActorF16X2><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);
-    else if (precision == RQ_POLICY_BF16_MFMA)
-        k_actor_step<ActorBF16><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);
-    else
-        // the two-tiles-per-pass build: ~30 registers fewer live, 2-3 % faster at every size (same arithmetic)
-        k_actor_step<ActorF32Lean><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);
+#define RQ_LAUNCH_ACTOR(ACT)                                                                                                            \
+    do {                                                                                                                                \
+        if (gpw > 1) k_actor_step<ACT, true><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);  \
+        else         k_actor_step<ACT, false><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb); \
+    } while (0)
+    if (precision == RQ_POLICY_F16X2_MFMA)     RQ_LAUNCH_ACTOR(ActorF16X2);
+    else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_ACTOR(ActorBF16);
+    else                                       RQ_LAUNCH_ACTOR(ActorF32Lean);   // the two-tiles-per-pass build: ~30 registers fewer live, 2-3 % faster at every size
+#undef RQ_LAUNCH_ACTOR
     return hipGetLastError();
 }
 
@@ -878,57 +574,20 @@ hipError_t launch_rollout_fused(hipStream_t s, Batch b, StepCfg c, NoiseCfg nc, 
                                 const float* packed, StatsPtrs st, int precision, SasArgs sas, TrajPtrs traj,
                                 unsigned long long* span) {
     if (b.n == 0 || n_steps == 0) return hipSuccess;
-    const unsigned g = grid_for(b.n, kFusedBlock);
     const bool ar = (flags & RQ_ROLLOUT_AUTORESET) != 0;
-    // span != nullptr: every wave leaves (in, out | xcd << 60, loop begin, loop end) wall-clock ticks at span[4 * workgroup]
-    // (rq_device_last_rollout_ms).  Round 2 took the kernel's begin / end from hipExtLaunchKernel events; calibrated under
-    // rocprofv3 in one process, an event-carrying launch itself runs ~4 us longer than a plain one and the events read
-    // ~4 us more on top.
-#define RQ_LAUNCH_FUSED(NZ, AR, RC, ACT) \
-    hipLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, false, ACT>), dim3(g), dim3(kFusedBlock), 0, s, \
-                       b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas, span)
-    // with the SampleAndSquash stage: only the 256-register builds carry it
-#define RQ_LAUNCH_FUSED_SAS(NZ, AR, RC, ACT) \
-    hipLaunchKernelGGL((k_rollout_fused<NZ, AR, RC, true, ACT>), dim3(g), dim3(kFusedBlock), 0, s, \
-                       b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas, span)
-#define RQ_LAUNCH_FUSED_SAS_RC(NZ, AR, ACT) \
-    do { if (rec) RQ_LAUNCH_FUSED_SAS(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED_SAS(NZ, AR, false, ACT); } while (0)
-#define RQ_LAUNCH_FUSED_SAS_ACT(ACT)                                                      \
-    do {                                                                                  \
-        if (noise) { if (ar) RQ_LAUNCH_FUSED_SAS_RC(true, true, ACT); else RQ_LAUNCH_FUSED_SAS_RC(true, false, ACT); }   \
-        else       { if (ar) RQ_LAUNCH_FUSED_SAS_RC(false, true, ACT); else RQ_LAUNCH_FUSED_SAS_RC(false, false, ACT); } \
-    } while (0)
-#define RQ_LAUNCH_FUSED_RC(NZ, AR, ACT) \
-    do { if (rec) RQ_LAUNCH_FUSED(NZ, AR, true, ACT); else RQ_LAUNCH_FUSED(NZ, AR, false, ACT); } while (0)
-#define RQ_LAUNCH_FUSED_ACT(ACT)                                                          \
-    do {                                                                                  \
-        if (noise) { if (ar) RQ_LAUNCH_FUSED_RC(true, true, ACT); else RQ_LAUNCH_FUSED_RC(true, false, ACT); }   \
-        else       { if (ar) RQ_LAUNCH_FUSED_RC(false, true, ACT); else RQ_LAUNCH_FUSED_RC(false, false, ACT); } \
-    } while (0)
-    const bool rec = traj.obs != nullptr;
+    const FusedArgs a{b, c, nc, sc, seed, epoch0, n_steps, params, state, hidden, weights, packed, st, traj, sas, span};
+    // the 16-bit actors live in their own translation unit (rq_kernels_16bit.hip: another instruction scheduler)
+    if (precision == RQ_POLICY_F16X2_MFMA || precision == RQ_POLICY_BF16_MFMA)
+        return launch_rollout_fused_16bit(s, a, noise, ar, precision);
     // Two builds of the same loop (same arithmetic, GRU two tiles at a time): a 512-register one for one wave per
     // SIMD - every batch up to 65 536 envs (1024 SIMDs x 64 lanes) - and a 256-register one, two waves per SIMD,
     // beyond.  The 256-register build parks loop invariants in scratch before the loop (~7 us per launch); at one
     // wave per SIMD both run the loop at the same speed (3.21 vs 3.23 us/step), so the small batches take the
-    // build with the cheaper prologue.
+    // build with the cheaper prologue.  With the SampleAndSquash stage: only the 256-register builds carry it.
     const bool lean = b.n > 65536u;
-    if (sas.mode != RQ_SAS_OFF) {
-        if (precision == RQ_POLICY_F16X2_MFMA)     RQ_LAUNCH_FUSED_SAS_ACT(ActorF16X2);
-        else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_FUSED_SAS_ACT(ActorBF16Lean);
-        else                                       RQ_LAUNCH_FUSED_SAS_ACT(ActorF32Lean);
-    }
-    else if (precision == RQ_POLICY_F16X2_MFMA) RQ_LAUNCH_FUSED_ACT(ActorF16X2);
-    else if (precision == RQ_POLICY_BF16_MFMA) {
-        if (lean) RQ_LAUNCH_FUSED_ACT(ActorBF16Lean); else RQ_LAUNCH_FUSED_ACT(ActorBF16);
-    }
-    else if (lean)                        RQ_LAUNCH_FUSED_ACT(ActorF32Lean);
-    else                                  RQ_LAUNCH_FUSED_ACT(ActorF32);
-#undef RQ_LAUNCH_FUSED_SAS_ACT
-#undef RQ_LAUNCH_FUSED_SAS_RC
-#undef RQ_LAUNCH_FUSED_SAS
-#undef RQ_LAUNCH_FUSED_RC
-#undef RQ_LAUNCH_FUSED_ACT
-#undef RQ_LAUNCH_FUSED
+    if (sas.mode != RQ_SAS_OFF) launch_fused_actor<true, ActorF32Lean>(s, a, noise, ar);
+    else if (lean)              launch_fused_actor<false, ActorF32Lean>(s, a, noise, ar);
+    else                        launch_fused_actor<false, ActorF32>(s, a, noise, ar);
     return hipGetLastError();
 }
 

@@ -113,6 +113,12 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // `precision`: rq_policy_precision; `sas`: the optional SampleAndSquash output stage.
 // hidden_in != nullptr: the state BEFORE the step is read from there and `hidden` only written (speculative evaluation).
 // `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
+// 64-env groups one wave of k_actor_step works through at n envs (1 = the non-streaming instantiation); bench.py's
+// launch_grid mirrors this
+inline uint32_t actor_groups_per_wave(uint32_t n) {
+    const uint32_t groups = (n + 63u) / 64u;
+    return groups >= 16384u ? 32u : (groups >= 4096u ? 4u : 1u);
+}
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,
                              int precision, SasArgs sas, Mailbox mb = Mailbox{}, const float* hidden_in = nullptr);

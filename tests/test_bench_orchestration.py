@@ -154,7 +154,13 @@ def test_effective_region_charges_the_exchange_share():
 
 def test_launch_grid_matches_the_launchers():
     import bench
-    assert bench.launch_grid("rq::k_actor_step<rq::ActorF32T<true> >", 2097152) == 262144     # 8 groups per wave
-    assert bench.launch_grid("rq::k_actor_step<rq::ActorF32T<true> >", 65536) == 65536
+    assert bench.launch_grid(bench.actor_step_kernel_name(2097152), 2097152) == 65536     # 32 groups per wave (round 4)
+    assert bench.launch_grid(bench.actor_step_kernel_name(65536), 65536) == 65536          # the same grid ...
+    assert bench.actor_step_kernel_name(2097152) == "rq::k_actor_step<rq::ActorF32T<true>, true>"      # ... another kernel
+    assert bench.actor_step_kernel_name(65536) == "rq::k_actor_step<rq::ActorF32T<true>, false>"
+    assert bench.launch_grid(bench.actor_step_kernel_name(262144), 262144) == 65536        # 4 groups per wave
+    assert bench.pmc_key("rq::k_step<false>", 65536) == "rq::k_step<false>#n65536"
+    # the committed tables of rounds 1-3 (keyed by grid) still resolve for the kernels whose grid is the env count
+    assert bench.pmc_traffic("rq::k_step<false>", 2097152)["bytes_per_env"] > 250
     assert bench.launch_grid("rq::k_step<false>", 65536) == 65536
     assert bench.launch_grid("rq::k_rollout_fused<false, true, false, false, rq::ActorF32T<false> >", 1000) == 1024

@@ -57,12 +57,16 @@ sys.path.insert(0, root)
 from bench import launch_grid                      # noqa: E402
 
 
+from bench import pmc_key                          # noqa: E402
+
+
 def envs_of(name, grid):
-    """env count of a dispatch: the grid for most kernels; k_actor_step packs several 64-env groups per wave, so its
-    grid is matched against the batches bench.py launches it at (65 536 and 2 097 152)"""
-    for n in (2097152, 65536):
-        if launch_grid(name, n) == grid and name.startswith("rq::k_actor_step"):
-            return n
+    """env count of a dispatch: the grid for most kernels (rounded up to the workgroup); the streaming instantiation of
+    k_actor_step packs several 64-env groups per wave, so its grid is matched against the batches bench.py launches it at"""
+    if name.startswith("rq::k_actor_step") and name.rstrip().endswith("true>"):
+        for n in (2097152, 1048576, 262144):
+            if launch_grid(name, n) == grid:
+                return n
     return grid
 
 
@@ -76,7 +80,8 @@ for (name, grid), d in sorted(pmc.items()):
     # "HBM"; calibrated here on k_observe, whose reads are exactly 92 B/env) -> double it; WRITE_SIZE
     # matched the byte count of k_observe's 104 B/env stores exactly -> used as is.  Units: KiB.
     traffic = None if f is None or w is None else (2.0 * f + w) * 1024.0
-    out[f"{name}@{grid}"] = {**{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()},
+    out[pmc_key(name, envs_of(name, grid))] = {**{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()},
+                             "grid": grid,
                              "hbm_bytes_per_launch_corrected": traffic,
                              "envs": envs_of(name, grid),
                              "hbm_bytes_per_env": None if traffic is None else round(traffic / envs_of(name, grid), 2)}
@@ -127,7 +132,7 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
                 "rq_device_set_rollout_timing): in an un-profiled run they agree with the per-dispatch durations above to ~1 % "
                 "(profiles/r03_kernel_timing_calibration.md; the same command un-profiled: DESIGN.md section 6).\n")
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
-    f.write("| kernel@grid | envs | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|---|\n")
+    f.write("| kernel#n<envs> | envs | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|---|\n")
     for k, d in out.items():
         f.write(f"| `{k}` | {d.get('envs')} | {d.get('vgpr')}/{d.get('agpr')}/{d.get('sgpr')} | {d.get('avg_dur_us_fetch', 0):.2f} | "
                 f"{d.get('FETCH_SIZE_KiB_avg', 0):.1f} | {d.get('WRITE_SIZE_KiB_avg', 0):.1f} | {d.get('hbm_bytes_per_env')} |\n")
