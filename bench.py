@@ -130,7 +130,7 @@ class Shard:
 def actor_groups_per_wave(n):
     """raptor_amd/csrc/rq_kernels.hpp actor_groups_per_wave: 64-env groups per wave of k_actor_step at n envs"""
     groups = (n + 63) // 64
-    return 32 if groups >= 16384 else (4 if groups >= 4096 else 1)
+    return 1 if groups < 4096 else min(64, groups // 1024)
 
 
 def actor_step_kernel_name(n, actor="rq::ActorF32T<true>"):
@@ -193,21 +193,73 @@ def fused_kernel_name(precision, n, steps_per_launch):
     return f"rq::k_rollout_fused<false, true, false, false, {actor}>"     # <NOISE, AUTORESET, RECORD, SAS, ACTOR>
 
 
+# what ONE wave per SIMD pays per instruction (tools/lonewave.hip on the MI355X, profiles/r04_lonewave.txt; core-clock cycles):
+# any instruction 4.6; an independent vector instruction 5.06 (8.25 when it reads the result of the one right before it);
+# a transcendental 8.75; v_permlane*_swap 9.4; a bf16 MFMA hidden behind >= 4 vector instructions ~6
+LONE_WAVE_CYCLES = {"valu": 5.06, "trans": 8.75, "mfma_16bit_overlapped": 6.0, "salu": 4.63}
+
+
 def sq_profile(precision):
-    """MFMA utilisation of the fused kernel from the committed SQ-counter pass (tools/sq_profile.sh):
-    matrix-pipe busy cycles / wave cycles (SQ_WAVE_CYCLES counts quad-cycles) and the co-execution share."""
+    """MFMA utilisation of the FUSED ROLLOUT kernel from its committed SQ-counter pass (tools/sq_profile.sh ->
+    profiles/rNN_sq_counters.json; exactly that file name: round 3 globbed *_sq_counters.json and read the teacher
+    kernel's counters for the bf16 rollout): matrix-pipe busy cycles / wave cycles (SQ_WAVE_CYCLES counts quad-cycles),
+    the co-execution share, the clock under this load (GRBM_GUI_ACTIVE over the eight dies / duration) and the
+    instruction counts per wave-step with the lone-wave issue model built from them."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+    import re
+    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))
+             if re.fullmatch(r"r\d+_sq_counters\.json", os.path.basename(p))]
+    for path in sorted(paths, reverse=True):
         try:
             d = json.load(open(path))[precision]
             busy, wave = d["SQ_VALU_MFMA_BUSY_CYCLES"], 4.0 * d["SQ_WAVE_CYCLES"]
-            return {"mfma_busy_frac": round(busy / wave, 4),
-                    "mfma_valu_coexec_frac_of_busy": round(d["SQ_VALU_MFMA_COEXEC_CYCLES"] / busy, 4),
-                    "issue_stall_frac": round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4),
-                    "source": os.path.basename(path)}
+            out = {"mfma_busy_frac": round(busy / wave, 4),
+                   "mfma_valu_coexec_frac_of_busy": round(d["SQ_VALU_MFMA_COEXEC_CYCLES"] / busy, 4),
+                   "issue_stall_frac": round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4),
+                   "source": os.path.basename(path)}
+            if d.get("GRBM_GUI_ACTIVE") and d.get("dur_us_pass_b"):
+                out["clock_ghz_under_load"] = round(d["GRBM_GUI_ACTIVE"] / 8.0 / (d["dur_us_pass_b"] * 1e3), 3)
+            steps = d.get("wave_steps")          # waves x steps of the profiled launch (tools/sq_profile.sh, round 4)
+            if steps:
+                mfma = d["SQ_INSTS_MFMA"] / steps
+                trans = d["SQ_INSTS_VALU_TRANS_F32"] / steps
+                valu = d["SQ_INSTS_VALU"] / steps - mfma - trans
+                out["per_wave_step"] = {"mfma": round(mfma, 1), "transcendental": round(trans, 1), "other_vector": round(valu, 1),
+                                        "scalar": round(d["SQ_INSTS_SALU"] / steps, 1),
+                                        "cycles": round(wave / steps, 1)}
+                if precision != "fp32":      # the 16-bit MFMAs hide behind the vector work: the loop is vector-issue-bound
+                    floor = (valu * LONE_WAVE_CYCLES["valu"] + trans * LONE_WAVE_CYCLES["trans"]
+                             + mfma * LONE_WAVE_CYCLES["mfma_16bit_overlapped"] + d["SQ_INSTS_SALU"] / steps * LONE_WAVE_CYCLES["salu"])
+                    out["lone_wave_issue_model_cycles"] = round(floor, 1)
+                    out["measured_over_issue_model"] = round(wave / steps / floor, 4)
+            return out
         except Exception:
             continue
     return None
+
+
+def sixteen_bit_roofline(precision, n, steps_per_launch, avg_launch_s):
+    """`roofline` of the fused kernel with a 16-bit actor (BASELINE config 5: bf16 operands; the split-f16 build): the
+    contractions run on the 16-bit matrix pipe (24 MFMAs per wave-step, a few % of its peak) BESIDE the vector unit, so
+    what bounds the kernel is the fp32 vector work that remains - gates + env, priced against the fp32 vector peak - and,
+    at one wave per SIMD, the rate at which a lone wave issues instructions at all (sq_counters.lone_wave_issue_model)."""
+    valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
+    mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
+    kname = fused_kernel_name(precision, n, steps_per_launch)
+    tr = pmc_traffic(kname, n)
+    return {"kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
+            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
+            "traffic": None if tr is None else tr["bytes_per_launch"], "traffic_source": tr,
+            "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
+                    f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the 16-bit MFMA pipe at "
+                    f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak"
+                    + (" (x3 issued: hi.hi, hi.lo, lo.hi products)" if precision == "f16x2" else "")
+                    + "; one wave per SIMD: the binding limit is the lone wave's instruction issue (5.06 cycles per vector "
+                      "instruction, 8.75 per transcendental: tools/lonewave.hip), see sq_counters.measured_over_issue_model",
+            "mfma_TFLOPs": round(mfma, 2), "mfma_peak_TFLOPs": PEAK_BF16_TFLOPS, "mfma_frac_of_peak": round(mfma / PEAK_BF16_TFLOPS, 5),
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "steps_per_launch": steps_per_launch,
+            "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
+            "sq_counters": sq_profile("bf16") if precision == "bf16" else None}
 
 
 def chunks(total, size):
@@ -308,18 +360,42 @@ def extension_probe(device, n):
     out["rollout_recorded"] = {"env_steps_per_s": round(rate, 1), "us_per_step": round(best * 1e3 / steps, 3),
                                "trajectory_bytes_per_env_step": 109, "trajectory_GBps": round(rate * 109 / 1e9, 1)}
     del traj
-    # the other actor precisions on the same workload (the headline above stays the exact-fp32 build): launches of
-    # 500 steps, kernel + launch time from stream events
+    # the other actor precisions on the same workload (the headline above stays the exact-fp32 build).  Sustained figure,
+    # like `steady_state` for the fp32 build: regions of 10 x 500-step launches back to back (the 16-bit builds draw less
+    # power and the chip clocks up under them within ~1.5 ms: a single launch behind an idle gap runs ~12 % slower, also
+    # reported); kernel = each launch's own first-wave-in / last-wave-out span, launches enqueued one behind the other
     for prec, key in (("bf16", "rollout_bf16_actor"), ("f16x2", "rollout_split_f16_actor")):
         sh.policy.set_precision(prec)
-        for _ in range(3):
+        for _ in range(6):
             sh.rollout(500, "fused")
-        best = 1e9
+        regions, single = [], []
         for _ in range(5):
+            device.synchronize()
+            device.timer_start()
+            for _ in range(10):
+                sh.rollout(500, "fused")
+            regions.append(device.timer_stop() / 10)
+        for _ in range(5):
+            device.synchronize()
+            time.sleep(0.002)                       # an idle gap, as between two synchronised calls of a host loop
             device.timer_start()
             sh.rollout(500, "fused")
-            best = min(best, device.timer_stop())
-        out[key] = {"env_steps_per_s": round(n * 500 / (best * 1e-3), 1), "us_per_step": round(best * 1e3 / 500, 3)}
+            single.append(device.timer_stop())
+        for _ in range(6):
+            sh.rollout(500, "fused")
+        device.set_rollout_timing(True)
+        spans = []
+        for _ in range(10):
+            sh.rollout(500, "fused")
+            spans.append(device.last_rollout_ms())
+        device.set_rollout_timing(False)
+        ms, kernel_ms = float(np.median(regions)), float(np.median(spans))
+        out[key] = {"env_steps_per_s": round(n * 500 / (ms * 1e-3), 1), "us_per_step": round(ms * 1e3 / 500, 3),
+                    "us_per_step_kernel": round(kernel_ms * 1e3 / 500, 3),
+                    "us_per_step_single_launch_after_idle": round(float(np.median(single)) * 1e3 / 500, 3),
+                    "statistic": "median of 5 regions of 10 x 500-step launches back to back (kernel: of 10 more launches)"}
+        if prec == "bf16":      # BASELINE config 5 with its roofline (round 4), as `roofline` is built for --precision bf16
+            out[key]["roofline"] = sixteen_bit_roofline("bf16", n, 500, kernel_ms * 1e-3)
     out["rollout_split_f16_actor"]["note"] = ("operands as two f16 pieces each on v_mfma_f32_16x16x32_f16 (22 significand "
                                              "bits, known-answer error 1.2e-6): not fp32 arithmetic, not the headline")
     del sh
@@ -372,6 +448,53 @@ def teacher_probe(device, n, steps=500, hidden=64):
                                                  "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": PEAK_FP32_TFLOPS,
                                                  "frac": round(tf / PEAK_FP32_TFLOPS, 4)}
         del bank
+    return out
+
+
+def dagger_epoch_probe(device, teachers=1000, hidden=64):
+    """SURVEY.md section 8(f) rows 1 + 2 timed as the pipeline the reference's post-training would call them in (round 4):
+    one DAgger epoch of the reference collects ~77.7 k student-visited transitions (README.md:208; the step axis of its
+    training log: 75.3 M steps over 1 000 epochs) and labels them with the teacher of each quadrotor (1 000 teachers,
+    README.md:207-216) - here `rq_rollout_record` (fused rollout writing the trajectory) followed by
+    `rq_trajectory_relabel_teachers`, everything device-resident.  Two shapes of the same ~78 k transitions: one env per
+    teacher flown for 78 steps (what a per-teacher collection looks like; a 16-env tile then carries one env), and 16 envs
+    per teacher for 5 steps (whole tiles).  The reference's log spends 7.13 s per epoch on ITS whole epoch (collection in the
+    CPU l2f, teacher inference and 146 gradient steps): quoted for scale, not the same work."""
+    from raptor_amd.teachers import TeacherBank, parameter_count, balanced_teacher_assignment
+    rng = np.random.default_rng(0)
+    W = (rng.standard_normal((teachers, parameter_count(22, hidden, hidden))) * 0.1).astype(np.float32)
+    bank = TeacherBank(device, W, 22, hidden, hidden, "relu", "identity", precision="fp32")
+    out = {"teachers": teachers, "topology": f"22-{hidden}-{hidden}-4 [UPSTREAM-UNVERIFIED]",
+           "reference_log_seconds_per_epoch": 7.127, "reference_transitions_per_epoch": 77700}
+    for name, n, steps in (("one_env_per_teacher", teachers, 78), ("sixteen_envs_per_teacher", 16 * teachers, 5)):
+        sh = Shard(device, n, 0)
+        ids = (np.arange(n, dtype=np.int64) * teachers // n).astype(np.uint32)
+        tr = sh.vector.Trajectory(sh.env, steps)
+
+        def epoch():
+            tr.reset()
+            sh.vector.rollout(device, sh.env, sh.params, sh.state, sh.policy, sh.rng, steps, "fused", autoreset=True, trajectory=tr)
+            tr.relabel_teachers(bank, ids, fetch=False)
+
+        for _ in range(5):
+            epoch()
+        device.synchronize()
+        per, per_roll = [], []
+        for _ in range(9):
+            device.timer_start()
+            epoch()
+            per.append(device.timer_stop())
+        for _ in range(9):
+            tr.reset()
+            device.timer_start()
+            sh.vector.rollout(device, sh.env, sh.params, sh.state, sh.policy, sh.rng, steps, "fused", autoreset=True, trajectory=tr)
+            per_roll.append(device.timer_stop())
+        ms, ms_roll = float(np.median(per)), float(np.median(per_roll))
+        out[name] = {"envs": n, "steps": steps, "transitions": n * steps, "ms_per_epoch": round(ms, 4),
+                     "ms_rollout_record": round(ms_roll, 4), "ms_relabel": round(ms - ms_roll, 4),
+                     "transitions_per_s": round(n * steps / (ms * 1e-3), 1),
+                     "epochs_per_reference_epoch_time": round(7127.0 / ms, 1)}
+        del tr, sh
     return out
 
 
@@ -457,11 +580,85 @@ def cpu_baseline(seconds):
     c0, t0 = time.process_time(), time.perf_counter()
     value = run(n, steps)
     busy = (time.process_time() - c0) / (time.perf_counter() - t0)   # CPU-seconds per wall-second
-    return {"value": round(value, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+    # the same sample with as many threads as the container really gets (its CPU quota can sit far below the cores the
+    # OpenMP runtime sees: 128 threads on ~16 effective cores in the driver's box): the figure without oversubscription
+    eff = max(1, int(round(busy)))
+    value_eff = None
+    if eff < threads_all:
+        threads = eff
+        value_eff = run(n, max(20, steps // 2))
+        threads = threads_all
+    return {"value": round(value, 1), "unit": "env-steps/s", "cores": threads_all, "kind": "port",
             "effective_cores": round(busy, 1),      # < cores when the container's CPU quota is below its thread count
+            "value_at_effective_cores": None if value_eff is None else round(value_eff, 1),
+            "threads_at_effective_cores": eff,
             "extras": extras,
             "sample": f"{n} envs x {steps} steps of the same workload (domain-randomised, auto-reset), "
-                      f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads} threads"}
+                      f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads_all} threads"
+                      + ("" if value_eff is None else f"; again with {eff} threads ({max(20, steps // 2)} steps)")}
+
+
+def native_exchange_probe(engine, n, launches=6, repeats=5):
+    """What the path's one exchange costs where it matters (round 4): the C++ host's all-gather (rq_allgather_returns /
+    rq_comm_gathered on the REAL librccl, one rank - the communicator, the copy on the engine's stream, the event
+    hand-over to the side stream, ncclAllGather and the completion event are what N ranks execute too; only the xGMI
+    transfer itself is absent) posted after every 500-step launch with the NEXT 500-step launch enqueued right behind it,
+    at n envs per GPU.  -> us added per episode against the same launches without an exchange, the slowdown of the
+    rollout kernel itself (its own first-wave-in / last-wave-out span) with an exchange in flight beside it, the
+    exchange's latency on an otherwise idle device and the host time of the posting call."""
+    sh = engine.make_shard(n, 0)
+    ex = engine.native_exchange(1, 0, engine.native_unique_id())
+    dev = engine.device
+
+    def region(with_exchange):
+        engine.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            sh.rollout(EPISODE, "fused")
+            if with_exchange:
+                ex.post(sh)
+        if with_exchange:
+            ex.finish()
+        engine.synchronize()
+        return (time.perf_counter() - t0) / launches * 1e6
+
+    region(True)
+    region(False)                                   # clocks, lazy allocations, the communicator's first collective
+    plain = [region(False) for _ in range(repeats)]
+    with_ex = [region(True) for _ in range(repeats)]
+    engine.set_rollout_timing(True)
+    span_plain, span_beside = [], []
+    for _ in range(repeats):
+        sh.rollout(EPISODE, "fused")
+        span_plain.append(engine.last_rollout_ms() * 1e3)
+    for _ in range(repeats):
+        sh.rollout(EPISODE, "fused")                # the episode whose returns are gathered ...
+        ex.post(sh)
+        sh.rollout(EPISODE, "fused")                # ... beside this launch
+        span_beside.append(engine.last_rollout_ms() * 1e3)
+        ex.finish()
+    engine.set_rollout_timing(False)
+    alone, post_call = [], []
+    for _ in range(4 * repeats):
+        engine.synchronize()
+        t0 = time.perf_counter()
+        ex.post(sh)
+        t1 = time.perf_counter()
+        ex.finish()
+        alone.append((time.perf_counter() - t0) * 1e6)
+        post_call.append((t1 - t0) * 1e6)
+    gathered = ex.result()
+    base, withx = float(np.median(plain)), float(np.median(with_ex))
+    return {"envs": n, "launches_per_region": launches, "exchange": ex.kind + ", 1 rank, real librccl",
+            "us_per_episode_without_exchange": round(base, 2), "us_per_episode_with_exchange": round(withx, 2),
+            "added_us_per_episode": round(withx - base, 2), "added_fraction": round((withx - base) / base, 5),
+            "rollout_kernel_us": round(float(np.median(span_plain)), 2),
+            "rollout_kernel_us_with_exchange_in_flight": round(float(np.median(span_beside)), 2),
+            "rollout_slowdown_fraction": round(float(np.median(span_beside) / np.median(span_plain) - 1.0), 5),
+            "exchange_alone_us_post_to_gathered": round(float(np.median(alone)), 2),
+            "post_call_host_us": round(float(np.median(post_call)), 2),
+            "gathered_returns": int(np.prod(np.shape(gathered))),
+            "bytes_per_rank": 4 * n}
 
 
 class _NativeExchange:
@@ -760,15 +957,26 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
     flop_step = FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV
 
     def long_launches(sh, ex, n_envs, launches, label):
-        """`launches` x 500-step launches back to back, one region (clocks warm) -> dict"""
+        """`launches` x 500-step launches back to back per region (clocks warm): three regions, each timed on the wall
+        clock (barrier + synchronize on both sides, max over ranks) WITH kernel-level timing on, the kernel span read off
+        each region's last launch after the clock stopped - wall and kernel figures describe the same regions (round 3
+        took them from different ones, and the record showed a kernel time above the wall time) -> dict"""
         ss_plan = [EPISODE] * launches
         run(ss_plan, sh, ex)                         # untimed: the clocks reach their steady state
-        ss_wall, _ = timed_region(ss_plan, sh, ex)
-        ss_kernel_ms = kernel_probe_ms(ss_plan, 3, sh, ex) * len(ss_plan)
-        ss_wall = max_over_ranks([ss_wall])[0]
+        finish(ex)
+        walls3, spans3 = [], []
+        if args.mode == "fused":
+            engine.set_rollout_timing(True)
+        for _ in range(3):
+            w, _ = timed_region(ss_plan, sh, ex)
+            walls3.append(w)
+            spans3.append(engine.last_rollout_ms() if args.mode == "fused" else w * 1e3 / launches)
+        engine.set_rollout_timing(False)
+        ss_wall = float(np.median(max_over_ranks(walls3)))
+        ss_kernel_ms = float(np.mean(spans3)) * len(ss_plan)
         ss_steps = sum(ss_plan)
         ss_flops = flop_step * n_envs * ss_steps / (ss_kernel_ms * 1e-3) / 1e12
-        return {"launches": len(ss_plan), "steps_per_launch": EPISODE, "envs_per_gpu": n_envs,
+        return {"launches": len(ss_plan), "steps_per_launch": EPISODE, "envs_per_gpu": n_envs, "regions": 3,
                 "env_steps_per_s": round(n_envs * world * ss_steps / ss_wall, 1),
                 "us_per_step_wall": round(ss_wall / ss_steps * 1e6, 4),
                 "us_per_step_kernel": round(ss_kernel_ms / ss_steps * 1e3, 4),
@@ -782,9 +990,10 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
     steady = None
     if args.mode == "fused":
         steady = long_launches(shard, exchange, n, 10,
-                               "same process, after the timed regions and 10 untimed launches of the same kind; wall = barrier + "
-                               "synchronize on both sides, max over ranks, one all-gather per launch when there is more than one "
-                               "rank; kernel = first-wave-in / last-wave-out span of the last launch of three more such regions, on rank 0")
+                               "same process, after the timed regions and 10 untimed launches of the same kind; three regions: wall = "
+                               "median region (barrier + synchronize on both sides, max over ranks, one all-gather per launch when "
+                               "there is more than one rank); kernel = first-wave-in / last-wave-out span of the last launch of each "
+                               "of the SAME three regions (mean), on rank 0")
 
     # the last all-gathered returns (numpy [world * n]); one rank: the env's own
     gathered = exchange.result() if exchange is not None else None
@@ -803,7 +1012,8 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         since_exchange[0] = 0
         config4 = long_launches(shard4, ex4, n4, 4,
                                 "BASELINE config 3 (one GPU) / config 4 (262 144 envs on each of N GPUs, all-gather of returns per "
-                                "episode): 4 x 500-step launches in one region after 4 untimed ones, same process")
+                                "episode): 4 x 500-step launches per region, three regions after 4 untimed launches, same process; "
+                                "wall and kernel from the same regions")
         config4["total_envs"] = n4 * world
         del shard4
 
@@ -842,25 +1052,9 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
     launches = len(plan) if args.mode == "fused" else 3 * args.steps
     avg_launch_s = launch_ms * 1e-3                  # one rollout launch (median over the timed regions)
     if args.mode == "fused" and args.precision in ("bf16", "f16x2"):
-        # config 5: the contractions run on the bf16 XDL pipe (24 MFMAs per wave-step, a few % of its
-        # peak); what bounds the kernel is the fp32 VALU work that remains (gates + env)
         steps_per_launch = args.steps / len(plan)
-        valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
-        mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
-        kname = fused_kernel_name(args.precision, n, steps_per_launch)
-        tr = pmc_traffic(kname, n)
-        result["roofline"] = {
-            "kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
-            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
-            "traffic": None if tr is None else tr["bytes_per_launch"],
-            "traffic_source": tr,
-            "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
-                    f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the 16-bit MFMA pipe at "
-                    f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak"
-                    + (" (x3 issued: hi.hi, hi.lo, lo.hi products)" if args.precision == "f16x2" else ""),
-            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-            "steps_per_launch": steps_per_launch,
-            "sq_counters": sq_profile("bf16") if args.precision == "bf16" else None}
+        result["roofline"] = sixteen_bit_roofline(args.precision, n, steps_per_launch, avg_launch_s)
+        result["roofline"]["launches"] = launches
     elif args.mode == "fused":
         steps_per_launch = args.steps / len(plan)
         flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
@@ -888,6 +1082,12 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             "steps_per_launch": steps_per_launch,
             "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
             "sq_counters": sq_profile("fp32")}
+        sq = result["roofline"]["sq_counters"] or {}
+        if sq.get("clock_ghz_under_load"):
+            # the peak assumes 2.4 GHz; under this kernel's load the chip runs lower (GRBM_GUI_ACTIVE / duration of the
+            # profiled launch): that share of the shortfall is the power management's, not the kernel's
+            result["roofline"]["clock_ghz_under_load"] = sq["clock_ghz_under_load"]
+            result["roofline"]["frac_of_peak_at_that_clock"] = round(achieved / (PEAK_FP32_TFLOPS * sq["clock_ghz_under_load"] / 2.4), 4)
     else:
         # round 3: two launches per step - k_step also writes the next step's observation (104 B/env) from the state it
         # holds in registers, so the chain no longer re-reads the state for a k_observe launch
@@ -906,6 +1106,16 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
                              "n2097152": kernel_probe(device, 2097152, 5)}
         result["extensions_n65536"] = extension_probe(device, ENVS_PER_GPU)
         result["extensions_n65536"]["teacher_bank"] = teacher_probe(device, ENVS_PER_GPU)
+        result["dagger_epoch"] = dagger_epoch_probe(device)
+        try:       # needs an RCCL to bind (librccl of the process or of ROCm): absent -> the reason, not a failed benchmark
+            result["native_exchange_1rank"] = {f"n{m}": native_exchange_probe(engine, m) for m in (ENVS_PER_GPU, 262144)}
+            result["native_exchange_1rank"]["note"] = (
+                "rq_allgather_returns + rq_comm_gathered on the real librccl with ONE rank, posted after every 500-step "
+                "launch with the next launch enqueued behind it: the host-side and stream-ordering cost every rank of an N-GPU "
+                "run pays per episode (copy, events, ncclAllGather call, completion); the xGMI transfer of N x 4 B x envs is "
+                "what a multi-GPU node adds on top (256 KiB per rank at 65 536 envs: ~2 us per hop at 153 GB/s per link)")
+        except Exception as exc:      # noqa: BLE001
+            result["native_exchange_1rank"] = {"unavailable": str(exc)}
         result["readme_loop_n8"] = api_loop_probe(device)
         result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
     if world == 1 and not args.no_cpu_baseline:

@@ -114,10 +114,14 @@ hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // hidden_in != nullptr: the state BEFORE the step is read from there and `hidden` only written (speculative evaluation).
 // `packed`: the MFMA A-operand image of the policy (rq::pack_policy), RQ_PACKED_FLOATS floats
 // 64-env groups one wave of k_actor_step works through at n envs (1 = the non-streaming instantiation); bench.py's
-// launch_grid mirrors this
+// actor_groups_per_wave mirrors this.  From 262 144 envs on the launch keeps ~1 024 waves - one per SIMD - and lets each
+// stream through groups / 1 024 groups (tools/actor_gpw_sweep.py, round 4: 1 048 576 envs 61.5 us with 16 groups per wave
+// against 103 with 32 = 512 waves; 2 097 152 envs 119 - 124 us with 32 against 128 with 8 and 137 with 1 or 16)
 inline uint32_t actor_groups_per_wave(uint32_t n) {
     const uint32_t groups = (n + 63u) / 64u;
-    return groups >= 16384u ? 32u : (groups >= 4096u ? 4u : 1u);
+    if (groups < 4096u) return 1u;
+    const uint32_t g = groups / 1024u;
+    return g > 64u ? 64u : g;
 }
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
                              float* hidden, uint32_t ld_h, float* act, uint32_t ld_act, const uint8_t* frozen,

@@ -159,6 +159,7 @@ def test_launch_grid_matches_the_launchers():
     assert bench.actor_step_kernel_name(2097152) == "rq::k_actor_step<rq::ActorF32T<true>, true>"      # ... another kernel
     assert bench.actor_step_kernel_name(65536) == "rq::k_actor_step<rq::ActorF32T<true>, false>"
     assert bench.launch_grid(bench.actor_step_kernel_name(262144), 262144) == 65536        # 4 groups per wave
+    assert [bench.actor_groups_per_wave(n) for n in (1000, 65536, 262080, 262144, 1048576, 2097152, 8388608)] == [1, 1, 1, 4, 16, 32, 64]
     assert bench.pmc_key("rq::k_step<false>", 65536) == "rq::k_step<false>#n65536"
     # the committed tables of rounds 1-3 (keyed by grid) still resolve for the kernels whose grid is the env count
     assert bench.pmc_traffic("rq::k_step<false>", 2097152)["bytes_per_env"] > 250

@@ -34,12 +34,14 @@ for prec in ("fp32", "bf16"):
             d = per[r["Dispatch_Id"]]
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             d["_dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        # the 1000-step launches are the longest dispatches: average over them
+        # the longest dispatch is tools/launch_fit.py's 2000-step warm-up launch of 65 536 envs (1 024 waves): it is what
+        # the counters below describe, `wave_steps` = 1 024 x 2 000 turns them into per-wave-step figures
         longest = max(v["_dur_us"] for v in per.values())
         sel = [v for v in per.values() if v["_dur_us"] > 0.8 * longest]
         for k in sel[0]:
             rec[k if k != "_dur_us" else f"dur_us_pass_{p}"] = sum(v[k] for v in sel) / len(sel)
         rec[f"launches_pass_{p}"] = len(sel)
+    rec["wave_steps"] = 1024 * 2000
     out[prec] = rec
 dst = os.path.join(os.path.dirname(src), f"profiles_{tag}")
 os.makedirs(dst, exist_ok=True)
