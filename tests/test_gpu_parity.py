@@ -910,6 +910,35 @@ def test_rollout_fused_equals_chained_ragged_sizes_all_precisions(device, oracle
     assert a.env.finished_counts().min() >= 1                      # episodes ended and restarted on the way
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streaming_actor_step_past_the_batch_where_waves_take_several_groups(device, oracle, precision):
+    """Round 4: from 262 144 envs on k_actor_step is another instantiation - a wave streams through groups / 1 024 groups
+    of 64 envs with the next group's inputs in flight.  262 144 + 129 envs (4 groups per wave, the last wave's groups
+    partly and wholly past the batch): the chain built on it equals the fused kernel bit for bit, and the actions of a
+    sample of envs equal the oracle's actor on the same observations."""
+    n = 262144 + 129
+    kw = dict(seed=9, episode_step_limit=4)
+    a, b = World(device, oracle, n, **kw), World(device, oracle, n, **kw)
+    a.policy.set_precision(precision); b.policy.set_precision(precision)
+    for chunk in (3, 2):
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", True)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", True)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
+    assert np.array_equal(a.env.returns(), b.env.returns())
+    if precision == "fp32":
+        b.vector.observe(device, b.env, b.params, b.state, None, b.rng)
+        obs = b.env.observation()
+        H = b.policy.hidden_state(n)
+        b.policy.evaluate_step_device(b.env)
+        act = b.env.action()
+        pick = np.r_[0:70, 131000:131100, n - 200:n]
+        Hs = np.ascontiguousarray(H[pick])
+        ref = oracle.actor_batch_step(b.policy.weights, np.ascontiguousarray(obs[pick, :22]), Hs)
+        assert np.abs(act[pick] - ref).max() < 10 * ACTOR_TOL
+        assert np.abs(b.policy.hidden_state(n)[pick] - Hs).max() < 10 * ACTOR_TOL
+
+
 @pytest.mark.parametrize("case", range(int(os.environ.get("RQ_RANDOM_CASES", "32"))))
 def test_fused_equals_chained_over_random_settings(device, oracle, case):
     """Random batch size, episode limit, thresholds, noise, disturbance, action history, actor precision, recording and chunking -
