@@ -461,8 +461,17 @@ RQ_API int rq_comm_destroy(rq_comm* comm);
 RQ_API int rq_comm_info(const rq_comm* comm, uint32_t* n_ranks, uint32_t* rank);
 /* ENQUEUE the all-gather of this rank's rq_env_get_finished_returns: the copy on the env's own stream (right
  * behind the rollout that produced the returns), the collective on a side stream behind an event, double-
- * buffered - it overlaps the next rollout and the host does not block.  Every rank must call it the same number
- * of times with envs of the same size. */
+ * buffered; the host does not block.  Every rank must call it the same number of times with envs of the same size.
+ * What "beside the next rollout" costs, measured (round 4, one MI355X, the REAL librccl with one rank, an exchange posted
+ * after every 500-step fused launch with the next launch enqueued right behind it; bench.py `native_exchange_1rank`):
+ *   65 536 envs  (1 416 us per episode): + 18 us per episode (1.3 %); the rollout kernel's own span with an exchange in
+ *                flight beside it 1 412 us against 1 423 us without (no slowdown); exchange alone on an idle device, post
+ *                to gathered: 28 us; the posting call itself: 9 us of host time
+ *   262 144 envs (5 618 us per episode): + 38 us per episode (0.7 %); kernel span unchanged (5 648 us both ways)
+ * The fused kernel holds every SIMD with one 512-register wave, so the collective's own kernel can only start as waves
+ * retire - which is what these figures contain: the copy + events + ncclAllGather + completion ride in the gap between two
+ * launches.  With N ranks the xGMI transfer of N x 4 B x n_envs (2 MiB at 8 x 65 536) comes on top; that part has not run
+ * on hardware here (one GPU per box). */
 RQ_API int rq_allgather_returns(rq_env* env, rq_comm* comm);
 /* Wait for the most recently enqueued all-gather: device pointer to the [n_ranks * n_envs] result in global env
  * order (valid until the second next rq_allgather_returns), its length, and optionally a host copy. */
