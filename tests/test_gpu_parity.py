@@ -939,6 +939,65 @@ def test_streaming_actor_step_past_the_batch_where_waves_take_several_groups(dev
         assert np.abs(b.policy.hidden_state(n)[pick] - Hs).max() < 10 * ACTOR_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_short_launches_follow_every_change_between_them(device, oracle, precision):
+    """Many short fused launches with episode ends everywhere (the ahead-of-time sampled next-episode values are parked, used
+    and refilled across them), and between the launches everything those values are a function of is changed in turn -
+    another seed, another initial-state range, a disturbance switched on, parameters re-sampled and set from the host, the
+    episode counters moved by sample_initial_state and by a chained rollout, a frozen batch thawed, another parameter
+    object: after every change the fused path equals the chain of API-granular kernels bit for bit (state, policy state,
+    every statistic).  (Written for an experiment that kept the parked values from launch to launch - profiles/
+    r04_ab_not_kept.txt; what it pins holds for any such cache.)"""
+    n = 777
+    kw = dict(seed=21, episode_step_limit=5, termination_position=0.6)
+    a, b = World(device, oracle, n, **kw), World(device, oracle, n, **kw)
+    a.policy.set_precision(precision); b.policy.set_precision(precision)
+
+    def both(f):
+        f(a); f(b)
+
+    def run(chunks, autoreset=True, modes=("fused", "chained")):
+        for c in chunks:
+            a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, c, modes[0], autoreset)
+            b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, c, modes[1], autoreset)
+        assert np.array_equal(a.state.numpy(), b.state.numpy())
+        assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
+        for name in ("returns", "episode_steps", "finished_returns", "finished_lengths", "finished_counts",
+                     "finished_terminated", "rewards", "terminated", "done_codes", "frozen", "episode_index"):
+            assert np.array_equal(getattr(a.env, name)(), getattr(b.env, name)()), name
+
+    def set_cfg(w, **over):
+        cfg = w.env.config
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        w.env.config = cfg
+
+    run([1, 1, 2, 1, 3, 1, 1, 7, 1, 2])                                   # values parked by one launch, used by the next
+    both(lambda w: w.vector.initialize_rng(device, w.rng, 99))             # another seed
+    run([1, 2, 1, 1, 4])
+    both(lambda w: set_cfg(w, init_max_position=0.2, init_max_angle=0.3))  # another initial-state distribution
+    run([1, 1, 3, 1])
+    both(lambda w: set_cfg(w, disturbance_force_std=0.1, disturbance_torque_std=0.05))     # values 13..18 come alive
+    run([2, 1, 1, 5])
+    both(lambda w: w.vector.sample_initial_parameters(device, w.env, w.params, w.rng))     # mass / arm scale the disturbance
+    run([1, 1, 2, 1])
+    P = a.params.numpy().copy()
+    P[:, 0] *= np.float32(1.25)                                                               # heavier: set from the host
+    both(lambda w: w.params.set(P))
+    run([1, 3, 1, 1])
+    both(lambda w: w.vector.sample_initial_state(device, w.env, w.params, w.state, w.rng))   # moves every episode counter
+    run([1, 1, 2])
+    run([3, 4], modes=("chained", "chained"))                                                # counters moved by the other path
+    run([1, 1, 1, 6])
+    run([9], autoreset=False)                                                                 # every env ends and freezes ...
+    assert a.env.frozen().all()
+    run([1, 2, 1])                                                                            # ... and is thawed by the next launch
+    for w in (a, b):                                                                          # another parameter OBJECT on the same env
+        w.params = w.vector.VectorParameters()
+        w.vector.sample_initial_parameters(device, w.env, w.params, w.rng)
+    run([1, 1, 2, 1])
+
+
 @pytest.mark.parametrize("case", range(int(os.environ.get("RQ_RANDOM_CASES", "32"))))
 def test_fused_equals_chained_over_random_settings(device, oracle, case):
     """Random batch size, episode limit, thresholds, noise, disturbance, action history, actor precision, recording and chunking -
