@@ -1165,6 +1165,11 @@ def spawn_local_ranks(args, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
     status, alive = 0, set(range(n))
+    import signal
+
+    def stop(signum, _frame):          # the launcher being told to stop (a driver's timeout) takes its ranks along
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, stop)
     try:
         while alive:
             for r in sorted(alive):

@@ -83,6 +83,9 @@ class StubEngine:
         self.rank = int(os.environ.get("RANK", "0"))
         if os.environ.get("RQ_STUB_DIE_RANK") == str(self.rank):      # a rank that dies before the rendezvous
             raise SystemExit(7)
+        if os.environ.get("RQ_STUB_PIDDIR"):                           # lets a test see which processes the launcher started
+            with open(os.path.join(os.environ["RQ_STUB_PIDDIR"], f"rank{self.rank}.pid"), "w") as fh:
+                fh.write(str(os.getpid()))
         self.last_ms = 0.0
         self.timing = False
         self.t0 = 0.0

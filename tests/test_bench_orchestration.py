@@ -130,6 +130,40 @@ def test_plain_command_fails_when_a_rank_dies():
     assert not [l for l in out.stdout.split("\n") if l.lstrip().startswith("{")]        # no record of a broken job
 
 
+@pytest.mark.timeout(300)
+def test_stopping_the_launcher_stops_its_ranks(tmp_path):
+    """SIGTERM to `python bench.py --gpus 2` (a driver's timeout): the ranks it started do not outlive it."""
+    import signal
+    import time
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), RQ_STUB_PIDDIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "tests.bench_stub_engine", "--backend", "gloo",
+                          "--no-cpu-baseline", "--envs-per-gpu", "64", "--gpus", "2", "--steps", "500", "--warmup", "400000000"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)     # a 400 s warm-up
+    pids, deadline = [], time.time() + 120
+    while time.time() < deadline and len(pids) < 2:
+        pids = [int(open(os.path.join(tmp_path, f)).read()) for f in os.listdir(tmp_path) if f.endswith(".pid")
+                and open(os.path.join(tmp_path, f)).read().strip()]
+        time.sleep(0.2)
+    assert len(pids) == 2, "the ranks never came up"
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode != 0 and "{" not in out
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+            # a zombie of a grandchild cannot exist here (the launcher reaped or killed its children); still running = failure
+            with open(f"/proc/{pid}/stat") as fh:
+                alive = fh.read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, f"rank process {pid} outlived the launcher"
+
+
 def test_gpus_flag_must_match_the_launchers_world_size():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))

@@ -1149,7 +1149,7 @@ def _closed_loop_agreement(w, weights, steps, flags, min_same_history=0.99, min_
     insensitive = (np.abs(Sp[:, :13] - w.S[:, :13]).max(axis=1) < 1e-5) & \
                   (stp.fin_counts == w.st.fin_counts) & (stp.fin_lengths == w.st.fin_lengths)
     _report_fractions(w, steps, flags, same_history.mean(), insensitive.mean(), same_history[insensitive].mean())
-    # thresholds sit just under the fractions measured on the MI355X (profiles/r02_closed_loop_fractions.json:
+    # thresholds sit just under the fractions measured on the MI355X (profiles/r04_closed_loop_fractions.json, same figures as r02 / r03:
     # 500 steps: same history 0.996-1.0, insensitive 0.83 with domain randomisation, 0.875 without)
     assert same_history.mean() >= min_same_history, same_history.mean()
     assert insensitive.mean() >= min_insensitive, insensitive.mean()
