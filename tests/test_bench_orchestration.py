@@ -199,3 +199,24 @@ def test_launch_grid_matches_the_launchers():
     assert bench.pmc_traffic("rq::k_step<false>", 2097152)["bytes_per_env"] > 250
     assert bench.launch_grid("rq::k_step<false>", 65536) == 65536
     assert bench.launch_grid("rq::k_rollout_fused<false, true, false, false, rq::ActorF32T<false> >", 1000) == 1024
+
+
+def test_record_readers_pick_the_right_committed_profiles():
+    """Round 3 printed the teacher kernel's SQ counters as the bf16 rollout's (a glob caught the wrong file) and keyed the PMC
+    tables by grid size; round 4: the rollout's counters come from rNN_sq_counters.json by exact name, carry the clock under
+    load, the per-wave-step instruction counts and the lone-wave issue model; PMC entries resolve by (kernel, env count) for the
+    kernels whose grids coincide."""
+    import bench
+    for prec in ("fp32", "bf16"):
+        sq = bench.sq_profile(prec)
+        assert sq is not None and __import__("re").fullmatch(r"r\d+_sq_counters\.json", sq["source"]), sq
+        assert 1.8 < sq["clock_ghz_under_load"] < 2.5
+    bf = bench.sq_profile("bf16")
+    assert bf["per_wave_step"]["mfma"] == pytest.approx(24.0, abs=0.1) and bf["per_wave_step"]["transcendental"] == pytest.approx(96.0, abs=0.1)
+    assert 0.9 < bf["measured_over_issue_model"] < 1.05             # the bf16 loop runs at the lone wave's issue rate
+    assert bench.sq_profile("fp32")["per_wave_step"]["mfma"] == pytest.approx(120.0, abs=0.1)
+    big, small = bench.pmc_traffic(bench.actor_step_kernel_name(2097152), 2097152), bench.pmc_traffic(bench.actor_step_kernel_name(65536), 65536)
+    assert big["kernel"].endswith("true>") and small["kernel"].endswith("false>")          # same grid, two kernels, two entries
+    assert big["bytes_per_env"] == pytest.approx(232, abs=3) and small["bytes_per_env"] == pytest.approx(236, abs=6)
+    fused = bench.pmc_traffic(bench.fused_kernel_name("bf16", 65536, 500), 65536)
+    assert fused is not None and 460 < fused["bytes_per_env"] < 700
