@@ -25,10 +25,12 @@ DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-a
 DEVICE_FLAGS += os.environ.get("RQ_EXTRA_HIPCC_FLAGS", "").split()      # compiler-flag experiments only
 SOURCES = ["rq_kernels.hip", "rq_kernels_16bit.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
 HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_rollout.hpp", "rq_host.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
-# per-source flags: the 16-bit actors' fused rollout loop is scheduled for instruction-level parallelism (a lone wave
-# stalls ~3 cycles when an instruction reads the result of the one right before it: tools/lonewave.hip, rq_rollout.hpp)
-SOURCE_FLAGS = {"rq_kernels_16bit.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
-
+# per-source flags.  Round 4 built rq_kernels_16bit.hip with -mllvm -amdgpu-sched-strategy=max-ilp (a lone wave stalls ~3 cycles
+# when an instruction reads the result of the one right before it, tools/lonewave.hip; 24 -> 5 such pairs in the bf16 loop).  With
+# it the TWO-waves-per-SIMD bf16 build (ActorBF16Lean, > 65 536 envs) gave run-to-run different results - whole 16-env tiles, with
+# and without auto-reset, default scheduler: never (tests/test_gpu_parity.py::test_fused_rollout_is_deterministic) - and the gain
+# on the one-wave build was inside the box-to-box spread (1.449 -> 1.406 us/step on one box, nothing on the next): dropped.
+SOURCE_FLAGS = {}
 
 def _hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):

@@ -1,6 +1,6 @@
 // rq_kernels_16bit.hip - the fused rollout kernel instantiated for the 16-bit actors (bf16 operands: BASELINE config 5;
 // split-f16 operands), in a translation unit of its own because it wants another instruction scheduler than the
-// hand-ordered fp32 build: see rq_rollout.hpp.  Built with -mllvm -amdgpu-sched-strategy=max-ilp (raptor_amd/build.py).
+// hand-ordered fp32 build: see rq_rollout.hpp (and raptor_amd/build.py SOURCE_FLAGS for what was tried and taken back).
 #include "rq_rollout.hpp"
 
 namespace rq {

@@ -2,11 +2,13 @@
 // actor build, shared by the two translation units that instantiate it:
 //   rq_kernels.hip        the exact-fp32 actors (ActorF32 / ActorF32Lean): their instruction order is pinned by hand
 //                         (sched_barrier / sched_group_barrier around the MFMA batches);
-//   rq_kernels_16bit.hip  the bf16 and split-f16 actors, whose MFMAs co-execute with the vector unit: compiled with
-//                         -mllvm -amdgpu-sched-strategy=max-ilp (raptor_amd/build.py).  A lone wave issues one vector
-//                         instruction per 5.06 cycles but stalls to 8.25 when an instruction consumes the result of the one
-//                         right in front of it (tools/lonewave.hip): the default scheduler leaves ~24 such pairs per step
-//                         in that loop, max-ilp 5 (1.449 -> 1.406 us per step of 65 536 envs, round 4).
+//   rq_kernels_16bit.hip  the bf16 and split-f16 actors, whose MFMAs co-execute with the vector unit and whose loop is therefore
+//                         a scheduling problem of its own.  Round 4 compiled this unit with -mllvm
+//                         -amdgpu-sched-strategy=max-ilp (a lone wave issues one vector instruction per 5.06 cycles but stalls to
+//                         8.25 when it consumes the result of the one right in front of it, tools/lonewave.hip: 24 -> 5 such pairs
+//                         per step) - and took it back: the two-waves-per-SIMD bf16 build then differed from run to run
+//                         (raptor_amd/build.py SOURCE_FLAGS, test_fused_rollout_is_deterministic).  The unit stays the place
+//                         for such per-build flags.
 #pragma once
 #include <hip/hip_ext.h>
 
