@@ -134,15 +134,15 @@ def actor_groups_per_wave(n):
 
 
 def actor_step_kernel_name(n, actor="rq::ActorF32T<true>"):
-    """The k_actor_step instantiation launch_actor_step picks at n envs, as rocprofv3 prints it (the streaming form - several
-    groups per wave - and the one-group form are two kernels: their names tell a 2 097 152-env launch from a 65 536-env one
-    even where the grids coincide)."""
-    return f"rq::k_actor_step<{actor}, {'true' if actor_groups_per_wave(n) > 1 else 'false'}>"
+    """The kernel launch_actor_step picks at n envs, as rocprofv3 prints it: one 64-env group per wave (k_actor_step) up to
+    262 144 envs, the streaming kernel (k_actor_stream: groups / 1 024 groups per wave) beyond - two kernels, two names: a profile
+    tells a 2 097 152-env launch from a 65 536-env one even where the grids coincide."""
+    return f"rq::k_actor_stream<{actor} >" if actor_groups_per_wave(n) > 1 else f"rq::k_actor_step<{actor} >"
 
 
 def launch_grid(kernel, n):
     """Threads in the grid the launcher picks for `kernel` at n envs (raptor_amd/csrc/rq_kernels.hip)."""
-    if kernel.startswith("rq::k_actor_step"):
+    if kernel.startswith("rq::k_actor_stream"):
         groups = (n + 63) // 64
         gpw = actor_groups_per_wave(n)
         return ((groups + gpw - 1) // gpw * 64 + 255) // 256 * 256

@@ -119,82 +119,131 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
 // wave-uniform control flow with all 64 lanes holding valid data: lanes past the end of the
 // batch (and frozen envs) compute on a clamped index and only their STORES are predicated —
 // no lane leaves early.
-// STREAM: a wave works through groups_per_wave consecutive 64-env groups with the next group's inputs in flight (large
-// batches: the 18 KB operand image per wave is amortised and memory and matrix phases overlap); !STREAM: one group per wave,
-// no loop and no prefetch (up to 262 144 envs - round 4: the streaming form's unconditional prefetch re-read the wave's only
-// group).  Two instantiations, two kernel names: a profile tells the 2 097 152-env launch from the 65 536-env one even
-// where their grids coincide (32 groups per wave at 2 M envs = the 1 024 waves of 65 536 envs).
-template <typename ACTOR, bool STREAM>
-__global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, uint32_t groups_per_wave,
-                                                       const float* __restrict__ packed,
+// One 64-env group per wave (every batch up to 262 144 envs, and the host-row mailbox path of the small ones); the large
+// batches take k_actor_stream below.
+template <typename ACTOR>
+__global__ __launch_bounds__(kBlock, 2) void k_actor_step(uint32_t n, const float* __restrict__ packed,
                                                        const float* __restrict__ obs, uint32_t ld_obs,
                                                        const float* hidden_in, float* hidden,   // the same buffer unless speculative
                                                        uint32_t ld_h, float* __restrict__ act, uint32_t ld_act,
                                                        const uint8_t* __restrict__ frozen, SasArgs sas,
                                                        Mailbox mb) {
     ACTOR actor;
-    actor.template load<kBlock / 64>(packed);     // 18 KB of operand image per wave: amortised over groups_per_wave x 64 envs
+    actor.template load<kBlock / 64>(packed);     // 18 KB of operand image per wave
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t first = wave * groups_per_wave * 64;
-    // inputs of a 64-env group: 22 observation features of the lane's env, the Q-layout hidden state, the frozen flag
-    auto load_group = [&](uint32_t wave_base, float (&x)[22], float (&hQ)[4][4], uint32_t& fz) {
-        const uint32_t i0 = wave_base + lane;
-        const uint32_t i = i0 < n ? i0 : n - 1;
-        if (mb.rows_in != nullptr) {         // wave-uniform (kernel argument)
+    const uint32_t wave_base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
+    if (wave_base >= n) { mailbox_signal(mb); return; }          // wave-uniform
+    const uint32_t i0 = wave_base + lane;
+    const uint32_t i = i0 < n ? i0 : n - 1;
+    float x[22], hQ[4][4], a[4];
+    if (mb.rows_in != nullptr) {         // wave-uniform (kernel argument)
 #pragma unroll
-            for (int k = 0; k < 22; ++k) x[k] = mb.rows_in[(size_t)i * mb.in_stride + k];
-        } else {
+        for (int k = 0; k < 22; ++k) x[k] = mb.rows_in[(size_t)i * mb.in_stride + k];
+    } else {
 #pragma unroll
-            for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
-        }
-        load_hidden_q(hidden_in, ld_h, wave_base, n, hQ);      // == hidden unless the new state goes elsewhere (speculation)
-        fz = frozen != nullptr ? (uint32_t)frozen[i] : 0u;
-    };
-    if (first >= n) { mailbox_signal(mb); return; }          // wave-uniform
-    const uint32_t n_groups = STREAM ? min(groups_per_wave, (n - first + 63u) / 64u) : 1u;
-    float x[22], hQ[4][4];
-    uint32_t fz;
-    load_group(first, x, hQ, fz);
-#pragma unroll 1
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        const uint32_t wave_base = first + g * 64;
-        // software pipeline: the next group's loads are in flight while this group's MFMAs run (the waves of a launch
-        // move in lock-step, so without it the memory and the matrix phases alternate).  Vector-memory operations
-        // complete in order and the compiler's wait for this group's inputs counts what was issued behind them on
-        // EVERY path: the prefetch is therefore unconditional (the last group re-reads itself) and brings the frozen
-        // flag along - a load consumed right here would wait for everything issued before it, the prefetch included.
-        float xn[22], hn[4][4];
-        uint32_t fzn;
-        if constexpr (STREAM) load_group(g + 1 < n_groups ? wave_base + 64 : wave_base, xn, hn, fzn);
-        const uint32_t i0 = wave_base + lane;
-        const uint32_t i = i0 < n ? i0 : n - 1;
-        const bool commit = (i0 < n) && fz == 0;
-        const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
-        float a[4];
-        actor.step(x, hQ, a);
-        if (sas.mode)                        // wave-uniform (kernel argument)
-            sample_and_squash(sas, sas.epoch + (sas.epoch_base != nullptr ? *sas.epoch_base : 0u), sas.env_offset + i, hQ, a);
-        store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
-        if (commit) {
+        for (int k = 0; k < 22; ++k) x[k] = field(obs, k, ld_obs)[i];
+    }
+    load_hidden_q(hidden_in, ld_h, wave_base, n, hQ);      // == hidden unless the new state goes elsewhere (speculation)
+    const uint32_t fz = frozen != nullptr ? (uint32_t)frozen[i] : 0u;
+    const bool commit = (i0 < n) && fz == 0;
+    const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
+    actor.step(x, hQ, a);
+    if (sas.mode)                        // wave-uniform (kernel argument)
+        sample_and_squash(sas, sas.epoch + (sas.epoch_base != nullptr ? *sas.epoch_base : 0u), sas.env_offset + i, hQ, a);
+    store_hidden_q(hidden, ld_h, wave_base, commit_mask, hQ);
+    if (commit) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) field(act, k, ld_act)[i] = a[k];
-            if (mb.rows_out != nullptr) {
+        for (int k = 0; k < 4; ++k) field(act, k, ld_act)[i] = a[k];
+        if (mb.rows_out != nullptr) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) mb.rows_out[(size_t)i * 4 + k] = a[k];
-            }
-        }
-        if constexpr (STREAM) {
-#pragma unroll
-            for (int k = 0; k < 22; ++k) x[k] = xn[k];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hQ[t][r] = hn[t][r];
-            fz = fzn;
+            for (int k = 0; k < 4; ++k) mb.rows_out[(size_t)i * 4 + k] = a[k];
         }
     }
     mailbox_signal(mb);
+}
+
+// The streaming form for the large batches (from 262 144 envs): a wave works through groups_per_wave consecutive 64-env groups,
+// the next group's inputs in flight while this one is on the matrix cores - the 18 KB operand image per wave is amortised and
+// memory and matrix phases overlap (the waves of a launch move in lock-step, so without it they alternate).  Round 4 took the
+// per-access overhead out of the loop.  Written with plain pointers it spent, per group, 91 64-bit address additions (one per load
+// and store: field row base + lane), 53 register copies (the prefetched group moved into the working registers) and five
+// exec-masked store blocks: ~0.5 us of a lone wave's issue slots per 2.5 us group.  Here every access is a buffer
+// instruction - resource = the buffer, scalar offset = the field row, vector offset = the lane's env (one shift per group) -
+// stores of lanes that must not commit are sent out of range (the hardware drops them), and the loop is unrolled by two over
+// two register sets that swap roles.  Same loads, same arithmetic (ACTOR::step), same stores: bit-identical results.
+template <typename ACTOR>
+__global__ __launch_bounds__(kBlock, 2) void k_actor_stream(uint32_t n, uint32_t groups_per_wave, const float* __restrict__ packed,
+                                                            const float* __restrict__ obs, uint32_t ld_obs,
+                                                            const float* hidden_in, float* hidden, uint32_t ld_h,
+                                                            float* __restrict__ act, uint32_t ld_act,
+                                                            const uint8_t* __restrict__ frozen, SasArgs sas) {
+    ACTOR actor;
+    actor.template load<kBlock / 64>(packed);
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t first = wave * groups_per_wave * 64;
+    if (first >= n) return;                                  // wave-uniform
+    const uint32_t n_groups = min(groups_per_wave, (n - first + 63u) / 64u);
+    const uint32_t row_o = ld_obs * 4u, row_h = ld_h * 4u, row_a = ld_act * 4u;          // bytes per field row
+    const __amdgpu_buffer_rsrc_t r_obs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(obs), 0, 22u * row_o, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_hin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hidden_in), 0, 16u * row_h, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_hout = __builtin_amdgcn_make_buffer_rsrc(hidden, 0, 16u * row_h, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc(act, 0, 4u * row_a, 0x00020000);
+    const uint32_t q_rows = q * 4u * row_h;                  // this lane group's first hidden row (Q layout: rows 4q .. 4q + 3)
+    struct Group { float x[22]; float hQ[4][4]; uint32_t fz; };
+    auto load_group = [&](uint32_t wave_base, Group& G) {
+        const uint32_t i0 = wave_base + lane;
+        const uint32_t i = i0 < n ? i0 : n - 1;              // lanes past the batch shadow env n - 1 (finite inputs for the MFMAs)
+#pragma unroll
+        for (int k = 0; k < 22; ++k)
+            G.x[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_obs, i * 4u, (uint32_t)k * row_o, 0));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t e = wave_base + 16 * t + j;
+            e = e < n ? e : n - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                G.hQ[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_hin, e * 4u + q_rows, (uint32_t)r * row_h, 0));
+        }
+        G.fz = frozen != nullptr ? (uint32_t)frozen[i] : 0u;
+    };
+    auto step_and_store = [&](uint32_t wave_base, Group& G) {
+        const uint32_t i0 = wave_base + lane;
+        const uint32_t i = i0 < n ? i0 : n - 1;
+        const bool commit = (i0 < n) && G.fz == 0;
+        const uint64_t commit_mask = __builtin_amdgcn_ballot_w64(commit);
+        float a[4];
+        actor.step(G.x, G.hQ, a);
+        if (sas.mode)                        // wave-uniform (kernel argument)
+            sample_and_squash(sas, sas.epoch + (sas.epoch_base != nullptr ? *sas.epoch_base : 0u), sas.env_offset + i, G.hQ, a);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = (commit_mask >> (16 * t + j)) & 1ull;
+            const uint32_t vo = ok ? (wave_base + 16 * t + j) * 4u + q_rows : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, G.hQ[t][r]), r_hout, vo, (uint32_t)r * row_h, 0);
+        }
+        const uint32_t va = commit ? i * 4u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a[k]), r_act, va, (uint32_t)k * row_a, 0);
+    };
+    // Software pipeline over two register sets: while one group is on the matrix cores the other's loads are in flight.
+    // Vector-memory operations complete in order and the compiler's wait for a group's inputs counts what was issued
+    // behind them on EVERY path: the prefetch is therefore unconditional (past the wave's last group it re-reads that group).
+    Group A, B;
+    load_group(first, A);
+#pragma unroll 1
+    for (uint32_t g = 0; g < n_groups; g += 2) {
+        const uint32_t base = first + g * 64;
+        const bool has_b = g + 1 < n_groups;                 // wave-uniform
+        load_group(has_b ? base + 64 : base, B);
+        step_and_store(base, A);
+        if (!has_b) break;
+        load_group(g + 2 < n_groups ? base + 128 : base + 64, A);
+        step_and_store(base + 64, B);
+    }
 }
 
 // Raptor evaluated over a whole observation SEQUENCE in one launch (rl-tools evaluates [seq, batch, feature]
@@ -503,10 +552,15 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     static const uint32_t forced = [] { const char* e = std::getenv("RQ_ACTOR_GROUPS_PER_WAVE"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     const uint32_t gpw = forced ? forced : actor_groups_per_wave(n);       // the override: launch-shape sweeps (tools/)
     const unsigned grid = grid_for((groups + gpw - 1) / gpw * 64, kBlock);
+    // the streaming kernel: no host rows (they exist below 1 024 envs only) and every byte offset in 32 bits; otherwise one
+    // group per wave
+    const bool stream = gpw > 1 && mb.rows_in == nullptr && mb.rows_out == nullptr && mb.flag == nullptr &&
+                        (uint64_t)(ld_h > ld_obs ? ld_h : ld_obs) * 4u * 26u < 0x7FFFFFFFull;
+    const unsigned grid1 = grid_for(groups * 64, kBlock);
 #define RQ_LAUNCH_ACTOR(ACT)                                                                                                            \
     do {                                                                                                                                \
-        if (gpw > 1) k_actor_step<ACT, true><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);  \
-        else         k_actor_step<ACT, false><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb); \
+        if (stream) k_actor_stream<ACT><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas);   \
+        else        k_actor_step<ACT><<<grid1, kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);    \
     } while (0)
     if (precision == RQ_POLICY_F16X2_MFMA)     RQ_LAUNCH_ACTOR(ActorF16X2);
     else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_ACTOR(ActorBF16);

@@ -62,8 +62,8 @@ from bench import pmc_key                          # noqa: E402
 
 def envs_of(name, grid):
     """env count of a dispatch: the grid for most kernels (rounded up to the workgroup); the streaming instantiation of
-    k_actor_step packs several 64-env groups per wave, so its grid is matched against the batches bench.py launches it at"""
-    if name.startswith("rq::k_actor_step") and name.rstrip().endswith("true>"):
+    k_actor_stream packs several 64-env groups per wave, so its grid is matched against the batches bench.py launches it at"""
+    if name.startswith("rq::k_actor_stream"):
         for n in (2097152, 1048576, 524288, 262144):
             if launch_grid(name, n) == grid:
                 return n
