@@ -187,7 +187,7 @@ def fused_kernel_name(precision, n, steps_per_launch):
     if precision == "f16x2":
         actor = "rq::ActorF16X2"
     elif precision == "bf16":
-        actor = "rq::ActorBF16Lean" if n > 65536 else "rq::ActorBF16"
+        actor = "rq::ActorBF16"                     # (round 4: the one-wave build at every size)
     else:
         actor = "rq::ActorF32T<true> " if n > 65536 else "rq::ActorF32T<false> "
     return f"rq::k_rollout_fused<false, true, false, false, {actor}>"     # <NOISE, AUTORESET, RECORD, SAS, ACTOR>

@@ -6,16 +6,14 @@
 namespace rq {
 
 hipError_t launch_rollout_fused_16bit(hipStream_t s, const FusedArgs& a, bool noise, bool ar, int precision) {
-    // one wave per SIMD up to 65 536 envs, the two-waves-per-SIMD (256-register) build beyond; the SampleAndSquash
-    // stage rides on the 256-register bf16 build only
-    const bool lean = a.b.n > 65536u;
+    // The bf16 actor runs its one-wave-per-SIMD (512-register) build at EVERY batch size (round 4): the two-waves-per-SIMD build
+    // spills (124 dwords of scratch per lane) and was 4 % slower per env at 262 144 envs than the one-wave build is at 65 536
+    // (5.69 us against 4 x 1.36 us per step); only the SampleAndSquash stage still rides on the 256-register build.
     if (a.sas.mode != RQ_SAS_OFF) {
         if (precision == RQ_POLICY_F16X2_MFMA) launch_fused_actor<true, ActorF16X2>(s, a, noise, ar);
         else                                   launch_fused_actor<true, ActorBF16Lean>(s, a, noise, ar);
     } else if (precision == RQ_POLICY_F16X2_MFMA) {
         launch_fused_actor<false, ActorF16X2>(s, a, noise, ar);
-    } else if (lean) {
-        launch_fused_actor<false, ActorBF16Lean>(s, a, noise, ar);
     } else {
         launch_fused_actor<false, ActorBF16>(s, a, noise, ar);
     }

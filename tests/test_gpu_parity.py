@@ -2106,6 +2106,28 @@ def _native_exchange_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_exchange_beside_saturating_rollouts_probe(device):
+    """bench.py's `native_exchange_1rank` block (round 4) at a small size: the real librccl with one rank, an exchange posted
+    after every 500-step launch with the next launch enqueued behind it - the record's fields are there and sane, and what was
+    gathered is the env's own finished returns."""
+    import bench
+
+    class Args:
+        precision = "fp32"
+    eng = bench.GpuEngine(0, Args())
+    eng.device = device
+    try:
+        rec = bench.native_exchange_probe(eng, 4096, launches=2, repeats=2)
+    except Exception as exc:      # noqa: BLE001
+        if "rccl" in str(exc).lower():
+            pytest.skip(f"no RCCL to bind: {exc}")
+        raise
+    assert rec["envs"] == 4096 and rec["gathered_returns"] == 4096 and rec["bytes_per_rank"] == 16384
+    assert rec["us_per_episode_without_exchange"] > 100 and rec["us_per_episode_with_exchange"] > 100
+    assert abs(rec["added_fraction"]) < 0.5 and abs(rec["rollout_slowdown_fraction"]) < 0.2
+    assert 1.0 < rec["exchange_alone_us_post_to_gathered"] < 5000 and 0.5 < rec["post_call_host_us"] < 1000
+
+
 @pytest.mark.timeout(300)
 def test_native_rccl_exchange_across_gpus():
     """Two processes, two GPUs, RCCL over xGMI from the C++ host: every rank ends up with the concatenation of the
