@@ -926,6 +926,17 @@ def test_streaming_actor_step_past_the_batch_where_waves_take_several_groups(dev
     assert np.array_equal(a.state.numpy(), b.state.numpy())
     assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
     assert np.array_equal(a.env.returns(), b.env.returns())
+    # without auto-reset: envs freeze on the way (their stores are the ones the streaming kernel sends out of range)
+    for chunk in (2, 4):
+        a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, chunk, "fused", False)
+        b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, chunk, "chained", False)
+    assert a.env.frozen().all() and np.array_equal(a.env.frozen(), b.env.frozen())
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
+    assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n))
+    assert np.array_equal(a.env.done_codes(), b.env.done_codes())
+    for w in (a, b):                                     # thawed again by the next auto-reset launch
+        w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 1, "fused" if w is a else "chained", True)
+    assert np.array_equal(a.state.numpy(), b.state.numpy())
     if precision == "fp32":
         b.vector.observe(device, b.env, b.params, b.state, None, b.rng)
         obs = b.env.observation()
