@@ -330,6 +330,17 @@ def kernel_probe(device, n, reps):
                                      "data_phase_GBps": round(nb / (data_us * 1e-6) / 1e9, 1),
                                      "working_set_MB": round(nb / 1e6, 1),
                                      "resident_in_infinity_cache": bool(nb < 256 * 2 ** 20)}
+        if name == "k_actor_step" and n >= 262144:
+            # what bounds the large batches' actor step (k_actor_stream): the matrix + gate work of n / 64 groups over the
+            # 1 024 SIMDs (120 f32 MFMAs x 32 cycles + 96 transcendentals x 8.75 + ~130 vector instructions x 5.06 per group,
+            # at the clock the chip holds under fp32 MFMA load) and the traffic at the rate a pure copy of its access shape
+            # reaches (38 + 20 field-major streams: 5.3 TB/s, tools/streams.hip); perfect overlap would be their maximum
+            groups_per_simd = (n + 63) // 64 / 1024.0
+            matrix_us = groups_per_simd * (120 * 32 + 96 * 8.75 + 130 * 5.06) / 2.15e3
+            traffic_us = nb / 5.3e6
+            out[name]["bounds"] = {"kernel": actor_step_kernel_name(n), "matrix_and_gates_us": round(matrix_us, 1),
+                                   "traffic_at_copy_rate_of_its_shape_us": round(traffic_us, 1),
+                                   "measured_over_max_of_bounds": round(out[name]["us_per_launch"] / max(matrix_us, traffic_us), 3)}
         if nb < 256 * 2 ** 20:
             out[name]["note"] = ("launch-latency-bound at this size: the working set sits in the 256 MiB memory-side cache and "
                                  f"{floor_us:.1f} of the {out[name]['us_per_launch']:.1f} us are what any launch on this grid costs; "
