@@ -227,9 +227,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         }
         // everything above belongs to the actor (MFMA results consumed, transposes done); the env step below
         // contains hand-placed packed instructions the compiler's hazard tracking does not see through
-#ifdef RQ_BF16_FREE_SCHEDULE      // experiment (tools/variants.sh): let the scheduler move env work into the 16-bit actor's MFMA shadows
-        if constexpr (!WavesPerSimd<ACTOR>::bf16)
-#endif
+        // (round 4 measured the 16-bit builds without this barrier - the env step free to mix with their co-executing MFMAs:
+        // no gain)
         __builtin_amdgcn_sched_barrier(0);
         QuadState yn = y;
         f32x2 A01, A23;
