@@ -19,6 +19,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--reps", type=int, default=2000)
 ap.add_argument("--spin", action="store_true", help="hipSetDeviceFlags(hipDeviceScheduleSpin) before anything runs")
+ap.add_argument("--variants", default="lib+torch,torch only,lib only,query spin",
+                help="comma-separated subset of the region shapes to time (tools/runtime_knobs.sh times 'torch only')")
 args = ap.parse_args()
 import ctypes                                      # noqa: E402
 hip = ctypes.CDLL("libamdhip64.so")
@@ -37,7 +39,7 @@ def med(xs):
 
 
 stream = ctypes.c_void_p(int(device.stream))
-for variant in ("lib+torch", "torch only", "lib only", "query spin"):
+for variant in [v.strip() for v in args.variants.split(",") if v.strip()]:
     call, s1, s2, tot = [], [], [], []
     for _ in range(args.reps):
         torch.cuda.synchronize()
