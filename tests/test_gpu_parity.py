@@ -767,6 +767,68 @@ def test_caches_do_not_survive_their_objects(device, oracle, weights):
         gc.collect()
 
 
+@pytest.mark.parametrize("n", [8, 40, 1100])
+def test_two_worlds_interleaved_on_one_device(device, oracle, weights, n):
+    """The device keeps ONE observation cache and ONE speculated policy step (the small-batch loop of README.md:96-99), keyed
+    by the objects they were made for.  Two envs with their own params / states / policies share the device here and a
+    random schedule cuts their loops into one another at every point - observe of one, step of the other, a policy
+    evaluated on the other world's observation, loops resumed where they were left: every value handed back must be what
+    the oracle computes for THAT world (env data bit for bit, actions to ACTOR_TOL)."""
+    worlds = [World(device, oracle, n, seed=501), World(device, oracle, n, seed=502, offset=1000)]
+    shadow = []
+    for w in worlds:
+        w.sync_oracle_to_gpu_state()
+        w.next_state._ensure(w.env)
+        w.policy.reset()
+        shadow.append(dict(S=w.S.copy(), NS=None, epoch=0, obs=np.zeros((n, 26), np.float32), have_obs=False, act=None,
+                           H=np.tile(weights[2000:2016], (n, 1)).astype(np.float32)))
+    rng = np.random.default_rng(77 + n)
+    for it in range(1500):
+        k = int(rng.integers(0, 2))
+        w, sh = worlds[k], shadow[k]
+        op = rng.choice(["observe", "evaluate", "evaluate_with_the_other_policy", "step", "assign", "iteration", "get_state"])
+        if op == "observe":
+            w.vector.observe(device, w.env, w.params, w.state, sh["obs"], w.rng)
+            ref = oracle.observe(w.cfg, w.seed, sh["epoch"], w.offset, w.P, sh["S"]); sh["epoch"] += 1
+            assert np.array_equal(sh["obs"], ref), (it, k, op)
+            sh["have_obs"] = True
+        elif op in ("evaluate", "evaluate_with_the_other_policy") and sh["have_obs"]:
+            j = k if op == "evaluate" else 1 - k
+            act = worlds[j].policy.evaluate_step(sh["obs"][:, :22])
+            ref = oracle.actor_batch_step(weights, np.ascontiguousarray(sh["obs"][:, :22]), shadow[j]["H"])
+            assert np.max(np.abs(act - ref)) < 10 * ACTOR_TOL, (it, k, op)
+            sh["act"] = act
+        elif op == "step" and sh["act"] is not None:
+            w.vector.step(device, w.env, w.params, w.state, sh["act"], w.next_state, w.rng)
+            sh["NS"], r, term = oracle.step(w.cfg, w.P, sh["S"], sh["act"])
+            assert np.array_equal(w.env.rewards(), r) and np.array_equal(w.env.terminated(), term), (it, k, op)
+        elif op == "assign" and sh["NS"] is not None:
+            w.state.assign(w.next_state)
+            sh["S"] = sh["NS"].copy()
+        elif op == "iteration":
+            for _ in range(int(rng.integers(1, 4))):
+                w.vector.observe(device, w.env, w.params, w.state, sh["obs"], w.rng)
+                ref = oracle.observe(w.cfg, w.seed, sh["epoch"], w.offset, w.P, sh["S"]); sh["epoch"] += 1
+                assert np.array_equal(sh["obs"], ref), (it, k, op)
+                sh["have_obs"] = True
+                act = w.policy.evaluate_step(sh["obs"][:, :22])
+                ref = oracle.actor_batch_step(weights, np.ascontiguousarray(sh["obs"][:, :22]), sh["H"])
+                assert np.max(np.abs(act - ref)) < 10 * ACTOR_TOL, (it, k, op)
+                sh["act"] = act
+                w.vector.step(device, w.env, w.params, w.state, act, w.next_state, w.rng)
+                sh["NS"], r, term = oracle.step(w.cfg, w.P, sh["S"], act)
+                assert np.array_equal(w.env.rewards(), r) and np.array_equal(w.env.terminated(), term), (it, k, op)
+                w.state.assign(w.next_state)
+                sh["S"] = sh["NS"].copy()
+        elif op == "get_state":
+            assert np.array_equal(w.state.numpy(), sh["S"]), (it, k, op)
+            if sh["NS"] is not None:
+                assert np.array_equal(w.next_state.numpy(), sh["NS"]), (it, k, op)
+    for w, sh in zip(worlds, shadow):
+        assert np.array_equal(w.state.numpy(), sh["S"])
+        assert np.max(np.abs(w.policy.hidden_state(n) - sh["H"])) < 100 * ACTOR_TOL
+
+
 def test_speculative_policy_step_is_invisible(device, oracle, weights):
     """Round 3: in the small-batch loop rq_step also launches the policy the device last evaluated on the observation
     it cached, and evaluate_step takes that result when it is called with bit-identical rows, the same policy and an
