@@ -203,8 +203,10 @@ def sq_profile(precision):
     """MFMA utilisation of the FUSED ROLLOUT kernel from its committed SQ-counter pass (tools/sq_profile.sh ->
     profiles/rNN_sq_counters.json; exactly that file name: round 3 globbed *_sq_counters.json and read the teacher
     kernel's counters for the bf16 rollout): matrix-pipe busy cycles / wave cycles (SQ_WAVE_CYCLES counts quad-cycles),
-    the co-execution share, the clock under this load (GRBM_GUI_ACTIVE over the eight dies / duration) and the
-    instruction counts per wave-step with the lone-wave issue model built from them."""
+    the co-execution share, the clock of the PROFILED launch (GRBM_GUI_ACTIVE over the eight dies / duration: counter
+    collection itself holds the chip ~10 % below the clock of an un-profiled run, so this is not the clock of the record's
+    own launches - those carry `clock_ghz_under_load` from rq_device_last_rollout_clock) and the instruction counts per
+    wave-step with the lone-wave issue model built from them."""
     import glob
     import re
     paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))
@@ -218,7 +220,7 @@ def sq_profile(precision):
                    "issue_stall_frac": round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4),
                    "source": os.path.basename(path)}
             if d.get("GRBM_GUI_ACTIVE") and d.get("dur_us_pass_b"):
-                out["clock_ghz_under_load"] = round(d["GRBM_GUI_ACTIVE"] / 8.0 / (d["dur_us_pass_b"] * 1e3), 3)
+                out["clock_ghz_under_profiler"] = round(d["GRBM_GUI_ACTIVE"] / 8.0 / (d["dur_us_pass_b"] * 1e3), 3)
             steps = d.get("wave_steps")          # waves x steps of the profiled launch (tools/sq_profile.sh, round 4)
             if steps:
                 mfma = d["SQ_INSTS_MFMA"] / steps
@@ -333,10 +335,10 @@ def kernel_probe(device, n, reps):
         if name == "k_actor_step" and n >= 262144:
             # what bounds the large batches' actor step (k_actor_stream): the matrix + gate work of n / 64 groups over the
             # 1 024 SIMDs (120 f32 MFMAs x 32 cycles + 96 transcendentals x 8.75 + ~130 vector instructions x 5.06 per group,
-            # at the clock the chip holds under fp32 MFMA load) and the traffic at the rate a pure copy of its access shape
+            # at the 2.37 GHz the chip runs at in a busy loop) and the traffic at the rate a pure copy of its access shape
             # reaches (38 + 20 field-major streams: 5.3 TB/s, tools/streams.hip); perfect overlap would be their maximum
             groups_per_simd = (n + 63) // 64 / 1024.0
-            matrix_us = groups_per_simd * (120 * 32 + 96 * 8.75 + 130 * 5.06) / 2.15e3
+            matrix_us = groups_per_simd * (120 * 32 + 96 * 8.75 + 130 * 5.06) / 2.37e3
             traffic_us = nb / 5.3e6
             out[name]["bounds"] = {"kernel": actor_step_kernel_name(n), "matrix_and_gates_us": round(matrix_us, 1),
                                    "traffic_at_copy_rate_of_its_shape_us": round(traffic_us, 1),
@@ -372,9 +374,11 @@ def extension_probe(device, n):
                                "trajectory_bytes_per_env_step": 109, "trajectory_GBps": round(rate * 109 / 1e9, 1)}
     del traj
     # the other actor precisions on the same workload (the headline above stays the exact-fp32 build).  Sustained figure,
-    # like `steady_state` for the fp32 build: regions of 10 x 500-step launches back to back (the 16-bit builds draw less
-    # power and the chip clocks up under them within ~1.5 ms: a single launch behind an idle gap runs ~12 % slower, also
-    # reported); kernel = each launch's own first-wave-in / last-wave-out span, launches enqueued one behind the other
+    # like `steady_state` for the fp32 build: regions of 10 x 500-step launches back to back (the chip's clock follows its
+    # load of the last ~millisecond, tools/idle_clock.py: a single launch behind an idle gap runs ~12 % slower, also
+    # reported); kernel = the last launch's own first-wave-in / last-wave-out span of further such regions (back-to-back
+    # launches overlap their ends - the next one's waves start on SIMDs the finished ones freed - so a launch's own span
+    # can read slightly above the region's time per launch)
     for prec, key in (("bf16", "rollout_bf16_actor"), ("f16x2", "rollout_split_f16_actor")):
         sh.policy.set_precision(prec)
         for _ in range(6):
@@ -392,21 +396,23 @@ def extension_probe(device, n):
             device.timer_start()
             sh.rollout(500, "fused")
             single.append(device.timer_stop())
-        for _ in range(6):
-            sh.rollout(500, "fused")
         device.set_rollout_timing(True)
-        spans = []
-        for _ in range(10):
-            sh.rollout(500, "fused")
+        spans, clocks = [], []
+        for _ in range(5):                          # the LAST of ten launches back to back, as in the regions above: a
+            for _ in range(10):                     # read-back after every launch idles the chip and lowers its clock
+                sh.rollout(500, "fused")
             spans.append(device.last_rollout_ms())
+            clocks.append(device.last_rollout_clock_ghz())
         device.set_rollout_timing(False)
         ms, kernel_ms = float(np.median(regions)), float(np.median(spans))
         out[key] = {"env_steps_per_s": round(n * 500 / (ms * 1e-3), 1), "us_per_step": round(ms * 1e3 / 500, 3),
                     "us_per_step_kernel": round(kernel_ms * 1e3 / 500, 3),
                     "us_per_step_single_launch_after_idle": round(float(np.median(single)) * 1e3 / 500, 3),
-                    "statistic": "median of 5 regions of 10 x 500-step launches back to back (kernel: of 10 more launches)"}
+                    "clock_ghz_under_load": round(float(np.median(clocks)), 3),
+                    "statistic": "median of 5 regions of 10 x 500-step launches back to back (kernel span and core clock: the last launch of 5 more such regions)"}
         if prec == "bf16":      # BASELINE config 5 with its roofline (round 4), as `roofline` is built for --precision bf16
             out[key]["roofline"] = sixteen_bit_roofline("bf16", n, 500, kernel_ms * 1e-3)
+            out[key]["roofline"]["clock_ghz_under_load"] = out[key]["clock_ghz_under_load"]
     out["rollout_split_f16_actor"]["note"] = ("operands as two f16 pieces each on v_mfma_f32_16x16x32_f16 (22 significand "
                                              "bits, known-answer error 1.2e-6): not fp32 arithmetic, not the headline")
     del sh
@@ -763,6 +769,9 @@ class GpuEngine:
     def last_rollout_ms(self):
         return self.device.last_rollout_ms()
 
+    def last_rollout_clock_ghz(self):
+        return self.device.last_rollout_clock_ghz()
+
     def timer_start(self):
         self.device.timer_start()
 
@@ -896,43 +905,44 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             dist.barrier()
         return wall, posted
 
-    def kernel_probe_ms(plan, repetitions, sh=None, ex=None):
-        """Average duration (ms) of one rollout launch of the kind `plan` ends with.  Fused mode: the regions are run again
-        with kernel-level timing on (rq_device_set_rollout_timing, round 3: every wave records the wall-clock tick at which
-        it came in and went out; the duration is first-wave-in to last-wave-out on one die).  Calibrated under rocprofv3 in
-        one process: 74.7 us where the profiler prints 73.8 us per dispatch for plain launches of the
-        same kind, 1 532 vs 1 539 us for 500-step launches; round 2's hipExtLaunchKernel events read 82.7 us there, and the
-        launches carrying them ran 4 us longer themselves.  The MEAN over the repetitions, which cover whole episode
-        periods: every env's episode started together, so every 500 steps the whole batch resets at once and the launches
-        right after it run ~10 % longer than those late in the episode.  Chained mode: HIP events around a region, per step."""
-        out = []
+    probe_clock = [None]
+
+    def kernel_probe_ms(plan, repetitions, sh=None, ex=None, stride=1):
+        """Average duration (ms) of one rollout launch of the kind `plan` ends with.  Fused mode: regions exactly like the
+        timed ones (barrier + synchronize on both sides) are run again with kernel-level timing on
+        (rq_device_set_rollout_timing: every wave records the wall-clock tick at which it came in and went out and the
+        core-clock cycles of its steps; the duration is first-wave-in to last-wave-out on one die), and the records of every
+        `stride`-th region's launch are read back.  Calibrated under rocprofv3 in one process: 74.7 us
+        where the profiler prints 73.8 us per dispatch for plain launches of the same kind, 1 532 vs 1 539 us for 500-step
+        launches.  Why only every stride-th: the chip's core clock follows its load averaged over about a millisecond
+        (tools/idle_clock.py: 2.37 GHz with the ~15 us between two timed regions, 2.07 GHz behind 5 ms of idling, and many
+        launches to come back), and a read-back after EVERY launch - a copy, a synchronize, host arithmetic: ~50-100 us of
+        idle chip - lowered the clock of the launches it was timing (2.25 GHz, 65.4 us for the 20-step launch that takes
+        62.3 us inside a timed region).  Regions between two read-backs keep the timed regions' own cadence.  The stride is
+        one more than the regions of an episode, so the samples walk through the episode's phases: every env's episode
+        started together, so every 500 steps the whole batch resets at once and the launches right after it run ~10 %
+        longer than those late in the episode.  Chained mode: HIP events around a region, per step."""
+        out, clocks = [], []
         sync_all()
         if args.mode == "fused":
             engine.set_rollout_timing(True)
-            # the chip's clock state follows its recent load with a time constant of milliseconds: 50 launches read 70.7 us
-            # right after 2 000 regions, 78.8 us after half a second of idling (tools/probe_debug.py, round 3) - so the probe
-            # first runs ~10 ms of the same launches untimed (the host-side statistics since the last timed region idled the GPU)
-            for _ in range(max(2, min(400, 2500 // max(sum(plan), 1)))):     # a fixed count: every rank posts the same exchanges
-                run(plan, sh, ex)
-                finish(ex)
-                engine.last_rollout_ms()
-        for _ in range(repetitions):
-            if args.mode == "fused":
-                # last_rollout_ms waits on the engine's stream; no device-wide synchronize, no gap: the GPU stays in the state
-                # the warm-up left it in
-                run(plan, sh, ex)
-                finish(ex)
-                out.append(engine.last_rollout_ms())
-            else:
+            for k in range(repetitions * stride):
+                timed_region(plan, sh, ex)
+                if (k + 1) % stride == 0:
+                    out.append(engine.last_rollout_ms())
+                    clocks.append(engine.last_rollout_clock_ghz())
+            engine.set_rollout_timing(False)
+        else:
+            for _ in range(repetitions):
                 sync_all()
                 engine.timer_start()
                 run(plan, sh, ex)
                 out.append(engine.timer_stop() / sum(plan))
                 finish(ex)
-        engine.set_rollout_timing(False)
         sync_all()
         if os.environ.get("RQ_BENCH_DEBUG"):
             print("kernel_probe_ms", sum(plan), [round(x * 1e3, 1) for x in out], file=sys.stderr)
+        probe_clock[0] = float(np.mean(clocks)) if clocks else None       # core clock of the launches just timed
         return float(np.mean(out)) if args.mode == "fused" else float(np.median(out))
 
     # ---- warm-up: one-off costs first (RCCL communicator, first barrier, lazy allocations), then EXACTLY
@@ -963,7 +973,11 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
     elapsed, share = effective_region(walls, posts, args.steps, exchange is not None)
     # one rollout launch of the region's kind; fused: whole episode periods of regions (at least 2, ~0.2 s at most)
     periods = max(1, int(np.ceil(EPISODE / max(args.steps, 1)))) if args.steps < EPISODE else 1
-    launch_ms = kernel_probe_ms(plan, 2 * periods if args.mode == "fused" else min(len(walls), 50))
+    # fused: samples spread over the phases of an episode (two per phase, at most 60), `stride` regions apart
+    samples = min(2 * periods, 60)
+    stride = periods + max(1, periods // samples)
+    launch_ms = kernel_probe_ms(plan, samples if args.mode == "fused" else min(len(walls), 50), stride=stride)
+    launch_clock_ghz = probe_clock[0]
 
     flop_step = FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV
 
@@ -975,19 +989,25 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         ss_plan = [EPISODE] * launches
         run(ss_plan, sh, ex)                         # untimed: the clocks reach their steady state
         finish(ex)
-        walls3, spans3 = [], []
+        walls3, spans3, clocks3 = [], [], []
         if args.mode == "fused":
             engine.set_rollout_timing(True)
         for _ in range(3):
             w, _ = timed_region(ss_plan, sh, ex)
             walls3.append(w)
             spans3.append(engine.last_rollout_ms() if args.mode == "fused" else w * 1e3 / launches)
+            if args.mode == "fused":
+                clocks3.append(engine.last_rollout_clock_ghz())
         engine.set_rollout_timing(False)
         ss_wall = float(np.median(max_over_ranks(walls3)))
         ss_kernel_ms = float(np.mean(spans3)) * len(ss_plan)
         ss_steps = sum(ss_plan)
         ss_flops = flop_step * n_envs * ss_steps / (ss_kernel_ms * 1e-3) / 1e12
-        return {"launches": len(ss_plan), "steps_per_launch": EPISODE, "envs_per_gpu": n_envs, "regions": 3,
+        ss_clock = float(np.mean(clocks3)) if clocks3 else None
+        at_clock = {} if not ss_clock else {
+            "clock_ghz_under_load": round(ss_clock, 3),
+            "frac_of_peak_at_that_clock": round(ss_flops / (PEAK_FP32_TFLOPS * ss_clock / 2.4), 4)}
+        return {**at_clock, "launches": len(ss_plan), "steps_per_launch": EPISODE, "envs_per_gpu": n_envs, "regions": 3,
                 "env_steps_per_s": round(n_envs * world * ss_steps / ss_wall, 1),
                 "us_per_step_wall": round(ss_wall / ss_steps * 1e6, 4),
                 "us_per_step_kernel": round(ss_kernel_ms / ss_steps * 1e3, 4),
@@ -1093,12 +1113,16 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             "steps_per_launch": steps_per_launch,
             "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
             "sq_counters": sq_profile("fp32")}
-        sq = result["roofline"]["sq_counters"] or {}
-        if sq.get("clock_ghz_under_load"):
-            # the peak assumes 2.4 GHz; under this kernel's load the chip runs lower (GRBM_GUI_ACTIVE / duration of the
-            # profiled launch): that share of the shortfall is the power management's, not the kernel's
-            result["roofline"]["clock_ghz_under_load"] = sq["clock_ghz_under_load"]
-            result["roofline"]["frac_of_peak_at_that_clock"] = round(achieved / (PEAK_FP32_TFLOPS * sq["clock_ghz_under_load"] / 2.4), 4)
+        if launch_clock_ghz:
+            # the peak assumes 2.4 GHz.  The clock these launches really ran their steps at (rq_device_last_rollout_clock:
+            # shader-clock cycles over constant-rate ticks, median wave, mean over the probed launches): a launch that
+            # follows an idle gap - every timed region does - runs its first ~30 us at ~2.0 GHz and reaches ~2.38 GHz
+            # after ~60 us, so a 20-step launch averages ~2.2 GHz where back-to-back 500-step launches hold ~2.36
+            # (tools/wave_timeline.py).  That share of the shortfall is the power management's, not the kernel's.
+            # (Round 3 / early round 4 printed the clock of the PROFILED launch here, GRBM_GUI_ACTIVE / duration = 2.12-2.16:
+            # counter collection itself slows the chip; it is kept as sq_counters.clock_ghz_under_profiler.)
+            result["roofline"]["clock_ghz_under_load"] = round(launch_clock_ghz, 3)
+            result["roofline"]["frac_of_peak_at_that_clock"] = round(achieved / (PEAK_FP32_TFLOPS * launch_clock_ghz / 2.4), 4)
     else:
         # round 3: two launches per step - k_step also writes the next step's observation (104 B/env) from the state it
         # holds in registers, so the chain no longer re-reads the state for a k_observe launch

@@ -199,6 +199,13 @@ RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
  * [4 w + 2] = its first step was about to start, [4 w + 3] = its last step was done; 100 MHz, comparable within one die
  * only.  `records` = NULL: *n_waves only; otherwise it holds 4 * capacity values. */
 RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint32_t capacity, uint32_t* n_waves);
+/* The core clock (GHz) the most recent timed fused rollout ran its steps at: per wave, shader-clock cycles between its
+ * first step's start and its last step's end over the same span in constant-rate ticks; the median wave.  The clock
+ * follows the chip's load averaged over about a millisecond (tools/idle_clock.py, MI355X): 2.37-2.38 GHz under launches
+ * back to back or up to ~200 us apart, 2.07 GHz for a launch behind 5 ms of idling - and more than a millisecond of load
+ * to come back, so a lone 20-step launch behind a long pause takes 71 us where the same launch in a busy loop takes 62.
+ * (The three readers below share one copy of the records per launch.) */
+RQ_API int rq_device_last_rollout_clock(rq_device* dev, float* core_ghz);
 /* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
  * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves
  * its own data (bench.py reports it beside the API-granular kernels' HBM fractions). */

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "rq_device_set_rollout_timing": [_vp, C.c_int],
     "rq_device_last_rollout_ms": [_vp, _fp],
     "rq_device_last_rollout_waves": [_vp, C.c_void_p, C.c_uint32, _u32p],
+    "rq_device_last_rollout_clock": [_vp, _fp],
     "rq_device_set_speculation": [_vp, C.c_int],
     "rq_device_get_speculation": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p],
     "rq_device_stream": [_vp, C.POINTER(_vp)],

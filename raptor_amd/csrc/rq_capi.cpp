@@ -68,8 +68,11 @@ struct rq_device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    unsigned long long* k_span = nullptr;        // device [k_span_waves][4]: per wave, in / out / loop begin / loop end ticks of the last timed fused rollout
+    unsigned long long* k_span = nullptr;        // device [k_span_waves][4]: per wave, in / out / loop begin / loop end ticks of the last timed fused rollout;
+                                                 // behind the [k_span_used][4] in use: [k_span_used] core-clock cycles of the waves' steps
     uint32_t k_span_waves = 0, k_span_used = 0;
+    std::vector<unsigned long long> k_host;      // the records of the last timed rollout on the host (fetched once per launch)
+    bool k_fetched = false;
     double k_ticks_per_ms = 1e5;                 // wall clock rate (100 MHz on gfx950)
     bool k_timing = false;         // rq_device_set_rollout_timing
     bool k_timed = false;          // a launch carried the two events
@@ -665,15 +668,27 @@ RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable) {
     return RQ_OK;
 }
 
-RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
-    RQ_REQUIRE(dev && kernel_ms, RQ_ERR_INVALID_ARGUMENT, "null argument");
+namespace {
+// the records of the most recent timed fused rollout, waited for and copied once (ms, clock and the records themselves
+// are usually asked for one after the other: a copy + synchronize each kept the chip idle between the launches being timed)
+int fetch_rollout_records(rq_device* dev) {
     RQ_REQUIRE(dev->k_timed, RQ_ERR_NOT_INITIALIZED,
                "no fused rollout was launched on this device with rq_device_set_rollout_timing enabled");
+    if (dev->k_fetched) return RQ_OK;
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
-    std::vector<unsigned long long> span;
-    try { span.resize((size_t)dev->k_span_used * 4); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
-    RQ_HIP(hipMemcpyAsync(span.data(), dev->k_span, span.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, dev->stream));
+    try { dev->k_host.resize((size_t)dev->k_span_used * 5); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    RQ_HIP(hipMemcpyAsync(dev->k_host.data(), dev->k_span, dev->k_host.size() * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, dev->stream));
     RQ_HIP(hipStreamSynchronize(dev->stream));
+    dev->k_fetched = true;
+    return RQ_OK;
+}
+}  // namespace
+
+RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms) {
+    RQ_REQUIRE(dev && kernel_ms, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = fetch_rollout_records(dev); if (rc) return rc;
+    const std::vector<unsigned long long>& span = dev->k_host;
     unsigned long long first[8], last[8], longest = 0;
     for (int x = 0; x < 8; ++x) { first[x] = ~0ull; last[x] = 0; }
     for (uint32_t w = 0; w < dev->k_span_used; ++w) {
@@ -695,10 +710,26 @@ RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint3
     *n_waves = dev->k_span_used;
     if (records == nullptr) return RQ_OK;                 // size query
     RQ_REQUIRE(capacity >= dev->k_span_used, RQ_ERR_SHAPE_MISMATCH, "records holds fewer than *n_waves entries");
-    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    int rc = fetch_rollout_records(dev); if (rc) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "tick records are 64-bit");
-    RQ_HIP(hipMemcpyAsync(records, dev->k_span, (size_t)dev->k_span_used * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, dev->stream));
-    RQ_HIP(hipStreamSynchronize(dev->stream));
+    std::memcpy(records, dev->k_host.data(), (size_t)dev->k_span_used * 4 * sizeof(uint64_t));
+    return RQ_OK;
+}
+
+RQ_API int rq_device_last_rollout_clock(rq_device* dev, float* core_ghz) {
+    RQ_REQUIRE(dev && core_ghz, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = fetch_rollout_records(dev); if (rc) return rc;
+    const std::vector<unsigned long long>& span = dev->k_host;
+    const size_t waves = dev->k_span_used;
+    std::vector<double> ghz;
+    try { ghz.reserve(waves); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    for (size_t w = 0; w < waves; ++w) {
+        const unsigned long long t0 = span[4 * w + 2], t1 = span[4 * w + 3], cycles = span[4 * waves + w];
+        if (t1 > t0) ghz.push_back((double)cycles / ((double)(t1 - t0) / dev->k_ticks_per_ms * 1e6));   // cycles per ns
+    }
+    RQ_REQUIRE(!ghz.empty(), RQ_ERR_NOT_INITIALIZED, "the timed rollout took no step");
+    std::nth_element(ghz.begin(), ghz.begin() + ghz.size() / 2, ghz.end());
+    *core_ghz = (float)ghz[ghz.size() / 2];
     return RQ_OK;
 }
 
@@ -1520,7 +1551,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
             if (dev->k_span_waves < waves) {
                 RQ_HIP(hipStreamSynchronize(dev->stream));
                 if (dev->k_span) { RQ_HIP(hipFree(dev->k_span)); dev->k_span = nullptr; dev->k_span_waves = 0; }
-                RQ_HIP(hipMalloc(&dev->k_span, (size_t)waves * 4 * sizeof(unsigned long long)));
+                RQ_HIP(hipMalloc(&dev->k_span, (size_t)waves * 5 * sizeof(unsigned long long)));
                 dev->k_span_waves = waves;
             }
             dev->k_span_used = waves;
@@ -1530,6 +1561,7 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                                         policy->precision, sas_of(policy, rng->epoch, nullptr, env->offset), tp,
                                         dev->k_timing ? dev->k_span : nullptr));
         dev->k_timed = dev->k_timing && n_steps > 0;
+        dev->k_fetched = false;
     } else {
         // one step = observe -> evaluate_step -> step (-> record) on the stream.  Without a recording the step kernel
         // also assembles the NEXT step's observation (round 3: two launches per step instead of three; the first

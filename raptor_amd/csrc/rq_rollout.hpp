@@ -321,11 +321,12 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         }
     }
     };
-    unsigned long long t_loop = 0, t_done = 0;
-    if (span != nullptr) t_loop = (unsigned long long)wall_clock64();
+    // (the core-clock counter beside the constant-rate one: cycles over ticks is the clock the wave's steps really ran at)
+    unsigned long long t_loop = 0, t_done = 0, c_loop = 0, c_done = 0;
+    if (span != nullptr) { t_loop = (unsigned long long)wall_clock64(); c_loop = (unsigned long long)__builtin_readcyclecounter(); }
     if (sym_tau) rollout_loop(std::true_type{});
     else         rollout_loop(std::false_type{});
-    if (span != nullptr) t_done = (unsigned long long)wall_clock64();
+    if (span != nullptr) { c_done = (unsigned long long)__builtin_readcyclecounter(); t_done = (unsigned long long)wall_clock64(); }
 
     const bool commit = AUTORESET || !was_frozen;     // under auto-reset a frozen env was thawed above
     // an env whose episode ended BEFORE the launch's last step sat out the rest of it: its last transition of this rollout is
@@ -367,12 +368,14 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             rec[1] = ((unsigned long long)wall_clock64() & 0x0FFFFFFFFFFFFFFFull) | (xcd << 60);
             rec[2] = t_loop;          // prologue issued (its loads may still be in flight), first step about to start
             rec[3] = t_done;          // last step done, the epilogue's stores not yet issued
+            span[4 * (size_t)gridDim.x + blockIdx.x] = c_done - c_loop;      // core-clock cycles between rec[2] and rec[3]
         }
     }
 }
 
 // ------------------------------------------------------------------ launch -------------
 // span != nullptr: every wave leaves (in, out | xcd << 60, loop begin, loop end) wall-clock ticks at span[4 * workgroup]
+// and, behind all of those, the core-clock cycles its steps took at span[4 * workgroups + workgroup]
 // (rq_device_last_rollout_ms).  Round 2 took the kernel's begin / end from hipExtLaunchKernel events; calibrated under
 // rocprofv3 in one process, an event-carrying launch itself runs ~4 us longer than a plain one and the events read
 // ~4 us more on top.

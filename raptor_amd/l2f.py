@@ -91,6 +91,13 @@ class Device:
         return (rec[:, 0] & mask, rec[:, 1] & mask, (rec[:, 1] >> np.uint64(60)).astype(np.int64) & 7,
                 rec[:, 2] & mask, rec[:, 3] & mask)
 
+    def last_rollout_clock_ghz(self):
+        """Core clock (GHz) the most recent timed fused rollout ran its steps at (median wave: shader-clock cycles over
+        constant-rate ticks between its first step's start and its last step's end)."""
+        ghz = C.c_float()
+        _lib.call("rq_device_last_rollout_clock", self._h, C.byref(ghz))
+        return float(ghz.value)
+
     def launch_floor(self, n, reps=200):
         """Average us per launch of back-to-back near-empty kernels on an n-thread grid (diagnostic)."""
         us = C.c_float()

@@ -127,6 +127,9 @@ class StubEngine:
     def last_rollout_ms(self):
         return 1e-3 * 20       # a stand-in kernel time
 
+    def last_rollout_clock_ghz(self):
+        return 2.2             # a stand-in core clock
+
     def timer_start(self):
         self.t0 = time.perf_counter()
 

@@ -1141,8 +1141,8 @@ def test_fused_equals_chained_over_random_settings(device, oracle, case):
 
 
 def test_kernel_level_timing_records_and_leaves_results_alone(device, oracle):
-    """rq_device_set_rollout_timing / rq_device_last_rollout_ms / rq_device_last_rollout_waves: every wave of a timed fused
-    rollout leaves four ticks in order (in <= first step <= last step done <= out) and the die it ran on; the duration is
+    """rq_device_set_rollout_timing / rq_device_last_rollout_ms / rq_device_last_rollout_waves / rq_device_last_rollout_clock:
+    every wave of a timed fused rollout leaves four ticks in order (in <= first step <= last step done <= out) and the die it ran on; the duration is
     plausible; the rollout's results are those of an untimed one."""
     n = 70001                                        # the two-waves-per-SIMD build; 1 094 waves
     a, b = World(device, oracle, n, seed=3), World(device, oracle, n, seed=3)
@@ -1151,8 +1151,10 @@ def test_kernel_level_timing_records_and_leaves_results_alone(device, oracle):
         a.vector.rollout(device, a.env, a.params, a.state, a.policy, a.rng, 20, "fused", True)
         ms = device.last_rollout_ms()
         t_in, t_out, xcd, t_first, t_last = device.last_rollout_waves()
+        ghz = device.last_rollout_clock_ghz()
     finally:
         device.set_rollout_timing(False)
+    assert 1.2 < ghz < 2.6, ghz                     # the core clock the waves' steps ran at (the peak assumes 2.4 GHz)
     b.vector.rollout(device, b.env, b.params, b.state, b.policy, b.rng, 20, "fused", True)
     assert np.array_equal(a.state.numpy(), b.state.numpy())
     assert len(t_in) == (n + 63) // 64
