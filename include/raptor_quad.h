@@ -68,7 +68,7 @@ extern "C" {
 
 #define RQ_ABI_VERSION 3   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
                               rounds 2 and 3 (the latter: rq_device_last_rollout_waves)
-                              3 (round 4): rq_device_{set,get}_speculation; no struct changed */
+                              3 (round 4): rq_device_{set,get}_speculation, rq_device_last_rollout_clock; no struct changed */
 
 #if defined(__GNUC__)
 #define RQ_API __attribute__((visibility("default")))
