@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64) void k_mfma_mix(int iters, const float* __restr
 }
 
 static float* d_in; static float* d_out; static unsigned long long* d_cyc;
+static int g_wgs = 1024;      // workgroups of one wave: 1 024 = one wave per SIMD, 2 048 = two, 4 096 = four (argv[1])
 
 template <typename F>
 static void time_kernel(const char* name, int per_iter, int iters, F launch) {
@@ -98,23 +99,28 @@ static void time_kernel(const char* name, int per_iter, int iters, F launch) {
     launch(10); CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0)); launch(iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> cyc(1024);
-    CK(hipMemcpy(cyc.data(), d_cyc, 1024 * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> cyc(g_wgs);
+    CK(hipMemcpy(cyc.data(), d_cyc, (size_t)g_wgs * 8, hipMemcpyDeviceToHost));
     std::sort(cyc.begin(), cyc.end());
     const double n = (double)per_iter * iters;
-    printf("%-46s %7.2f counter ticks / instr (median wave)   %7.3f ns / instr (events, whole launch)\n", name, cyc[512] / n, ms * 1e6 / n);
+    const int per_simd = g_wgs / 1024;
+    printf("%-46s %7.2f counter ticks / instr (median wave)   %7.3f ns / instr (events, whole launch)", name, cyc[g_wgs / 2] / n, ms * 1e6 / n);
+    if (per_simd > 1) printf("   %6.2f ticks / instr and SIMD (%d waves share it)", cyc[g_wgs / 2] / n / per_simd, per_simd);
+    printf("\n");
 }
 
 #define PROBE(KIND, name)                                                                                                          \
-    time_kernel(name " 1 chain (latency)", 64, 2000, [&](int it) { k_probe<KIND, 1><<<1024, 64>>>(it, d_in, d_out, d_cyc); });     \
-    time_kernel(name " 8 chains (issue)", 64, 2000, [&](int it) { k_probe<KIND, 8><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel(name " 1 chain (latency)", 64, 2000, [&](int it) { k_probe<KIND, 1><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });     \
+    time_kernel(name " 8 chains (issue)", 64, 2000, [&](int it) { k_probe<KIND, 8><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
 
-int main() {
-    CK(hipMalloc(&d_in, 64 * 4)); CK(hipMalloc(&d_out, 1024 * 64 * 4)); CK(hipMalloc(&d_cyc, 1024 * 8));
+int main(int argc, char** argv) {
+    if (argc > 1) g_wgs = atoi(argv[1]);
+    if (g_wgs < 1024 || g_wgs % 1024) { printf("workgroups must be a multiple of 1024\n"); return 1; }
+    CK(hipMalloc(&d_in, 64 * 4)); CK(hipMalloc(&d_out, (size_t)g_wgs * 64 * 4)); CK(hipMalloc(&d_cyc, (size_t)g_wgs * 8));
     std::vector<float> h(64);
     for (int i = 0; i < 64; ++i) h[i] = 0.001f * i;
     CK(hipMemcpy(d_in, h.data(), 64 * 4, hipMemcpyHostToDevice));
-    printf("one wave per SIMD (1024 workgroups x 64 lanes); blocks of 64 instructions\n");
+    printf("%d wave(s) per SIMD (%d workgroups x 64 lanes); blocks of 64 instructions\n", g_wgs / 1024, g_wgs);
     PROBE(13, "s_nop 0")
     PROBE(0, "v_fma_f32")
     PROBE(12, "v_fmac_f32")
@@ -124,17 +130,17 @@ int main() {
     PROBE(5, "v_pk_mul_f32")
     PROBE(2, "v_exp_f32")
     PROBE(3, "v_rcp_f32")
-    time_kernel("exp,add,rcp x 1 chain (per instruction)", 64 * 3, 1000, [&](int it) { k_probe<11, 1><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
-    time_kernel("exp,add,rcp x 8 chains (per instruction)", 64 * 3, 1000, [&](int it) { k_probe<11, 8><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("exp,add,rcp x 1 chain (per instruction)", 64 * 3, 1000, [&](int it) { k_probe<11, 1><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("exp,add,rcp x 8 chains (per instruction)", 64 * 3, 1000, [&](int it) { k_probe<11, 8><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
     PROBE(6, "v_permlane32_swap")
     PROBE(7, "v_permlane16_swap")
     PROBE(8, "v_cvt_pk_bf16_f32")
     PROBE(9, "v_med3_f32")
     PROBE(10, "v_maximum3_f32")
-    time_kernel("bf16 MFMA 16x16x32 alone (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<0><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
-    time_kernel("bf16 MFMA + 2 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<2><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
-    time_kernel("bf16 MFMA + 4 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<4><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
-    time_kernel("bf16 MFMA + 8 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<8><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
-    time_kernel("bf16 MFMA + 16 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<16><<<1024, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("bf16 MFMA 16x16x32 alone (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<0><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("bf16 MFMA + 2 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<2><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("bf16 MFMA + 4 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<4><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("bf16 MFMA + 8 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<8><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
+    time_kernel("bf16 MFMA + 16 v_fma (per MFMA)", 16, 4000, [&](int it) { k_mfma_mix<16><<<g_wgs, 64>>>(it, d_in, d_out, d_cyc); });
     return 0;
 }
