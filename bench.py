@@ -182,6 +182,29 @@ def pmc_traffic(kernel, n):
     return None
 
 
+def rocprof_launch_stats(kernel, n, steps):
+    """What rocprofv3 printed for the launches of `kernel` in the timed regions of this same command (newest committed
+    profiles/rNN_fused_launch_stats.json, written by tools/summarize_profiles.py from the kernel trace: End - Start per
+    dispatch).  The profiler's duration begins when the command processor takes the dispatch and ends when the kernel's
+    writes are released; the waves' own clocks (`avg_launch_ms`) begin with their first instruction and end with their
+    last - ~2.6 us less for a 20-step launch.  None when no profile covers this kernel / step count."""
+    import glob
+    import re
+    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_fused_launch_stats.json"))
+             if re.fullmatch(r"r\d+_fused_launch_stats\.json", os.path.basename(p))]
+    for path in sorted(paths, reverse=True):
+        try:
+            d = json.load(open(path))
+            if int(d.get("steps", -1)) != int(steps) or int(d.get("envs_per_gpu") or -1) != int(n):
+                continue
+            row = d[kernel.replace(" ", "")]["timed_region_launches"]
+            return {"launches": row["launches"], "mean_us": row["mean_us"], "median_us": row["median_us"],
+                    "source": os.path.basename(path), "command": d.get("command")}
+        except Exception:
+            continue
+    return None
+
+
 def fused_kernel_name(precision, n, steps_per_launch):
     """The instantiation launch_rollout_fused picks (raptor_amd/csrc/rq_kernels.hip), as rocprofv3 prints it."""
     if precision == "f16x2":
@@ -912,9 +935,10 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         timed ones (barrier + synchronize on both sides) are run again with kernel-level timing on
         (rq_device_set_rollout_timing: every wave records the wall-clock tick at which it came in and went out and the
         core-clock cycles of its steps; the duration is first-wave-in to last-wave-out on one die), and the records of every
-        `stride`-th region's launch are read back.  Calibrated under rocprofv3 in one process: 74.7 us
-        where the profiler prints 73.8 us per dispatch for plain launches of the same kind, 1 532 vs 1 539 us for 500-step
-        launches.  Why only every stride-th: the chip's core clock follows its load averaged over about a millisecond
+        `stride`-th region's launch are read back.  Against rocprofv3's per-dispatch duration of the same launches the span
+        reads ~2.6 us short (63.3 against 65.9 us in the profiled run of the driver's command: the profiler's clock runs from
+        the command processor taking the dispatch to the release of the kernel's writes; `roofline.rocprofv3` carries its
+        figure).  Why only every stride-th: the chip's core clock follows its load averaged over about a millisecond
         (tools/idle_clock.py: 2.37 GHz with the ~15 us between two timed regions, 2.07 GHz behind 5 ms of idling, and many
         launches to come back), and a read-back after EVERY launch - a copy, a synchronize, host arithmetic: ~50-100 us of
         idle chip - lowered the clock of the launches it was timing (2.25 GHz, 65.4 us for the 20-step launch that takes
@@ -1103,9 +1127,10 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
                     f"{BYTES_FUSED_LAUNCH} B/env per launch of {int(steps_per_launch)} steps; the measured `traffic` adds "
                     "the operand image every wave loads and the loop-invariant registers parked in scratch before "
                     "the loop - a few bytes per env-step, HBM idle; avg_launch_ms = the kernel's own first-wave-in / "
-                    "last-wave-out span on the wall clock (rq_device_set_rollout_timing; within ~1 % of the per-dispatch "
-                    "duration rocprofv3 prints for the timed regions' launches, profiles/r03_summary.md), mean over "
-                    "further regions of the same kind covering whole episode periods; short launches carry the "
+                    "last-wave-out span on the wall clock (rq_device_set_rollout_timing), mean over launches inside further "
+                    "regions of the timed regions' own cadence, sampled through the episode's phases; the per-dispatch "
+                    "duration rocprofv3 prints for the same launches - command processor to released writes - reads "
+                    "~2.6 us more: `rocprofv3` below carries it and the fraction it gives; short launches carry the "
                     "kernel's prologue and epilogue (see steady_state for 500-step launches); the north-star's "
                     "'>= 60 % of the HBM roofline on the step kernel' is kernels.n2097152.k_step (HBM-bound there; at "
                     "65 536 envs the API-granular kernels are launch-latency-bound on Infinity-Cache-resident data)",
@@ -1113,6 +1138,15 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             "steps_per_launch": steps_per_launch,
             "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
             "sq_counters": sq_profile("fp32")}
+        rp = rocprof_launch_stats(fused_kernel_name(args.precision, n, steps_per_launch), n, args.steps) if launches == 1 else None
+        if rp:
+            # the committed rocprofv3 trace of this same command, and the fraction ITS per-dispatch duration gives: the
+            # profiler's clock starts when the command processor takes the dispatch and stops when the kernel's writes are
+            # released - ~2.6 us more per 20-step launch than the waves' own first-in / last-out span above (and its
+            # launches ran under the profiler, whose per-dispatch overhead stretches the regions and lowers the clock)
+            rp_flops = flop_step * n * steps_per_launch / (rp["mean_us"] * 1e-6) / 1e12
+            result["roofline"]["rocprofv3"] = {**rp, "achieved_TFLOPs_at_mean": round(rp_flops, 2),
+                                               "frac_at_mean": round(rp_flops / PEAK_FP32_TFLOPS, 4)}
         if launch_clock_ghz:
             # the peak assumes 2.4 GHz.  The clock these launches really ran their steps at (rq_device_last_rollout_clock:
             # shader-clock cycles over constant-rate ticks, median wave, mean over the probed launches): a launch that

@@ -189,9 +189,10 @@ RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
 /* Kernel-level timing of fused rollouts, off by default: while enabled every wave of a fused rollout kernel records the
  * wall-clock tick (constant 100 MHz) at which it came in and went out, and rq_device_last_rollout_ms returns, after waiting
  * for the most recent one, first-wave-in to last-wave-out on one die (the eight dies' counters are offset against one
- * another; the longest die counts).  Calibrated under rocprofv3 in one process: within ~1 % of the per-dispatch duration
- * the profiler prints for launches of 20 steps and more (it excludes the ~3 us of wave-launch ramp and completion signal
- * that dominate a 1-step launch).  Round 2 used hipExtLaunchKernel's begin / end events: they read ~8 us long. */
+ * another; the longest die counts).  Against rocprofv3's per-dispatch duration of the same launches (command processor
+ * takes the dispatch -> the kernel's writes are released) the waves' own span reads ~2.6 us short: 63.3 against 65.9 us
+ * for a 20-step launch of 65 536 envs, the same few us of a 1-step launch's 12 (profiles/r04_summary.md).  Round 2 used
+ * hipExtLaunchKernel's begin / end events: they read ~8 us long and the launches carrying them ran ~4 us longer. */
 RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
 RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
 /* The records themselves (a diagnostic: tools/wave_timeline.py): per wave w of the most recent timed fused rollout four

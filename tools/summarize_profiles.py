@@ -111,6 +111,7 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
                 per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         f.write("\n## `k_rollout_fused`, per instantiation (us per launch, from the kernel trace)\n\n"
                 "| instantiation | launches | mean | median | min | max |\n|---|---|---|---|---|---|\n")
+        launch_stats = {"command": cmd, "steps": b["steps"], "envs_per_gpu": b.get("config", {}).get("envs_per_gpu"), "source": "rocprofv3 --kernel-trace, End - Start per dispatch (us)"}
         for name, d in sorted(per.items()):
             ds = sorted(d)
             f.write(f"| `{name}` | {len(d)} | {sum(d) / len(d):.2f} | {ds[len(ds) // 2]:.2f} | {ds[0]:.2f} | {ds[-1]:.2f} |\n")
@@ -120,6 +121,11 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
             short = [x for x in ds if 0.5 * med <= x <= 2.0 * med]
             long_ = [x for x in ds if x > 5.0 * med]
             if long_ and len(short) > 10:
+                launch_stats[name.replace(" ", "")] = {
+                    "timed_region_launches": {"launches": len(short), "mean_us": round(sum(short) / len(short), 2),
+                                              "median_us": round(short[len(short) // 2], 2)},
+                    "launches_of_500_steps": {"launches": len(long_), "mean_us": round(sum(long_) / len(long_), 2),
+                                              "median_us": round(long_[len(long_) // 2], 2)}}
                 f.write(f"| &nbsp;&nbsp;of which the timed regions' launches ({b['steps']} steps) | {len(short)} | "
                         f"{sum(short) / len(short):.2f} | {short[len(short) // 2]:.2f} | {short[0]:.2f} | {short[-1]:.2f} |\n")
                 f.write(f"| &nbsp;&nbsp;of which 500-step launches (steady_state, probes) | {len(long_)} | "
@@ -129,8 +135,14 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
                 f"`roofline.kernel` = `{rl.get('kernel')}`, `roofline.avg_launch_ms` = {rl.get('avg_launch_ms')}; "
                 f"`steady_state.kernel` = `{ss.get('kernel')}`, `steady_state.avg_launch_ms` = {ss.get('avg_launch_ms')}.  "
                 "bench.py takes these from the kernels' own first-wave-in / last-wave-out spans (per-wave wall-clock records, "
-                "rq_device_set_rollout_timing): in an un-profiled run they agree with the per-dispatch durations above to ~1 % "
-                "(profiles/r03_kernel_timing_calibration.md; the same command un-profiled: DESIGN.md section 6).\n")
+                "rq_device_set_rollout_timing) of launches inside regions of the timed regions' own cadence.  The profiler's "
+                "per-dispatch duration of the SAME launches reads ~2.6 us more (a 20-step launch; ~10 us of a 500-step one's 1 420): "
+                "it begins when the command processor takes the dispatch and ends when the kernel's writes have been released, "
+                "the waves' own clocks begin with their first instruction and end with their last.  `roofline.rocprofv3` in "
+                "bench.py's line carries the figures of this table (from " + f"{tag}_fused_launch_stats.json" + ") and the fraction "
+                "they give; the clock of these profiled launches is `roofline.clock_ghz_under_load` of the profiled run's line "
+                f"({rl.get('clock_ghz_under_load')} GHz; the same command un-profiled: DESIGN.md section 6).\n")
+        json.dump(launch_stats, open(os.path.join(dst, f"{tag}_fused_launch_stats.json"), "w"), indent=1, sort_keys=True)
     f.write("\n## PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction)\n\n")
     f.write("| kernel#n<envs> | envs | VGPR/AGPR/SGPR | avg us | FETCH KiB | WRITE KiB | HBM bytes/env (corrected) |\n|---|---|---|---|---|---|---|\n")
     for k, d in out.items():
