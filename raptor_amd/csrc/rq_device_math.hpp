@@ -665,7 +665,9 @@ struct ActorF32T {
 
     // every lane loads its slice of the packed image; all 64 lanes must be active.  WAVES = waves per workgroup.
     template <int WAVES>
-    __device__ __forceinline__ void load(const float* __restrict__ packed) {
+    __device__ __forceinline__ void load(const float* __restrict__ packed) { load_impl<WAVES, true>(packed); }
+    template <int WAVES, bool PARK>
+    __device__ __forceinline__ void load_impl(const float* __restrict__ packed) {
         __shared__ __attribute__((aligned(16))) float lds[WAVES * kLdsFloats];
         const int lane = threadIdx.x & 63;
         // per wave: the observation tile (64 x 25 floats), then the reduction tile (64 x 5 quads, 16-byte aligned)
@@ -692,6 +694,13 @@ struct ActorF32T {
             for (int e = 0; e < 4; ++e)
                 if (4 * g + e < QW_REGS) W[4 * g + e] = x[e];
         }
+        if constexpr (PARK) park();
+    }
+    // The same in two halves (the fused kernel's prologue puts work between them that must not wait for the image):
+    // load_issue asks for the image, park takes it into the registers it lives in.
+    template <int WAVES>
+    __device__ __forceinline__ void load_issue(const float* __restrict__ packed) { load_impl<WAVES, false>(packed); }
+    __device__ __forceinline__ void park() {
         // The 30 images that are only ever an MFMA's A operand (layer_0, W_input, W_hidden) live in ACCUMULATION
         // registers: the matrix instructions read A / B from either file, the VALU only from the architected 256,
         // and with one wave per SIMD the other 256 sit idle - parked there, the operands leave the VALU's file to
@@ -1017,6 +1026,9 @@ struct ActorBF16 {
 #pragma unroll
         for (int v = 0; v < BW_REGS - BW_BR; ++v) B[v] = packed[(BW_BR + v) * 64 + lane];
     }
+    template <int WAVES>
+    __device__ __forceinline__ void load_issue(const float* __restrict__ packed) { load<WAVES>(packed); }
+    __device__ __forceinline__ void park() {}
     __device__ __forceinline__ float h0(int r) const { return B[BW_H0 - BW_BR + r]; }
     __device__ __forceinline__ bf16x8 a_op(int base) const {
         const dwordx4 u = {A[base], A[base + 1], A[base + 2], A[base + 3]};
@@ -1181,6 +1193,9 @@ struct ActorF16X2 {
 #pragma unroll
         for (int v = 0; v < FW_REGS - FW_BR; ++v) B[v] = packed[(FW_BR + v) * 64 + lane];
     }
+    template <int WAVES>
+    __device__ __forceinline__ void load_issue(const float* __restrict__ packed) { load<WAVES>(packed); }
+    __device__ __forceinline__ void park() {}
     __device__ __forceinline__ float h0(int r) const { return B[FW_H0 - FW_BR + r]; }
     __device__ __forceinline__ f16x8 a_op(int base) const {
         const dwordx4 u = {A[base], A[base + 1], A[base + 2], A[base + 3]};

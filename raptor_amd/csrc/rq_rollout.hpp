@@ -65,6 +65,10 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     const bool valid = i0 < b.n;
     const size_t ld = b.ld;
     const uint64_t genv = b.env_offset + i;
+    // what the ahead-of-time sampler needs is asked for first: it runs while the rest of the prologue's loads are in flight
+    uint32_t ep = AUTORESET ? st.episode[i] : 0u;
+    float hover_rpm = 0.0f;
+    if (AUTORESET) hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
     QuadState y;
     f32x2 LA01, LA23;
@@ -83,11 +87,34 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     const uint8_t last_t_raw = st.last_terminated[i];
     uint8_t last_d = AUTORESET ? (uint8_t)0 : st.last_done[i];       // auto-reset: rebuilt in the epilogue
     const uint8_t frozen_raw = st.frozen[i];
-    uint32_t ep = AUTORESET ? st.episode[i] : 0u;
     // the operand image (L2-resident after a die's first wave) is asked for AFTER the env's own fields: those come from
     // HBM / the memory-side cache and their latency is the long one
     ACTOR actor;
-    actor.template load<kFusedBlock / 64>(packed);
+    actor.template load_issue<kFusedBlock / 64>(packed);
+    // (kAhead, pre, pre_mask: see "sampled AHEAD" below)
+    constexpr bool kAhead = AUTORESET && (WavesPerSimd<ACTOR>::value == 1 || std::is_same<ACTOR, ActorBF16Lean>::value);
+    constexpr int kPre = 19;
+    float pre[kPre];
+    uint64_t pre_mask = 0;                       // wave-uniform
+    if (kAhead) {
+        // Every launch STARTS with valid parked values (round 4, second half): the sampler runs here, inline, for all 64
+        // lanes, while the prologue's ~90 load instructions are in flight - its inputs were asked for first, and it sits
+        // between the request for the operand image and the image's move into its registers (a CALL would wait for every
+        // outstanding load; so would anything placed behind actor.park()).  Before, a launch began with nothing parked and
+        // the wave that met the launch's first episode end sampled there and then: 1.9 us that the other 1 023 waves of a
+        // 65 536-env launch waited for at its end (tools/wave_timeline.py: the slowest wave's steps 2.4 us longer than the
+        // median wave's in a 20-step launch; now 0.9, for 1.2 us more prologue in every wave: 20-step regions 77.24 ->
+        // 76.66 us on one box, three alternations).
+        float s0[17], la0[4], f0[6];
+        sample_state(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[i], hover_rpm, field(params, RQ_P_ROTOR_POS, ld)[i],
+                     field(params, (RQ_P_ROTOR_POS + 1), ld)[i], s0, la0, f0);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[j]) : "v"(s0[j]));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pre[13 + j]) : "v"(f0[j]));
+        pre_mask = ~0ull;
+    }
+    actor.park();
     float h0Q[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -105,26 +132,17 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
     // in ACCUMULATION registers for every lane, and an env whose episode ends takes them with 19 register reads.  The
     // sampler itself (six Philox blocks, sin / cos, Box-Muller: ~1 000 instructions, and at an episode end it used to run
     // for the one or two lanes concerned while the other 62 waited - the slowest wave of a 20-step launch paid it three
-    // times, tools/wave_timeline.py) runs for ALL 64 lanes at once, and only when an ending env finds its values used
-    // up: `pre_mask` has a bit per lane whose parked values are for its current episode counter.  Lanes that still hold
-    // valid ones get the same values again (same counter, same function), so the refill is unconditional.
+    // times, tools/wave_timeline.py) runs for ALL 64 lanes at once: in the prologue of every launch (above, under the
+    // prologue's loads) and again only when an ending env finds its values used up - its second end since the last
+    // sampling: `pre_mask` has a bit per lane whose parked values are for its current episode counter.  Lanes that still
+    // hold valid ones get the same values again (same counter, same function), so the refill is unconditional.
     // Only the builds with one wave per SIMD do this: the two-waves-per-SIMD builds have 256 registers per wave in all,
     // every one of them an architected register; asking for accumulation registers splits that budget 128 + 128 and the
     // hot loop spills (262 144 envs: 0.70 -> 0.55 of the peak).  There the second wave fills the time one spends sampling.
     // (The two-wave bf16 build has the room: 6.45 -> 5.7 us per step of 262 144 envs with it.)
-    constexpr bool kAhead = AUTORESET && (WavesPerSimd<ACTOR>::value == 1 || std::is_same<ACTOR, ActorBF16Lean>::value);
     // the env index as the rare paths see it: opaque, so that the addresses they form are computed there and then instead of
     // being kept through the loop (see the epilogue)
     auto rare_index = [&]() { uint32_t r = i; asm volatile("" : "+v"(r)); return r; };
-    constexpr int kPre = 19;
-    float pre[kPre];
-    uint64_t pre_mask = 0;                       // wave-uniform
-    float hover_rpm = 0.0f;
-    if (AUTORESET) hover_rpm = field(params, RQ_P_HOVER_RPM, ld)[i];
-    if (kAhead) {
-#pragma unroll
-        for (int j = 0; j < kPre; ++j) asm volatile("" : "=a"(pre[j]));    // named, not written: pre_mask = 0 says none is valid
-    }
     auto refill = [&]() {                        // every lane: sample_initial_state for its episode counter ep
         const uint32_t ir = rare_index();
         const PreSample fresh = sample_state_ahead(sc, seed, ep, genv, field(params, RQ_P_MASS, ld)[ir], hover_rpm,
@@ -161,8 +179,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
         // episode here, as every episode end under auto-reset does: re-sampled, policy state reset.  The
         // chained mode does the same before its first step (k_thaw_frozen).
         const uint64_t thaw = __builtin_amdgcn_ballot_w64(was_frozen);
-        if (thaw != 0) {
-            if constexpr (kAhead) refill();
+        if (thaw != 0) {                             // (kAhead: the prologue parked the values they take)
             if (was_frozen) take_presampled();
             pre_mask &= ~thaw;
             select_hidden_q(thaw, h0Q, hQ);
