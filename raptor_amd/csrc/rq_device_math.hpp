@@ -1012,6 +1012,19 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float f0, float f1, float f2, floa
     return v;
 }
 
+// Lane group q = lane >> 4 takes v_q.  Where an output layer runs as one MFMA per 16-env tile with tile t's weight rows in
+// A rows 4t .. 4t+3, tile t's outputs come out at lane group t - the native layout - but every OTHER row of that MFMA's
+// result is 0 x (tile t's operand): zero for finite operands, NaN as soon as an env of tile t holds an infinity or a NaN.
+// Rounds 2-4 accumulated the four tiles into one result, which is the native layout for free and lets one env's
+// non-finite hidden state turn the actions of the three envs at the same position of the other tiles into NaN (found in
+// round 4: an infinite observation in row 5 of a bf16 batch changed rows 21, 37 and 53).  Each tile keeps its own
+// accumulator now and every lane group reads only its own: three selects per output on two loop-invariant masks.
+__device__ __forceinline__ float pick_lane_group(float v0, float v1, float v2, float v3) {
+    const uint32_t q = (threadIdx.x >> 4) & 3u;
+    const float lo = (q & 1u) ? v1 : v0, hi = (q & 1u) ? v3 : v2;
+    return (q & 2u) ? hi : lo;
+}
+
 struct ActorBF16 {
     static constexpr int kPackedRegs = BW_REGS;
     uint32_t A[BW_BR];
@@ -1148,17 +1161,16 @@ struct ActorBF16 {
 #pragma unroll
         for (int t = 0; t < 4; ++t) gru_gates_prescaled(gr[t], gz[t], gni[t], gnh[t], hQ[t]);
         const f32x4 cb2 = {B[BW_B2 - BW_BR], B[BW_B2 - BW_BR + 1], B[BW_B2 - BW_BR + 2], B[BW_B2 - BW_BR + 3]};
-        f32x4 d0 = cb2, d1 = zero;
+        f32x4 d[4];               // one accumulator per tile: see pick_lane_group
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             hp[t][0] = pk(hQ[t][0], hQ[t][1]); hp[t][1] = pk(hQ[t][2], hQ[t][3]);
             const dwordx4 u = {yp[t][0], yp[t][1], hp[t][0], hp[t][1]};
             const bf16x8 hb = __builtin_bit_cast(bf16x8, u);
-            if (t & 1) d1 = mfma(a_op(BW_L2 + 4 * t), hb, d1);
-            else       d0 = mfma(a_op(BW_L2 + 4 * t), hb, d0);
+            d[t] = mfma(a_op(BW_L2 + 4 * t), hb, cb2);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
+        for (int r = 0; r < 4; ++r) a[r] = pick_lane_group(d[0][r], d[1][r], d[2][r], d[3][r]);
     }
 };
 
@@ -1321,7 +1333,8 @@ struct ActorF16X2 {
             }
         }
         // layer_2: the gate operand's tuple with the new hidden state in k-slots 4..7 (A is zero in slots 0..3)
-        f32x4 dh0 = bias(FW_B2), dh1 = zero;
+        const f32x4 cb2 = bias(FW_B2);
+        f32x4 d[4];               // one accumulator per tile: see pick_lane_group
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             uint32_t nh0, nl0, nh1, nl1;
@@ -1329,19 +1342,12 @@ struct ActorF16X2 {
             split2(hQ[t][2], hQ[t][3], nh1, nl1);
             const f16x8 xh = tuple(yh[t][0], yh[t][1], nh0, nh1);
             const f16x8 xl = tuple(yl[t][0], yl[t][1], nl0, nl1);
-            if (t & 1) {
-                dh1 = mfma(a_op(FW_L2H + 4 * t), xh, dh1);
-                dh1 = mfma(a_op(FW_L2H + 4 * t), xl, dh1);
-                dh1 = mfma(a_op(FW_L2L + 4 * t), xh, dh1);
-            } else {
-                dh0 = mfma(a_op(FW_L2H + 4 * t), xh, dh0);
-                dh0 = mfma(a_op(FW_L2H + 4 * t), xl, dh0);
-                dh0 = mfma(a_op(FW_L2L + 4 * t), xh, dh0);
-            }
+            d[t] = mfma(a_op(FW_L2H + 4 * t), xh, cb2);
+            d[t] = mfma(a_op(FW_L2H + 4 * t), xl, d[t]);
+            d[t] = mfma(a_op(FW_L2L + 4 * t), xh, d[t]);
         }
-        const f32x4 d0 = dh0, d1 = dh1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = d0[r] + d1[r];
+        for (int r = 0; r < 4; ++r) a[r] = pick_lane_group(d[0][r], d[1][r], d[2][r], d[3][r]);
     }
 };
 
@@ -1358,22 +1364,19 @@ __device__ __forceinline__ void squash_action(float (&a)[4]) {
 }
 
 // The log-std rows of the 8-output head on the matrix cores, from the post-update hidden state in the Q layout:
-// image = 16 A operands laid out like layer_2's ([t][s]: lane (q, j) = (j >> 2 == t) ? W_ls[j & 3][4q + s] : 0, the
-// four tiles accumulate into one D = the native layout) followed by 4 bias images.  Read from memory when used
+// image = 16 A operands laid out like layer_2's ([t][s]: lane (q, j) = (j >> 2 == t) ? W_ls[j & 3][4q + s] : 0: tile t's
+// result at lane group t = the native layout) followed by 4 bias images.  Read from memory when used
 // (L2-resident, 5 KB): a stage that is off in the shipped policy must not hold registers in the rollout loop.
 __device__ __forceinline__ void logstd_head(const float* __restrict__ img, const float (&hQ)[4][4], float (&ls)[4]) {
     const int lane = threadIdx.x & 63;
-    f32x4 d0 = {img[16 * 64 + lane], img[17 * 64 + lane], img[18 * 64 + lane], img[19 * 64 + lane]};
-    f32x4 d1 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias = {img[16 * 64 + lane], img[17 * 64 + lane], img[18 * 64 + lane], img[19 * 64 + lane]};
+    f32x4 d[4] = {bias, bias, bias, bias};        // one accumulator per tile: see pick_lane_group
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        d0 = mfma16(img[(0 + s) * 64 + lane], hQ[0][s], d0);
-        d1 = mfma16(img[(4 + s) * 64 + lane], hQ[1][s], d1);
-        d0 = mfma16(img[(8 + s) * 64 + lane], hQ[2][s], d0);
-        d1 = mfma16(img[(12 + s) * 64 + lane], hQ[3][s], d1);
-    }
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ls[r] = d0[r] + d1[r];
+        for (int t = 0; t < 4; ++t) d[t] = mfma16(img[(4 * t + s) * 64 + lane], hQ[t][s], d[t]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ls[r] = pick_lane_group(d[0][r], d[1][r], d[2][r], d[3][r]);
 }
 
 // a = raw output of the mean head (native layout); hQ = hidden state after this step.  Wave-uniform control flow

@@ -1941,6 +1941,43 @@ def test_action_history_raw_on_the_gpu(device, oracle):
     assert np.abs(sa[:, 17:21]).max() > 1.0          # the history really holds unclipped commands
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
+def test_rows_of_a_batch_do_not_see_each_others_infinities(device, precision):
+    """"Works on batches by default" (README.md:24) means row by row.  Rounds 2-4 ran the 16-bit actors' output layer as one
+    MFMA per 16-env tile and ACCUMULATED the four tiles of a wave into one result - tile t's weight rows are zero outside
+    rows 4t .. 4t+3, which is exact for finite operands and 0 x inf = NaN otherwise: an infinite observation in row 5 of a
+    bf16 batch turned the actions of rows 21, 37 and 53 into NaN (round 4).  Every tile keeps its own accumulator now.
+    Checked in every precision: a non-finite observation, a huge one, and a non-finite policy state in one row leave every
+    other row's action and policy state bit for bit what they are without it (also with the SampleAndSquash stage on,
+    whose log-std head is laid out the same way)."""
+    from raptor_amd.foundation_policy import Raptor
+    rng = np.random.default_rng(5)
+    for n in (64, 1100):
+        x = rng.standard_normal((n, 22)).astype(np.float32)
+        h = (0.3 * rng.standard_normal((n, 16))).astype(np.float32)
+        others = np.ones(n, bool); others[5] = False
+        for sas in (False, True):
+            pol = Raptor(device, precision=precision)
+            w_ls = (0.1 * rng.standard_normal((4, 16))).astype(np.float32)
+
+            def run(obs, hid):
+                if sas:                                # (again every time: the same sampling steps in every run)
+                    pol.set_sample_and_squash("sample", w_ls, np.full(4, -1.0, np.float32), seed=3)
+                pol.reset()
+                pol.evaluate_step(x)                   # sizes the policy
+                pol.set_hidden_state(hid)
+                a = pol.evaluate_step(obs)
+                return a, pol.hidden_state(n)
+            a0, h0 = run(x, h)
+            for bad in (np.inf, -np.inf, np.nan, 1e30):
+                y = x.copy(); y[5, 3] = bad
+                a1, h1 = run(y, h)
+                assert np.array_equal(a1[others], a0[others]) and np.array_equal(h1[others], h0[others]), (n, sas, bad, "observation")
+                g = h.copy(); g[5, 7] = bad
+                a2, h2 = run(x, g)
+                assert np.array_equal(a2[others], a0[others]) and np.array_equal(h2[others], h0[others]), (n, sas, bad, "policy state")
+
+
 def test_split_f16_actor_saturates_out_of_range_inputs(device, oracle, weights):
     """RQ_POLICY_F16X2_MFMA beyond the f16 range (|x| >= 65 520 converts to infinity, and infinity minus infinity in the
     residual would be NaN in the GRU state for good): observations and layer_0's output are saturated at +-65 504 before
