@@ -1978,6 +1978,32 @@ def test_rows_of_a_batch_do_not_see_each_others_infinities(device, precision):
                 assert np.array_equal(a2[others], a0[others]) and np.array_equal(h2[others], h0[others]), (n, sas, bad, "policy state")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
+@pytest.mark.parametrize("mode", ["fused", "chained"])
+def test_a_diverged_env_stays_alone_in_a_rollout(device, oracle, precision, mode):
+    """The same property through the rollout kernels: with termination off, one env of a batch is handed an infinite (then
+    a NaN) position; every other env's state, policy state and statistics after the rollout are bit for bit those of the
+    batch without it - fused and chained, with and without auto-reset, in every precision, at a batch with a ragged tail
+    and past the size where waves share a SIMD."""
+    for n in (200, 70001):
+        for autoreset in (True, False):
+            for bad in (np.inf, np.nan):
+                out = []
+                for poisoned in (False, True):
+                    w = World(device, oracle, n, seed=77, termination_enabled=0)
+                    w.policy.set_precision(precision)
+                    w.policy.reset()
+                    if poisoned:
+                        S = w.state.numpy()
+                        S[21, 1] = bad
+                        w.state.set(S)
+                    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 7, mode, autoreset)
+                    out.append((w.state.numpy(), w.policy.hidden_state(n), w.env.returns()))
+                others = np.ones(n, bool); others[21] = False
+                for clean, dirty in zip(*out):
+                    assert np.array_equal(clean[others], dirty[others]), (n, autoreset, bad)
+
+
 def test_split_f16_actor_saturates_out_of_range_inputs(device, oracle, weights):
     """RQ_POLICY_F16X2_MFMA beyond the f16 range (|x| >= 65 520 converts to infinity, and infinity minus infinity in the
     residual would be NaN in the GRU state for good): observations and layer_0's output are saturated at +-65 504 before
