@@ -1987,7 +1987,7 @@ def test_a_diverged_env_stays_alone_in_a_rollout(device, oracle, precision, mode
     and past the size where waves share a SIMD."""
     for n in (200, 70001):
         for autoreset in (True, False):
-            for bad in (np.inf, np.nan):
+            for bad, victim in ((np.inf, 21), (np.nan, 21), (np.inf, n - 1)):      # n - 1: the env the tail lanes shadow
                 out = []
                 for poisoned in (False, True):
                     w = World(device, oracle, n, seed=77, termination_enabled=0)
@@ -1995,13 +1995,13 @@ def test_a_diverged_env_stays_alone_in_a_rollout(device, oracle, precision, mode
                     w.policy.reset()
                     if poisoned:
                         S = w.state.numpy()
-                        S[21, 1] = bad
+                        S[victim, 1] = bad
                         w.state.set(S)
                     w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 7, mode, autoreset)
                     out.append((w.state.numpy(), w.policy.hidden_state(n), w.env.returns()))
-                others = np.ones(n, bool); others[21] = False
+                others = np.ones(n, bool); others[victim] = False
                 for clean, dirty in zip(*out):
-                    assert np.array_equal(clean[others], dirty[others]), (n, autoreset, bad)
+                    assert np.array_equal(clean[others], dirty[others]), (n, autoreset, bad, victim)
 
 
 def test_split_f16_actor_saturates_out_of_range_inputs(device, oracle, weights):
