@@ -444,17 +444,29 @@ def extension_probe(device, n):
     x = torch.randn(steps, n, 22, device="cuda:%d" % torch.cuda.current_device())
     for _ in range(3):
         pol.evaluate_sequence(x)
-    best = 1e9
+    single = 1e9
     for _ in range(3):
         device.timer_start()
         pol.evaluate_sequence(x)
-        best = min(best, device.timer_stop())
+        single = min(single, device.timer_stop())
+    # sustained, like the rollout figures: the chip's clock follows its load of the last milliseconds (tools/idle_clock.py) -
+    # the twentieth of twenty launches back to back runs 17 % faster than one launch between two synchronisations
+    regions = []
+    for _ in range(3):
+        device.synchronize()
+        device.timer_start()
+        for _ in range(16):
+            pol.evaluate_sequence(x)
+        regions.append(device.timer_stop() / 16)
+    best = float(np.median(regions))
     rate = n * steps / (best * 1e-3)
     tf = rate * FLOP_ACTOR / 1e12
     out["evaluate_sequence"] = {"bound": "mfma", "policy_steps_per_s": round(rate, 1),
-                                "us_per_step": round(best * 1e3 / steps, 3), "achieved_TFLOPs": round(tf, 2),
+                                "us_per_step": round(best * 1e3 / steps, 3),
+                                "us_per_step_single_launch": round(single * 1e3 / steps, 3), "achieved_TFLOPs": round(tf, 2),
                                 "peak_TFLOPs": PEAK_FP32_TFLOPS, "frac": round(tf / PEAK_FP32_TFLOPS, 4),
-                                "bytes_per_step": 104, "achieved_GBps": round(rate * 104 / 1e9, 1)}
+                                "bytes_per_step": 104, "achieved_GBps": round(rate * 104 / 1e9, 1),
+                                "statistic": "median of 3 regions of 16 launches back to back (single: best of 3 launches, each between two synchronisations)"}
     return out
 
 
@@ -476,12 +488,13 @@ def teacher_probe(device, n, steps=500, hidden=64):
                           ("contiguous", (np.arange(n, dtype=np.int64) * teachers // n).astype(np.uint32))):
             for _ in range(4):                     # untimed: the first launches of a bank run on cold caches and clocks
                 tr.relabel_teachers(bank, ids, fetch=False)
-            device.synchronize()
             per = []
-            for _ in range(5):
+            for _ in range(3):                     # regions of 4 launches back to back (the clock follows the load: see evaluate_sequence)
+                device.synchronize()
                 device.timer_start()
-                tr.relabel_teachers(bank, ids, fetch=False)
-                per.append(device.timer_stop())
+                for _ in range(4):
+                    tr.relabel_teachers(bank, ids, fetch=False)
+                per.append(device.timer_stop() / 4)
             ms = float(np.median(per))
             tf = flop_label * n * steps / (ms * 1e-3) / 1e12
             out[f"teachers_{teachers}_{name}"] = {"ms": round(ms, 3), "labels_per_s": round(n * steps / (ms * 1e-3), 1),
