@@ -466,7 +466,21 @@ typedef struct rq_comm rq_comm;
 RQ_API int rq_comm_unique_id(void* id_out, size_t bytes);
 RQ_API int rq_comm_create(rq_device* dev, uint32_t n_ranks, uint32_t rank, const void* id, size_t bytes, rq_comm** out);
 RQ_API int rq_comm_destroy(rq_comm* comm);
+/* (n_ranks, rank) as the communicator ITSELF reports them - ncclCommCount / ncclCommUserRank -, not rq_comm_create's arguments
+ * handed back; rq_comm_create fails when the two disagree. */
 RQ_API int rq_comm_info(const rq_comm* comm, uint32_t* n_ranks, uint32_t* rank);
+/* What a record of a multi-GPU run needs to prove which RCCL saw how many ranks on which GPU (bench.py config.rccl):
+ * every field is asked of RCCL / the HIP runtime at the time of the call. */
+typedef struct rq_comm_description {
+    uint32_t struct_bytes;        /* in: sizeof(rq_comm_description)                                                    */
+    uint32_t n_ranks, rank;       /* ncclCommCount, ncclCommUserRank                                                    */
+    int32_t  rccl_version;        /* ncclGetVersion (major * 10000 + minor * 100 + patch), -1 when the library has none  */
+    int32_t  device;              /* ncclCommCuDevice: the HIP ordinal the communicator is bound to                      */
+    char     pci_bus_id[32];      /* hipDeviceGetPCIBusId of that device, e.g. "0000:05:00.0"                            */
+    char     library_path[256];   /* the file ncclAllGather was mapped from (dladdr): PyTorch's copy or /opt/rocm's      */
+    uint64_t collectives_posted;  /* rq_allgather_returns calls on this communicator so far                             */
+} rq_comm_description;
+RQ_API int rq_comm_describe(const rq_comm* comm, rq_comm_description* out);
 /* ENQUEUE the all-gather of this rank's rq_env_get_finished_returns: the copy on the env's own stream (right
  * behind the rollout that produced the returns), the collective on a side stream behind an event, double-
  * buffered; the host does not block.  Every rank must call it the same number of times with envs of the same size.

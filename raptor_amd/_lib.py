@@ -169,6 +169,7 @@ _SIGNATURES = {
     "rq_comm_create": [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(_vp)],
     "rq_comm_destroy": [_vp],
     "rq_comm_info": [_vp, _u32p, _u32p],
+    "rq_comm_describe": [_vp, _vp],
     "rq_allgather_returns": [_vp, _vp],
     "rq_comm_gathered": [_vp, C.POINTER(_vp), _u32p, _fp],
     "rq_teacher_bank_create": [_vp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(_vp)],

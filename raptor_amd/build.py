@@ -23,6 +23,9 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"--offload-arch={ARCH}",
                 "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 DEVICE_FLAGS += os.environ.get("RQ_EXTRA_HIPCC_FLAGS", "").split()      # compiler-flag experiments only
+if os.environ.get("RQ_NO_MFMA_VGPR_FORM"):                                 # (an -mllvm option cannot be given twice to override it)
+    _i = DEVICE_FLAGS.index("-amdgpu-mfma-vgpr-form=1")
+    del DEVICE_FLAGS[_i - 1:_i + 1]
 SOURCES = ["rq_kernels.hip", "rq_kernels_16bit.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
 HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_rollout.hpp", "rq_host.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
 # per-source flags.  Round 4 built rq_kernels_16bit.hip with -mllvm -amdgpu-sched-strategy=max-ilp (a lone wave stalls ~3 cycles

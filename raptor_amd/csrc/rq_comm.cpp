@@ -33,6 +33,8 @@ typedef int (*CommInitRankFn)(NcclComm*, int, NcclId, int);
 typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, NcclComm, hipStream_t);
 typedef const char* (*ErrorStringFn)(int);
+typedef int (*CommCountFn)(NcclComm, int*);          // ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+typedef int (*GetVersionFn)(int*);
 
 struct Rccl {
     void* lib = nullptr;
@@ -41,6 +43,10 @@ struct Rccl {
     CommDestroyFn comm_destroy = nullptr;
     AllGatherFn all_gather = nullptr;
     ErrorStringFn error_string = nullptr;
+    // what the communicator says about ITSELF (rq_comm_describe): a record of an N-rank run must not echo its own arguments
+    CommCountFn comm_count = nullptr, comm_user_rank = nullptr, comm_device = nullptr;
+    GetVersionFn get_version = nullptr;
+    std::string path;                        // the file the all-gather's code was mapped from (dladdr)
     std::string error;
 };
 
@@ -61,10 +67,17 @@ Rccl* rccl() {
         r.comm_destroy = (CommDestroyFn)dlsym(r.lib, "ncclCommDestroy");
         r.all_gather = (AllGatherFn)dlsym(r.lib, "ncclAllGather");
         r.error_string = (ErrorStringFn)dlsym(r.lib, "ncclGetErrorString");
-        if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) {
-            r.error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+        r.comm_count = (CommCountFn)dlsym(r.lib, "ncclCommCount");
+        r.comm_user_rank = (CommCountFn)dlsym(r.lib, "ncclCommUserRank");
+        r.comm_device = (CommCountFn)dlsym(r.lib, "ncclCommCuDevice");
+        r.get_version = (GetVersionFn)dlsym(r.lib, "ncclGetVersion");
+        if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.comm_count || !r.comm_user_rank) {
+            r.error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclCommCount / ncclCommUserRank";
             r.lib = nullptr;
+            return;
         }
+        Dl_info where;
+        if (dladdr((void*)r.all_gather, &where) && where.dli_fname) r.path = where.dli_fname;
     });
     return &r;
 }
@@ -144,6 +157,14 @@ RQ_API int rq_comm_create(rq_device* dev, uint32_t n_ranks, uint32_t rank, const
     std::memcpy(nid.bytes, id, RQ_COMM_ID_BYTES);
     const int nrc = r->comm_init_rank(&c->comm, (int)n_ranks, nid, (int)rank);      // collective over all ranks
     if (nrc != 0) { c->comm = nullptr; rq_comm_destroy(c); return rq::fail(RQ_ERR_HIP, std::string("rq_comm_create: ") + nccl_message(nrc)); }
+    // the communicator RCCL built must be the one that was asked for: its own count and rank, not the arguments' echo
+    int got_n = -1, got_r = -1;
+    const int qrc = r->comm_count(c->comm, &got_n) | r->comm_user_rank(c->comm, &got_r);
+    if (qrc != 0 || got_n != (int)n_ranks || got_r != (int)rank) {
+        rq_comm_destroy(c);
+        return rq::fail(RQ_ERR_HIP, "rq_comm_create: the communicator reports rank " + std::to_string(got_r) + " of " + std::to_string(got_n) +
+                                        ", asked for rank " + std::to_string(rank) + " of " + std::to_string(n_ranks));
+    }
     *out = c;
     return RQ_OK;
 }
@@ -165,8 +186,36 @@ RQ_API int rq_comm_destroy(rq_comm* c) {
 
 RQ_API int rq_comm_info(const rq_comm* c, uint32_t* n_ranks, uint32_t* rank) {
     RQ_REQUIRE(c, RQ_ERR_INVALID_ARGUMENT, "null argument");
-    if (n_ranks) *n_ranks = c->n_ranks;
-    if (rank) *rank = c->rank;
+    // asked of the communicator (ncclCommCount / ncclCommUserRank), not remembered from rq_comm_create's arguments
+    int got_n = -1, got_r = -1;
+    const int qrc = rccl()->comm_count(c->comm, &got_n) | rccl()->comm_user_rank(c->comm, &got_r);
+    if (qrc != 0) return rq::fail(RQ_ERR_HIP, std::string("rq_comm_info: ") + nccl_message(qrc));
+    if (n_ranks) *n_ranks = (uint32_t)got_n;
+    if (rank) *rank = (uint32_t)got_r;
+    return RQ_OK;
+}
+
+RQ_API int rq_comm_describe(const rq_comm* c, rq_comm_description* out) {
+    RQ_REQUIRE(c && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(out->struct_bytes == sizeof(rq_comm_description), RQ_ERR_INVALID_ARGUMENT,
+               "rq_comm_description.struct_bytes must be sizeof(rq_comm_description) of this header");
+    Rccl* r = rccl();
+    std::memset(out, 0, sizeof(*out));
+    out->struct_bytes = sizeof(*out);
+    int v = -1;
+    int rc = r->comm_count(c->comm, &v);
+    if (rc != 0) return rq::fail(RQ_ERR_HIP, std::string("rq_comm_describe: ") + nccl_message(rc));
+    out->n_ranks = (uint32_t)v;
+    rc = r->comm_user_rank(c->comm, &v);
+    if (rc != 0) return rq::fail(RQ_ERR_HIP, std::string("rq_comm_describe: ") + nccl_message(rc));
+    out->rank = (uint32_t)v;
+    out->rccl_version = -1;
+    if (r->get_version && r->get_version(&v) == 0) out->rccl_version = v;
+    out->device = c->ordinal;
+    if (r->comm_device && r->comm_device(c->comm, &v) == 0) out->device = v;      // the device RCCL bound the communicator to
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), out->device) != hipSuccess) out->pci_bus_id[0] = 0;
+    std::strncpy(out->library_path, r->path.c_str(), sizeof(out->library_path) - 1);
+    out->collectives_posted = c->posts;
     return RQ_OK;
 }
 

@@ -578,7 +578,7 @@ hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, cons
     const bool lean = n > 65536u;          // two waves per SIMD only pay when there are that many
 #define RQ_LAUNCH_SEQ(ACT) k_actor_sequence<ACT><<<g, kFusedBlock, 0, s>>>(n, steps, packed, obs, stride, hidden, ld_h, act, squash)
     if (precision == RQ_POLICY_F16X2_MFMA) RQ_LAUNCH_SEQ(ActorF16X2);
-    else if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_SEQ(ActorBF16Lean); else RQ_LAUNCH_SEQ(ActorBF16); }
+    else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_SEQ(ActorBF16);          // one build at every size (round 5: see ActorBF16Lean)
     else                                  { if (lean) RQ_LAUNCH_SEQ(ActorF32Lean); else RQ_LAUNCH_SEQ(ActorF32); }
 #undef RQ_LAUNCH_SEQ
     return hipGetLastError();
@@ -594,7 +594,7 @@ hipError_t launch_actor_relabel(hipStream_t s, uint32_t n, uint32_t ld, uint32_t
     const bool lean = n > 65536u;
 #define RQ_LAUNCH_RELABEL(ACT) k_actor_relabel<ACT><<<g, kFusedBlock, 0, s>>>(n, ld, steps, packed, obs, done, hidden, ld_h, act, squash)
     if (precision == RQ_POLICY_F16X2_MFMA) RQ_LAUNCH_RELABEL(ActorF16X2);
-    else if (precision == RQ_POLICY_BF16_MFMA) { if (lean) RQ_LAUNCH_RELABEL(ActorBF16Lean); else RQ_LAUNCH_RELABEL(ActorBF16); }
+    else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_RELABEL(ActorBF16);      // one build at every size (round 5: see ActorBF16Lean)
     else                                  { if (lean) RQ_LAUNCH_RELABEL(ActorF32Lean); else RQ_LAUNCH_RELABEL(ActorF32); }
 #undef RQ_LAUNCH_RELABEL
     return hipGetLastError();

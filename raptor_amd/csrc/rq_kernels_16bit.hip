@@ -1,19 +1,26 @@
 // rq_kernels_16bit.hip - the fused rollout kernel instantiated for the 16-bit actors (bf16 operands: BASELINE config 5;
-// split-f16 operands), in a translation unit of its own because it wants another instruction scheduler than the
-// hand-ordered fp32 build: see rq_rollout.hpp (and raptor_amd/build.py SOURCE_FLAGS for what was tried and taken back).
+// split-f16 operands), in a translation unit of its own: a place for per-build compiler flags (raptor_amd/build.py
+// SOURCE_FLAGS; none today - round 4 tried another instruction scheduler here and took it back) and half the compile time.
 #include "rq_rollout.hpp"
 
 namespace rq {
 
 hipError_t launch_rollout_fused_16bit(hipStream_t s, const FusedArgs& a, bool noise, bool ar, int precision) {
-    // The bf16 actor runs its one-wave-per-SIMD (512-register) build at EVERY batch size (round 4): the two-waves-per-SIMD build
-    // spills (124 dwords of scratch per lane) and was 4 % slower per env at 262 144 envs than the one-wave build is at 65 536
-    // (5.69 us against 4 x 1.36 us per step); only the SampleAndSquash stage still rides on the 256-register build.
+    // The bf16 actor runs its one-wave-per-SIMD (512-register) build at EVERY batch size and with every output stage.
+    // Round 4 kept a two-waves-per-SIMD (256-register) build, ActorBF16Lean, for the SampleAndSquash stage and for large batches;
+    // under another instruction scheduler (-amdgpu-sched-strategy=max-ilp) that build gave run-to-run different results and round
+    // 5 could not name the cause (profiles/r05_bf16_two_wave_hunt.md: what it is NOT is measured).  A kernel
+    // whose correctness depends on an instruction order nobody can justify does not ship: the type exists in experiment builds
+    // only (-DRQ_BF16_FUSED_LEAN, tools/hazard_variants.sh), no product launcher names it, tests/test_capi_cpu.py checks that.
     if (a.sas.mode != RQ_SAS_OFF) {
         if (precision == RQ_POLICY_F16X2_MFMA) launch_fused_actor<true, ActorF16X2>(s, a, noise, ar);
-        else                                   launch_fused_actor<true, ActorBF16Lean>(s, a, noise, ar);
+        else                                   launch_fused_actor<true, ActorBF16>(s, a, noise, ar);
     } else if (precision == RQ_POLICY_F16X2_MFMA) {
         launch_fused_actor<false, ActorF16X2>(s, a, noise, ar);
+#ifdef RQ_BF16_FUSED_LEAN      // experiment builds only: the two-waves-per-SIMD build beyond 65 536 envs, as round 4 shipped it
+    } else if (a.b.n > 65536u) {
+        launch_fused_actor<false, ActorBF16Lean>(s, a, noise, ar);
+#endif
     } else {
         launch_fused_actor<false, ActorBF16>(s, a, noise, ar);
     }

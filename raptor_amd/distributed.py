@@ -162,6 +162,25 @@ class NativeReturnsExchange:
         _lib.call("rq_comm_info", self._h, C.byref(n), C.byref(r))
         return n.value, r.value
 
+    def describe(self):
+        """What RCCL and the HIP runtime say about this communicator (rq_comm_describe): ranks, rank, RCCL version, the
+        library file the collective's code was mapped from, the device and its PCI bus id -> dict."""
+        import ctypes as C
+        from . import _lib
+
+        class Description(C.Structure):          # rq_comm_description (include/raptor_quad.h)
+            _fields_ = [("struct_bytes", C.c_uint32), ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("rccl_version", C.c_int32),
+                        ("device", C.c_int32), ("pci_bus_id", C.c_char * 32), ("library_path", C.c_char * 256),
+                        ("collectives_posted", C.c_uint64)]
+        d = Description()
+        d.struct_bytes = C.sizeof(Description)
+        _lib.call("rq_comm_describe", self._h, C.byref(d))
+        v = int(d.rccl_version)
+        return {"ranks": int(d.n_ranks), "rank": int(d.rank), "version_code": v,
+                "version": None if v < 0 else (f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v >= 10000 else f"{v // 1000}.{v // 100 % 10}.{v % 100}"),
+                "device": int(d.device), "pci_bus_id": d.pci_bus_id.decode(), "library_path": d.library_path.decode(),
+                "collectives_posted": int(d.collectives_posted)}
+
     def post(self, env):
         from . import _lib
         _lib.call("rq_allgather_returns", env._require("environment"), self._h)

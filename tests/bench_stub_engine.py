@@ -6,7 +6,9 @@ with world_size 2 on the gloo backend before an 8-GPU node ever sees it.
     RANK=0 WORLD_SIZE=2 ... python bench.py --gpus 2 --engine tests.bench_stub_engine --backend gloo ...
 
 Failure injection (environment): RQ_STUB_FAIL_PHASE1=<rank> makes that rank fail to produce a communicator id,
-RQ_STUB_FAIL_PHASE2=<rank> makes its communicator creation fail - the other ranks must not be left waiting."""
+RQ_STUB_FAIL_PHASE2=<rank> makes its communicator creation fail - the other ranks must not be left waiting;
+RQ_STUB_WRONG_RANKS=<k> makes the communicator describe itself as spanning k ranks, RQ_STUB_SCRAMBLE=1 makes the gathered
+blocks come back rotated by one rank - either way bench.py must refuse to print a value."""
 import os
 import time
 
@@ -70,7 +72,18 @@ class _StubNativeExchange:
 
     def result(self):
         out = self.finish()
-        return None if out is None else out.numpy()
+        if out is None:
+            return None
+        got = out.numpy()
+        if os.environ.get("RQ_STUB_SCRAMBLE") and self.world > 1:      # a gather that lands the ranks' blocks in the wrong places
+            got = np.roll(got.reshape(self.world, -1), 1, axis=0).reshape(-1).copy()
+        return got
+
+    def describe(self):
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        fake = os.environ.get("RQ_STUB_WRONG_RANKS")          # a communicator that spans fewer ranks than the job
+        return {"ranks": int(fake) if fake else self.world, "rank": rank, "version": "stub", "version_code": 0, "device": rank,
+                "pci_bus_id": f"stub:{rank:02x}:00.0", "library_path": __file__, "collectives_posted": None}
 
 
 class StubEngine:

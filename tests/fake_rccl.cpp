@@ -1,5 +1,5 @@
-// fake_rccl.cpp — TESTS ONLY.  The five RCCL entry points rq_comm.cpp binds (ncclGetUniqueId, ncclCommInitRank,
-// ncclCommDestroy, ncclAllGather, ncclGetErrorString) for ranks that are PROCESSES SHARING ONE GPU: the box the
+// fake_rccl.cpp — TESTS ONLY.  The RCCL entry points rq_comm.cpp binds (ncclGetUniqueId, ncclCommInitRank,
+// ncclCommDestroy, ncclAllGather, ncclGetErrorString, ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion) for ranks that are PROCESSES SHARING ONE GPU: the box the
 // GPU tests run on has a single MI355X, real RCCL needs one device per rank, and rq_allgather_returns' double
 // buffering, event ordering and global env order had never run with n_ranks = 2.  Built by the test
 // (hipcc -shared -fPIC) and selected with RQ_RCCL_LIBRARY.
@@ -148,6 +148,29 @@ __attribute__((visibility("default"))) int ncclAllGather(const void* send, void*
     Job* job = new Job{c, ++c->seq, bytes};
     if (hipLaunchHostFunc(stream, exchange_on_host, job) != hipSuccess) { delete job; return 1; }
     if (hipMemcpyAsync(recv, c->host_recv, bytes * (size_t)c->n_ranks, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int ncclCommCount(const Comm* c, int* count) {
+    if (!c || !count) return 4;
+    *count = c->n_ranks;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int ncclCommUserRank(const Comm* c, int* rank) {
+    if (!c || !rank) return 4;
+    *rank = c->rank;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int ncclCommCuDevice(const Comm* c, int* device) {
+    if (!c || !device) return 4;
+    return hipGetDevice(device) == hipSuccess ? 0 : 1;
+}
+
+__attribute__((visibility("default"))) int ncclGetVersion(int* version) {
+    if (!version) return 4;
+    *version = 0;                                     // no RCCL release: a record that carries 0 ran on this stand-in
     return 0;
 }
 

@@ -153,6 +153,18 @@ def test_comm_entry_points_validate_and_fail_loudly_without_a_gpu():
         assert (rc == 0 and any(buf.raw)) or (rc != 0 and len(lib.rq_last_error()) > 0)
 
 
+def test_product_library_holds_no_two_wave_bf16_kernel():
+    """Round 5: the two-waves-per-SIMD bf16 actor build (ActorBF16Lean) gave run-to-run different results under another instruction
+    schedule and its cause was not found (profiles/r05_bf16_two_wave_hunt.md): it exists in experiment builds only.  The product
+    library must not contain a kernel instantiated with it, and rq_comm_describe / rq_comm_info refuse null handles."""
+    from raptor_amd import _lib
+    lib = _lib.load()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"ActorBF16E" in blob                           # the one-wave build is there (mangled kernel names are in the code object)
+    assert b"ActorBF16Lean" not in blob
+    assert lib.rq_comm_describe(None, None) == -1 and lib.rq_comm_info(None, None, None) == -1
+
+
 def test_split_f16_operand_image_reconstructs_the_weights():
     """RQ_POLICY_F16X2_MFMA keeps every weight as two f16 numbers, hi = f16(w') and lo = f16(w' - hi) with w'
     the weight after the gate pre-scaling.  rq_policy_pack_image is host code: decode the image with numpy's float16

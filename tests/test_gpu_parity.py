@@ -1073,28 +1073,62 @@ def test_short_launches_follow_every_change_between_them(device, oracle, precisi
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
 def test_fused_rollout_is_deterministic(device, oracle, precision):
-    """The same rollout twice gives the same bits - every build of the fused kernel: one wave per SIMD (4 097, 65 536 envs) and
-    two (70 001, 131 072, 262 144 + 129), with and without auto-reset, short launches and a longer one.  Round 4 found the
-    two-waves-per-SIMD bf16 build differing FROM RUN TO RUN (whole 16-env tiles, ~1 % of the envs) when its translation unit
-    was compiled with the max-ilp instruction scheduler; fused-against-chained at 70 001 envs had not seen it (the runs agree
-    most of the time).  Three repetitions per case; the chained path the same."""
-    cases = [(4097, 3, True), (65536, 2, True), (70001, 3, True), (131072, 3, True), (131072, 3, False), (131072, 40, True),
-             (262144 + 129, 2, True)]
-    for n, steps, autoreset in cases:
+    """The same rollout twice gives the same bits - every build of the fused kernel that ships: the fp32 build with one wave per
+    SIMD (4 097, 65 536 envs) and with two (70 001, 131 072, 262 144 + 129), the bf16 and split-f16 builds (one wave per SIMD at
+    every size since round 5), with and without auto-reset, short launches and a longer one - AND the SampleAndSquash
+    instantiations of each (round 4's verdict: the builds behind that stage had no determinism test).  Round 4 found a
+    two-waves-per-SIMD bf16 build differing FROM RUN TO RUN (lanes 48 .. 63 of ~1 % of the waves) when compiled with the max-ilp
+    instruction scheduler; round 5 could not name the cause and took that build out of the product
+    (profiles/r05_bf16_two_wave_hunt.md).  Three repetitions per case; the chained path the same."""
+    cases = [(4097, 3, True, "off"), (65536, 2, True, "off"), (70001, 3, True, "off"), (131072, 3, True, "off"), (131072, 3, False, "off"),
+             (131072, 40, True, "off"), (262144 + 129, 2, True, "off"),
+             (65536, 3, True, "mean"), (131072, 3, True, "mean"), (131072, 3, False, "sample"), (70001, 25, True, "sample")]
+    for n, steps, autoreset, sas in cases:
         for rep in range(3):
             kw = dict(seed=40 + rep, episode_step_limit=4 if steps < 10 else 25)
             a, b = World(device, oracle, n, **kw), World(device, oracle, n, **kw)
-            a.policy.set_precision(precision); b.policy.set_precision(precision)
             for w in (a, b):
+                w.policy.set_precision(precision)
+                if sas != "off":
+                    w.policy.set_sample_and_squash(sas, log_std_bias=np.full(4, -1.0, np.float32), seed=5)
                 w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, steps, "fused", autoreset)
-            assert np.array_equal(a.state.numpy(), b.state.numpy()), (n, steps, autoreset, rep)
-            assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n)), (n, steps, autoreset, rep)
+            assert np.array_equal(a.state.numpy(), b.state.numpy()), (n, steps, autoreset, sas, rep)
+            assert np.array_equal(a.policy.hidden_state(n), b.policy.hidden_state(n)), (n, steps, autoreset, sas, rep)
             assert np.array_equal(a.env.returns(), b.env.returns())
     a, b = World(device, oracle, 131072, seed=3, episode_step_limit=4), World(device, oracle, 131072, seed=3, episode_step_limit=4)
     a.policy.set_precision(precision); b.policy.set_precision(precision)
     for w in (a, b):
         w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 5, "chained", True)
     assert np.array_equal(a.state.numpy(), b.state.numpy()) and np.array_equal(a.policy.hidden_state(131072), b.policy.hidden_state(131072))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
+def test_sequence_and_relabel_are_deterministic_at_large_batches(device, oracle, precision):
+    """Raptor.evaluate_sequence and Trajectory.relabel above 65 536 envs - where the fp32 actor switches to its two-waves-per-SIMD
+    build and where the bf16 one used to (round 4 shipped ActorBF16Lean there without a determinism test; round 5 runs the
+    one-wave bf16 build at every size): the same call twice, the same bits, three repetitions."""
+    import torch
+    from raptor_amd.foundation_policy import Raptor
+    n, steps = 70001, 6
+    x = torch.randn(steps, n, 22, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(7))
+    outs = []
+    for rep in range(3):
+        pol = Raptor(device, precision=precision)
+        pol.reset()
+        outs.append((pol.evaluate_sequence(x).cpu().numpy(), pol.hidden_state(n)))
+    for o, h in outs[1:]:
+        assert np.array_equal(o, outs[0][0]) and np.array_equal(h, outs[0][1])
+    w = World(device, oracle, n, seed=13, episode_step_limit=4)
+    w.policy.set_precision(precision)
+    traj = w.vector.Trajectory(w.env, steps)
+    w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, steps, "fused", True, trajectory=traj)
+    labels = []
+    for rep in range(3):
+        teacher = Raptor(device, precision=precision)
+        teacher.reset()
+        labels.append(traj.relabel(teacher))
+    assert np.array_equal(labels[0], labels[1]) and np.array_equal(labels[0], labels[2])
+    assert np.array_equal(labels[0], traj.numpy()["act"])            # the recording policy's own actions come back
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("RQ_RANDOM_CASES", "32"))))
@@ -2196,6 +2230,11 @@ def test_native_rccl_exchange_one_rank(device, oracle):
     w = World(device, oracle, 4096, seed=41, episode_step_limit=20)
     ex = NativeReturnsExchange(device, 1, 0, NativeReturnsExchange.unique_id())
     assert ex.info() == (1, 0)
+    d = ex.describe()               # asked of RCCL and the HIP runtime (round 5), not echoed from the arguments above
+    assert d["ranks"] == 1 and d["rank"] == 0 and d["device"] == 0 and d["collectives_posted"] == 0
+    assert d["version_code"] > 20000 and d["version"].count(".") == 2, d          # a real RCCL: 2.x.y
+    assert "rccl" in os.path.basename(d["library_path"]).lower() and os.path.exists(d["library_path"]), d
+    assert len(d["pci_bus_id"]) >= 7 and d["pci_bus_id"].count(":") == 2, d
     snaps = []
     for k in range(5):
         w.vector.rollout(device, w.env, w.params, w.state, w.policy, w.rng, 20, "fused", True)
@@ -2261,6 +2300,7 @@ def test_exchange_beside_saturating_rollouts_probe(device):
             pytest.skip(f"no RCCL to bind: {exc}")
         raise
     assert rec["envs"] == 4096 and rec["gathered_returns"] == 4096 and rec["bytes_per_rank"] == 16384
+    assert rec["exchange_verified"] is True and rec["rccl"]["ranks"] == 1 and rec["rccl"]["version_code"] > 20000      # RCCL's own account
     assert rec["us_per_episode_without_exchange"] > 100 and rec["us_per_episode_with_exchange"] > 100
     assert abs(rec["added_fraction"]) < 0.5 and abs(rec["rollout_slowdown_fraction"]) < 0.2
     assert 1.0 < rec["exchange_alone_us_post_to_gathered"] < 5000 and 0.5 < rec["post_call_host_us"] < 1000
@@ -2317,6 +2357,8 @@ def _shared_gpu_exchange_worker(rank, world, n, episodes, fake_lib, conn):
         ident = conn.recv()                                   # the parent relays rank 0's id to every rank
         ex = NativeReturnsExchange(dev, world, rank, ident)
         assert ex.info() == (world, rank)
+        d = ex.describe()
+        assert (d["ranks"], d["rank"], d["version_code"]) == (world, rank, 0) and d["library_path"] == fake_lib, d      # the stand-in says so itself
         snaps = []
         for k in range(episodes):
             # no host synchronisation between posts: the copy of episode k's returns sits on the engine's stream behind
@@ -2333,7 +2375,8 @@ def _shared_gpu_exchange_worker(rank, world, n, episodes, fake_lib, conn):
 
 
 @pytest.mark.timeout(600)
-def test_native_exchange_two_ranks_on_one_gpu(device, tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_exchange_two_ranks_on_one_gpu(device, tmp_path, world):
     """rq_comm_create / rq_allgather_returns / rq_comm_gathered with n_ranks = 2 (round 3): two processes share the one
     GPU of this box and bind a tests-only RCCL (tests/fake_rccl.cpp: all-gather = device->host copy, a host function
     in the stream that meets the other rank in shared memory, host->device copy - enqueued on the stream the product
@@ -2349,7 +2392,7 @@ def test_native_exchange_two_ranks_on_one_gpu(device, tmp_path):
     subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                                                  "fake_rccl.cpp"), "-o", fake, "-lrt"],
                    check=True, capture_output=True)
-    n, world, episodes = 4096, 2, 7
+    n, episodes = 4096, 7
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(world)]
     procs = [ctx.Process(target=_shared_gpu_exchange_worker, args=(r, world, n, episodes, fake, pipes[r][1])) for r in range(world)]
@@ -2444,6 +2487,10 @@ def test_bench_py_with_two_ranks_on_one_gpu(device, tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 16384 and d["config"]["engine"] == "hip"
     assert d["config"]["exchange"].startswith("native RCCL"), d["config"]["exchange"]
     assert d["config"]["gathered_returns"] == 16384
+    assert d["config"]["exchange_verified"] is True and d["config4"]["exchange_verified"] is True          # round 5: layout checked before a value is printed
+    assert d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["library_path"] == fake and d["config"]["rccl"]["version_code"] == 0
+    assert [r["rank"] for r in d["config"]["rccl"]["per_rank"]] == [0, 1]
+    assert d["config"]["rccl"]["distinct_gpus"] == 1        # both ranks of THIS test share the box's one GPU, and the record shows it
     assert d["timing"]["exchange_share"]["regions_with_extra_exchange"] >= 3
     assert d["steady_state"]["exchanges"] == 10 and d["config4"]["total_envs"] == 2 * 262144 and d["config4"]["exchanges"] == 4
     assert d["value"] > 1e8 and d["roofline"]["frac"] > 0.01
