@@ -272,7 +272,7 @@ def sixteen_bit_roofline(precision, n, steps_per_launch, avg_launch_s):
     mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
     kname = fused_kernel_name(precision, n, steps_per_launch)
     tr = pmc_traffic(kname, n)
-    return {"kernel": kname, "bound": "mfma", "achieved": round(valu, 3),
+    return {"kernel": kname, "bound": "valu_issue", "achieved": round(valu, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
             "traffic": None if tr is None else tr["bytes_per_launch"], "traffic_source": tr,
             "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
@@ -654,6 +654,58 @@ def cpu_baseline(seconds):
             "sample": f"{n} envs x {steps} steps of the same workload (domain-randomised, auto-reset), "
                       f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads_all} threads"
                       + ("" if value_eff is None else f"; again with {eff} threads ({max(20, steps // 2)} steps); `value` is the faster run")}
+
+
+def parity_block(device):
+    """What the record may claim about agreement with the reference, next to the headline (round 5): the actor against the
+    reference's two known-answer vectors, measured NOW on the HIP path; the environment's status (nothing in the reference tree can
+    pin it); and the one reference-produced statistic with no free parameter on the dynamics side - the training log's crazyflie/*
+    tags - against what this specification gives, which it does NOT reproduce (numbers from the newest committed
+    profiles/*_env_constraints.json, oracle runs of tools/env_constraint_study.py; the joint scan of
+    tools/joint_constraint_scan.py beside it)."""
+    import glob
+    from raptor_amd.foundation_policy import Raptor
+    out = {"actor": {"pinned_by": "checkpoint.h example (checkpoint.h:197-215) and h5:/example/{input,output}: 2 x [500, 2, 22] -> [500, 2, 4]",
+                     "tolerance": 1e-5},
+           "env": {"status": "unpinned vs l2f: the reference tree holds no source, test or trajectory of vector::step / observe / sample_* "
+                             "(.gitmodules:1-3: empty rl-tools submodule; README.md:33: pip packages not in the container)",
+                   "checked_instead": "bit-exact against oracle/raptor_oracle.c (the repository's own restatement) in `pytest -m gpu`; "
+                                      "closed-loop stabilisation by the shipped checkpoint"}}
+    gold = os.path.join(ROOT, "tests", "golden")
+    try:
+        pol = Raptor(device)
+        x = np.fromfile(os.path.join(gold, "kat_h_input.bin"), "<f4").reshape(500, 2, 22)
+        y = np.fromfile(os.path.join(gold, "kat_h_output.bin"), "<f4").reshape(500, 2, 4)
+        out["actor"]["kat_h_max_abs_err"] = float(pol.selftest(x, y, tolerance=1e-5))
+        from raptor_amd.checkpoint import load_checkpoint_h5
+        _, example, _ = load_checkpoint_h5(os.path.join(gold, "checkpoint.h5"))
+        if example is not None:
+            out["actor"]["kat_h5_max_abs_err"] = float(pol.selftest(example[0], example[1], tolerance=1e-5))
+    except Exception as exc:      # noqa: BLE001
+        out["actor"]["error"] = str(exc)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_env_constraints.json")), reverse=True)
+    if paths:
+        d = json.load(open(paths[0]))
+        row = next((r for r in d["rows"] if not r["change"]), None)
+        keys = ("share_terminated", "episode_length", "terminated_episode_length")
+        if row:
+            out["reference_log"] = {
+                "source": "logs.tfevents of the reference's checkpoint (tests/golden/reference_log.json), pool of the last 100 epochs; "
+                          "this specification: " + os.path.basename(paths[0]) + " (oracle, " + str(d["envs"]) + " envs)",
+                "evaluation": {"log": {k: round(d["log_sampled_quadrotors"][k], 4) for k in keys},
+                               "this_specification": {k: row["sampled_quadrotors"][k] for k in keys},
+                               "note": "termination_position = 1 m was FITTED to this tag's share: agreement there is not evidence"},
+                "crazyflie": {"log": {k: round(d["log_nominal_crazyflie"][k], 4) for k in keys},
+                              "this_specification": {k: row["nominal_crazyflie"][k] for k in keys},
+                              "note": "NOT reproduced (share three times too low); no fitted constant enters here"},
+                "reward_per_step": {"log": d.get("log_reward_per_step"), "this_specification": row["sampled_quadrotors"].get("reward_per_step")}}
+    joint = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_joint_constraints.json")), reverse=True)
+    if joint and "reference_log" in out:
+        j = json.load(open(joint[0]))
+        out["reference_log"]["joint_scan"] = {"source": os.path.basename(joint[0]), "verdict": j["verdict"],
+                                              "settings_reproducing_both_tags": len(j["joint_matches"])}
+    out["summary"] = "actor pinned; env unpinned (under-determined by the reference tree): parity is partial"
+    return out
 
 
 def native_exchange_probe(engine, n, launches=6, repeats=5):
@@ -1302,6 +1354,8 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             result["native_exchange_1rank"] = {"unavailable": str(exc)}
         result["readme_loop_n8"] = api_loop_probe(device)
         result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
+    if world == 1 and engine.name == "hip":
+        result["parity"] = parity_block(engine.device)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     result["config"]["exchanges_per_timed_region"] = round(args.steps / EPISODE, 4) if exchange is not None else 0

@@ -66,9 +66,11 @@
 extern "C" {
 #endif
 
-#define RQ_ABI_VERSION 3   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
+#define RQ_ABI_VERSION 4   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
                               rounds 2 and 3 (the latter: rq_device_last_rollout_waves)
-                              3 (round 4): rq_device_{set,get}_speculation, rq_device_last_rollout_clock; no struct changed */
+                              3 (round 4): rq_device_{set,get}_speculation, rq_device_last_rollout_clock; no struct changed
+                              4 (round 5): rq_comm_describe (new struct rq_comm_description); rq_comm_info / rq_comm_create ask RCCL for
+                              the communicator's own rank and size; rq_teacher_bank_create_layers */
 
 #if defined(__GNUC__)
 #define RQ_API __attribute__((visibility("default")))
@@ -442,6 +444,15 @@ typedef struct rq_teacher_bank rq_teacher_bank;
 RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t n_teachers, uint32_t in_dim,
                            uint32_t h1, uint32_t h2, int hidden_activation, int output_activation,
                            rq_teacher_bank** out);
+/* Any sequential stack of dense layers - what a teacher checkpoint in the reference's HDF5 layout may hold (README.md:211-216;
+ * raptor_amd.teachers.TeacherBank.from_checkpoints reads such files): in_dim -> widths[0] -> ... -> widths[n_hidden - 1] -> 4 with
+ * n_hidden in 1..3 and widths multiples of 16 up to 128; weights: n_teachers blocks [W1 | b1 | ... | W_out (4 x last) | b_out].
+ * Two hidden layers of 16 / 32 / 64 units are the register-stationary family above (this call then IS rq_teacher_bank_create);
+ * everything else streams its fp32 operands from L2 through the exact-f32 MFMA (rq_teacher.hip k_teacher_relabel_layers):
+ * rq_teacher_bank_set_precision accepts RQ_POLICY_FP32 only for such a bank. */
+RQ_API int rq_teacher_bank_create_layers(rq_device* dev, const float* weights, uint32_t n_teachers, uint32_t in_dim,
+                                  uint32_t n_hidden, const uint32_t* widths, int hidden_activation, int output_activation,
+                                  rq_teacher_bank** out);
 RQ_API int rq_teacher_bank_destroy(rq_teacher_bank* bank);
 RQ_API int rq_teacher_bank_set_precision(rq_teacher_bank* bank, int precision);   /* rq_policy_precision */
 /* Actions of teacher teacher_id[i] (host array, one id per env) on every recorded step of env i.

@@ -255,5 +255,19 @@ def teacher_relabel(weights, in_dim, h1, h2, act, out_act, obs, teacher_id, nthr
     return out
 
 
+def mlp_relabel(weights, in_dim, widths, act, out_act, obs, teacher_id, nthreads=0):
+    """Any stack of dense layers in_dim -> widths[0] -> ... -> 4 (1 to 3 hidden layers, widths <= 128; codes: 0 identity, 1 ReLU,
+    2 tanh): weights [n_teachers, P] as [W1 | b1 | ... | W_out | b_out], obs [T, n, 22], teacher_id [n] -> actions [T, n, 4]."""
+    w, wp = _f(weights)
+    o, op = _f(obs)
+    ids = np.ascontiguousarray(teacher_id, np.uint32)
+    wd = np.ascontiguousarray(widths, np.uint32)
+    T, n, _ = o.shape
+    out = np.empty((T, n, 4), np.float32)
+    lib().orc_mlp_relabel(wp, C.c_uint32(in_dim), C.c_uint32(len(wd)), _p(wd, C.c_uint32), C.c_int(act), C.c_int(out_act),
+                          op, _p(ids, C.c_uint32), C.c_uint32(T), C.c_uint32(n), _p(out, C.c_float), C.c_int(nthreads))
+    return out
+
+
 def max_threads():
     return int(lib().orc_max_threads())

@@ -659,6 +659,49 @@ ORC_EXPORT void orc_teacher_relabel(const float* w, uint32_t in, uint32_t h1, ui
         }
 }
 
+/* Any sequential stack of dense layers (round 5; raptor_quad.h rq_teacher_bank_create_layers): in -> widths[0] -> ... ->
+ * widths[n_hidden - 1] -> 4, the same Dense arithmetic layer by layer ([W | b] blocks in order, rows = outputs; the layout of
+ * rl-tools dense layers, checkpoint.h:39-53), n_hidden <= 3, widths <= 128. */
+ORC_EXPORT void orc_mlp_forward(const float* w, uint32_t in, uint32_t n_hidden, const uint32_t* widths, int act, int out_act,
+                                const float* x, float* out) {
+    float a[128], b[128];
+    const float* src = x;
+    float* dst = a;
+    uint32_t prev = in;
+    for (uint32_t l = 0; l <= n_hidden; ++l) {
+        const uint32_t rows = l < n_hidden ? widths[l] : 4;
+        const float *W = w, *bias = W + (size_t)rows * prev;
+        float* y = l < n_hidden ? dst : out;
+        for (uint32_t o = 0; o < rows; ++o) {
+            float acc = bias[o];
+            for (uint32_t k = 0; k < prev; ++k) acc = fmaf(W[(size_t)o * prev + k], src[k], acc);
+            y[o] = orc_act(l < n_hidden ? act : out_act, acc);
+        }
+        w = bias + rows;
+        src = y;
+        dst = (y == a) ? b : a;
+        prev = rows;
+    }
+}
+
+/* obs [T][n][22] -> out [T][n][4] with teacher teacher_id[i] for env i */
+ORC_EXPORT void orc_mlp_relabel(const float* w, uint32_t in, uint32_t n_hidden, const uint32_t* widths, int act, int out_act,
+                                const float* obs, const uint32_t* teacher_id, uint32_t T, uint32_t n, float* out, int nthreads) {
+    size_t per = 0;
+    uint32_t prev = in;
+    for (uint32_t l = 0; l < n_hidden; ++l) { per += (size_t)widths[l] * prev + widths[l]; prev = widths[l]; }
+    per += (size_t)4 * prev + 4;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ++ii)
+        for (uint32_t t = 0; t < T; ++t) {
+            const size_t slot = (size_t)t * n + (size_t)ii;
+            orc_mlp_forward(w + per * teacher_id[ii], in, n_hidden, widths, act, out_act, obs + slot * 22, out + slot * 4);
+        }
+}
+
 ORC_EXPORT int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

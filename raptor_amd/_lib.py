@@ -173,6 +173,7 @@ _SIGNATURES = {
     "rq_allgather_returns": [_vp, _vp],
     "rq_comm_gathered": [_vp, C.POINTER(_vp), _u32p, _fp],
     "rq_teacher_bank_create": [_vp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(_vp)],
+    "rq_teacher_bank_create_layers": [_vp, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, C.c_int, C.c_int, C.POINTER(_vp)],
     "rq_teacher_bank_destroy": [_vp],
     "rq_teacher_bank_set_precision": [_vp, C.c_int],
     "rq_trajectory_relabel_teachers": [_vp, _vp, _vp, _fp, C.c_int],
@@ -182,7 +183,7 @@ _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class _EnvConfigAbi1(C.Structure):
@@ -193,7 +194,7 @@ class _EnvConfigAbi1(C.Structure):
     as_dict = EnvConfig.as_dict
 
 
-_CONFIG_BY_ABI = {1: _EnvConfigAbi1, 2: EnvConfig, 3: EnvConfig}
+_CONFIG_BY_ABI = {1: _EnvConfigAbi1, 2: EnvConfig, 3: EnvConfig, 4: EnvConfig}
 _config_type = EnvConfig
 
 
@@ -244,8 +245,9 @@ def load():
         _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         # RAPTOR_QUAD_ABI_ANY: same-box timing of an OLDER build (tools/ab_run.sh).  Only calls both versions share work:
-        # entry points the older library lacks are left unbound (calling one raises AttributeError at the call), and the
-        # rq_env_*_config calls, whose struct differs between ABI versions, are refused (_config_abi_guard)
+        # entry points the older library lacks are left unbound (calling one raises AttributeError at the call); the
+        # rq_env_*_config calls, whose struct differs between ABI versions, are bound to THAT version's struct below, or
+        # refused when this package does not know it (env_config_type)
         any_abi = bool(os.environ.get("RAPTOR_QUAD_ABI_ANY"))
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(lib, name, None)
@@ -261,6 +263,13 @@ def load():
                 raise RaptorQuadError(-1, f"ABI version mismatch: raptor_amd speaks {ABI_VERSION}, {LIB_PATH} is {abi}")
             global _config_type
             _config_type = _CONFIG_BY_ABI.get(abi)      # None: the rq_env_*_config calls are refused (env_config_type)
+            if _config_type is not None and _config_type is not EnvConfig:
+                # ctypes checks pointer types by class: a pointer to the older struct is not a POINTER(EnvConfig)
+                ptr = C.POINTER(_config_type)
+                for name, argtypes in (("rq_env_default_config", [ptr]), ("rq_env_set_config", [_vp, ptr]), ("rq_env_get_config", [_vp, ptr])):
+                    fn = getattr(lib, name, None)
+                    if fn is not None:
+                        fn.argtypes = argtypes
         _lib = lib
     return _lib
 

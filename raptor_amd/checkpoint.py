@@ -200,6 +200,67 @@ def write_checkpoint_h5(path, weights, example=None, meta=_DEFAULT_META, checkpo
     write_file(path, build(tree, ""))
 
 
+_ACT_NAMES = {"RELU": "relu", "TANH": "tanh", "IDENTITY": "identity", "FAST_TANH": "tanh"}
+
+
+def load_mlp_checkpoint_h5(path, group="actor"):
+    """A `sequential` of `dense` layers in rl-tools' HDF5 layout - what `extract_checkpoints.sh` gathers for the teachers
+    (README.md:211-216), the layout of `h5:/actor/layers/*` in the shipped student checkpoint: groups `<group>/layers/{i}` with string
+    attributes `type` = "dense" and `activation_function`, datasets `weights/parameters` [out, in] and `biases/parameters` [1, out]
+    or [out].  -> (layers: list of (W [out, in], b [out]) float32, activations: list of "relu" | "tanh" | "identity").
+    Anything else (a recurrent layer, a missing dataset, shapes that do not chain) is refused with the reason."""
+    from .hdf5_min import File
+    root = File(path).root
+    if group not in root:
+        raise ValueError(f"{path}: no group /{group}")
+    g = root[group]
+    if g.attrs.get("type") != "sequential":
+        raise ValueError(f"{path}: /{group} is '{g.attrs.get('type')}', expected a 'sequential' model")
+    layers, acts, i = [], [], 0
+    while f"layers/{i}" in g:
+        lay = g[f"layers/{i}"]
+        kind, fn = lay.attrs.get("type"), lay.attrs.get("activation_function")
+        if kind != "dense":
+            raise ValueError(f"{path}: /{group}/layers/{i} is a '{kind}' layer; a teacher is a stack of dense layers")
+        if fn not in _ACT_NAMES:
+            raise ValueError(f"{path}: /{group}/layers/{i} has activation '{fn}' (supported: {sorted(_ACT_NAMES)})")
+        try:
+            W, b = lay["weights/parameters"].numpy(), lay["biases/parameters"].numpy()
+        except KeyError as e:
+            raise ValueError(f"{path}: /{group}/layers/{i} lacks {e}")
+        W, b = np.asarray(W, np.float32), np.asarray(b, np.float32).reshape(-1)
+        if W.ndim != 2 or b.shape[0] != W.shape[0] or (layers and W.shape[1] != layers[-1][0].shape[0]):
+            raise ValueError(f"{path}: /{group}/layers/{i}: weights {W.shape}, biases {b.shape} do not chain")
+        layers.append((W, b))
+        acts.append(_ACT_NAMES[fn])
+        i += 1
+    if not layers:
+        raise ValueError(f"{path}: /{group} has no layers")
+    return layers, acts
+
+
+def write_mlp_checkpoint_h5(path, layers, activations, group="actor", meta=None):
+    """Inverse of ``load_mlp_checkpoint_h5``: dense layers (W [out, in], b [out]) with their activations ("relu" | "tanh" |
+    "identity") in the group / dataset / attribute layout rl-tools writes for a `sequential` model (the attribute conventions of
+    tests/golden/checkpoint.h5: matrices carry type / rows / cols as strings); libhdf5's h5dump accepts the file
+    (tests/test_host_logic.py)."""
+    from .hdf5_min import DatasetSpec, GroupSpec, write_file
+    names = {"relu": "RELU", "tanh": "TANH", "identity": "IDENTITY"}
+    lay = {}
+    for i, ((W, b), a) in enumerate(zip(layers, activations)):
+        W = np.ascontiguousarray(W, np.float32)
+        b = np.ascontiguousarray(b, np.float32).reshape(1, -1)
+        if W.ndim != 2 or b.shape[1] != W.shape[0]:
+            raise ValueError(f"layer {i}: weights {W.shape} and biases {b.shape} do not match")
+        lay[str(i)] = GroupSpec({"weights": GroupSpec({"parameters": DatasetSpec(W, _shape_attrs(W.shape, True))}),
+                                 "biases": GroupSpec({"parameters": DatasetSpec(b, _shape_attrs(b.shape, True))})},
+                                {"type": "dense", "activation_function": names[a]})
+    attrs = {"type": "sequential"}
+    if meta is not None:
+        attrs["meta"] = meta
+    write_file(path, GroupSpec({group: GroupSpec({"layers": GroupSpec(lay)}, attrs)}))
+
+
 def load_checkpoint(path):
     """Dispatch on the file type: HDF5 signature -> `load_checkpoint_h5`, otherwise the C++ export."""
     with open(path, "rb") as f:

@@ -218,6 +218,10 @@ struct rq_teacher_bank {
     float* images_f16x2 = nullptr;   // [n_teachers][teacher_image_regs_f16x2 * 64]
     uint32_t* tiles = nullptr;       // device: tile_teacher [cap] followed by tile_env [cap][16]
     uint32_t tile_capacity = 0;
+    // the generic dense stack (rq_teacher_bank_create_layers outside the register-stationary family): fp32, operands streamed
+    bool layers = false;
+    uint32_t n_hidden = 2, widths[3] = {0, 0, 0}, hp = 0;
+    float* images_layers = nullptr;  // [n_teachers][teacher_layers_image_floats(hp, n_hidden)]
 };
 
 namespace {
@@ -723,11 +727,14 @@ RQ_API int rq_device_last_rollout_clock(rq_device* dev, float* core_ghz) {
     const size_t waves = dev->k_span_used;
     std::vector<double> ghz;
     try { ghz.reserve(waves); } catch (...) { return fail(RQ_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    // a wave whose envs were all frozen left its loop at once (no auto-reset): a few cycles over one or two ticks of the
+    // 100 MHz counter is quantisation noise, not a clock - only waves that ran for >= 100 ticks (1 us) count
+    constexpr unsigned long long kMinTicks = 100;
     for (size_t w = 0; w < waves; ++w) {
         const unsigned long long t0 = span[4 * w + 2], t1 = span[4 * w + 3], cycles = span[4 * waves + w];
-        if (t1 > t0) ghz.push_back((double)cycles / ((double)(t1 - t0) / dev->k_ticks_per_ms * 1e6));   // cycles per ns
+        if (t1 >= t0 + kMinTicks) ghz.push_back((double)cycles / ((double)(t1 - t0) / dev->k_ticks_per_ms * 1e6));   // cycles per ns
     }
-    RQ_REQUIRE(!ghz.empty(), RQ_ERR_NOT_INITIALIZED, "the timed rollout took no step");
+    RQ_REQUIRE(!ghz.empty(), RQ_ERR_NOT_INITIALIZED, "no wave of the timed rollout stepped for a microsecond or longer");
     std::nth_element(ghz.begin(), ghz.begin() + ghz.size() / 2, ghz.end());
     *core_ghz = (float)ghz[ghz.size() / 2];
     return RQ_OK;
@@ -1371,7 +1378,10 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
                 return RQ_OK;
             }
         }
-        speculation_unused(dev);
+        // a speculated step of THIS policy that did not match (other rows, hidden state touched since) is spent; ANOTHER policy's
+        // stays available - it depends on that policy's version and the cached rows only (a loop evaluating a student and a teacher
+        // on the same rows used to throw the teacher's step away here, every iteration, until speculation was suspended for good)
+        if (dev->sp_policy == pol) { speculation_unused(dev); dev->sp_policy = nullptr; }
         if (dev->sp_suspended && dev->speculate && dev->last_policy == pol && dev->oc_env && batch == dev->oc_n &&
             mailbox_wait(dev, dev->oc_seq) == RQ_OK) {
             // suspended after a run of misses: this call is what a hit looks like (the rows the last step cached, handed
@@ -1382,7 +1392,6 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
                                    RQ_POLICY_INPUT_DIM * sizeof(float)) == 0;
             if (same) { dev->sp_suspended = false; dev->sp_misses = 0; }
         }
-        dev->sp_policy = nullptr;
         dev->last_policy = pol;         // the policy rq_step will speculate with
     }
     rc = policy_size(pol, batch); if (rc) return rc;
@@ -1817,9 +1826,60 @@ RQ_API int rq_teacher_bank_create(rq_device* dev, const float* weights, uint32_t
     return RQ_OK;
 }
 
+RQ_API int rq_teacher_bank_create_layers(rq_device* dev, const float* weights, uint32_t n_teachers, uint32_t in_dim, uint32_t n_hidden,
+                                  const uint32_t* widths, int hidden_activation, int output_activation, rq_teacher_bank** out) {
+    RQ_REQUIRE(dev && weights && widths && out, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    RQ_REQUIRE(n_hidden >= 1 && n_hidden <= 3, RQ_ERR_INVALID_ARGUMENT, "a teacher has one, two or three hidden layers");
+    auto fast_width = [](uint32_t h) { return h == 16 || h == 32 || h == 64; };
+    if (n_hidden == 2 && fast_width(widths[0]) && fast_width(widths[1]))      // the register-stationary family (three precisions)
+        return rq_teacher_bank_create(dev, weights, n_teachers, in_dim, widths[0], widths[1], hidden_activation, output_activation, out);
+    RQ_REQUIRE(n_teachers > 0, RQ_ERR_INVALID_ARGUMENT, "n_teachers must be positive");
+    RQ_REQUIRE(in_dim >= 1 && in_dim <= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT,
+               "in_dim must be 1..22 (the recorded policy inputs)");
+    uint32_t widest = 0;
+    for (uint32_t l = 0; l < n_hidden; ++l) {
+        RQ_REQUIRE(widths[l] >= 16 && widths[l] <= 128 && widths[l] % 16 == 0, RQ_ERR_INVALID_ARGUMENT,
+                   "hidden widths must be multiples of 16 from 16 to 128");
+        widest = widths[l] > widest ? widths[l] : widest;
+    }
+    RQ_REQUIRE(hidden_activation == RQ_ACT_RELU || hidden_activation == RQ_ACT_TANH, RQ_ERR_INVALID_ARGUMENT,
+               "hidden activation must be RQ_ACT_RELU or RQ_ACT_TANH");
+    RQ_REQUIRE(output_activation == RQ_ACT_IDENTITY || output_activation == RQ_ACT_TANH, RQ_ERR_INVALID_ARGUMENT,
+               "output activation must be RQ_ACT_IDENTITY or RQ_ACT_TANH");
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
+    rq_teacher_bank* b = new (std::nothrow) rq_teacher_bank();
+    RQ_REQUIRE(b, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    b->dev = dev; b->ordinal = dev->ordinal; b->n_teachers = n_teachers; b->in_dim = in_dim;
+    b->act = hidden_activation; b->out_act = output_activation;
+    b->layers = true; b->n_hidden = n_hidden; b->hp = widest <= 64 ? 64u : 128u;
+    for (uint32_t l = 0; l < n_hidden; ++l) b->widths[l] = widths[l];
+    b->h1 = widths[0]; b->h2 = n_hidden > 1 ? widths[1] : 0;
+    const size_t per = rq::teacher_layers_param_count((int)in_dim, (int)n_hidden, widths);
+    const size_t floats = rq::teacher_layers_image_floats((int)b->hp, (int)n_hidden);
+    std::vector<float> img;
+    try {                                   // nothing throws across the boundary
+        img.resize(floats * n_teachers);
+    } catch (const std::bad_alloc&) {
+        delete b;
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_teacher_bank_create_layers: host allocation failed");
+    }
+    for (uint32_t t = 0; t < n_teachers; ++t)
+        rq::pack_teacher_layers(weights + per * t, (int)in_dim, (int)n_hidden, widths, (int)b->hp, b->act, b->out_act, img.data() + floats * t);
+    hipError_t e = hipMalloc(&b->images_layers, img.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(b->images_layers, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rq_teacher_bank_destroy(b);
+        return fail(RQ_ERR_OUT_OF_MEMORY, "rq_teacher_bank_create_layers: device allocation or upload failed");
+    }
+    *out = b;
+    return RQ_OK;
+}
+
 RQ_API int rq_teacher_bank_destroy(rq_teacher_bank* bank) {
     if (!bank) return RQ_OK;
     DeviceScope on_device(bank->ordinal);
+    if (bank->images_layers) (void)hipFree(bank->images_layers);
     if (bank->images_f32) (void)hipFree(bank->images_f32);
     if (bank->images_bf16) (void)hipFree(bank->images_bf16);
     if (bank->images_f16x2) (void)hipFree(bank->images_f16x2);
@@ -1832,6 +1892,8 @@ RQ_API int rq_teacher_bank_set_precision(rq_teacher_bank* bank, int precision) {
     RQ_REQUIRE(bank, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(precision == RQ_POLICY_FP32 || precision == RQ_POLICY_BF16_MFMA || precision == RQ_POLICY_F16X2_MFMA,
                RQ_ERR_INVALID_ARGUMENT, "unknown precision");
+    RQ_REQUIRE(!bank->layers || precision == RQ_POLICY_FP32, RQ_ERR_INVALID_ARGUMENT,
+               "a bank outside the two-hidden-layer {16, 32, 64} family is evaluated in fp32 only");
     bank->precision = precision;
     return RQ_OK;
 }
@@ -1885,6 +1947,10 @@ RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* ban
     }
     const float* images = bank->precision == RQ_POLICY_BF16_MFMA ? bank->images_bf16
                         : bank->precision == RQ_POLICY_F16X2_MFMA ? bank->images_f16x2 : bank->images_f32;
+    if (bank->layers)
+        RQ_HIP(rq::launch_teacher_relabel_layers(dev->stream, n_tiles, env->ld, t->length, bank->in_dim, bank->n_hidden, bank->hp, bank->act,
+                                                 bank->out_act, bank->images_layers, bank->tiles, bank->tiles + n_tiles, t->obs, d_act));
+    else
     RQ_HIP(rq::launch_teacher_relabel(dev->stream, n_tiles, env->ld, t->length, bank->in_dim, bank->h1, bank->h2, bank->act,
                                       bank->out_act, bank->precision, images, bank->tiles, bank->tiles + n_tiles, t->obs,
                                       d_act));

@@ -260,6 +260,59 @@ static void pack_teacher_16(const float* w, int in_dim, int h1, int h2, int act,
     }
 }
 
+// the generic dense stack's streamed image (layout: rq_teacher.hip k_teacher_relabel_layers)
+void pack_teacher_layers(const float* w, int in_dim, int n_hidden, const uint32_t* widths, int hp, int act, int out_act, float* image) {
+    const int M = hp / 16, K = hp / 4, G = M / 4;
+    const size_t total = teacher_layers_image_floats(hp, n_hidden);
+    for (size_t i = 0; i < total; ++i) image[i] = 0.0f;
+    const float kT = -2.8853900817779268f;
+    const float kh = act == RQ_ACT_TANH ? kT : 1.0f, ko = out_act == RQ_ACT_TANH ? kT : 1.0f;
+    // layer views
+    const float* W[4]; const float* b[4]; int rows[4], cols[4];
+    {
+        const float* p = w;
+        int prev = in_dim;
+        for (int l = 0; l < n_hidden; ++l) {
+            W[l] = p; rows[l] = (int)widths[l]; cols[l] = prev; p += (size_t)rows[l] * prev;
+            b[l] = p; p += rows[l]; prev = rows[l];
+        }
+        W[n_hidden] = p; rows[n_hidden] = 4; cols[n_hidden] = prev; p += (size_t)4 * prev; b[n_hidden] = p;
+    }
+    for (int l = 0; l < 64; ++l) {
+        const int q = l >> 4, i = l & 15;
+        // layer 1: [s][g][lane][u], row 16 (4 g + u) + i, feature 4 s + q; feature in_dim carries the bias
+        for (int s = 0; s < 6; ++s)
+            for (int g = 0; g < G; ++g)
+                for (int u = 0; u < 4; ++u) {
+                    const int row = 16 * (4 * g + u) + i, f = 4 * s + q;
+                    float v = 0.0f;
+                    if (row < rows[0]) v = kh * (f < in_dim ? W[0][(size_t)row * in_dim + f] : (f == in_dim ? b[0][row] : 0.0f));
+                    image[((size_t)(s * G + g) * 64 + l) * 4 + u] = v;
+                }
+        float* p = image + (size_t)6 * M * 64;
+        for (int layer = 1; layer < n_hidden; ++layer) {
+            for (int k = 0; k < K; ++k)
+                for (int g = 0; g < G; ++g)
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = 16 * (4 * g + u) + i, col = 16 * (k / 4) + 4 * q + (k % 4);
+                        p[((size_t)(k * G + g) * 64 + l) * 4 + u] = (row < rows[layer] && col < cols[layer]) ? kh * W[layer][(size_t)row * cols[layer] + col] : 0.0f;
+                    }
+            float* pb = p + (size_t)K * M * 64;
+            for (int m = 0; m < M; ++m)
+                for (int r = 0; r < 4; ++r) {
+                    const int unit = 16 * m + 4 * q + r;
+                    pb[(size_t)(m * 4 + r) * 64 + l] = unit < rows[layer] ? kh * b[layer][unit] : 0.0f;
+                }
+            p += (size_t)K * M * 64 + (size_t)M * 4 * 64;
+        }
+        for (int k = 0; k < K; ++k) {
+            const int col = 16 * (k / 4) + 4 * q + (k % 4);
+            p[(size_t)k * 64 + l] = (i < 4 && col < cols[n_hidden]) ? ko * W[n_hidden][(size_t)i * cols[n_hidden] + col] : 0.0f;
+        }
+        for (int r = 0; r < 4; ++r) p[(size_t)(K + r) * 64 + l] = q == 0 ? ko * b[n_hidden][r] : 0.0f;
+    }
+}
+
 void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image) {
     pack_teacher_16(w, in_dim, h1, h2, act, out_act, false, image);
 }

@@ -400,6 +400,115 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, ui
     }
 }
 
+// ---- any stack of dense layers (round 5): in -> w1 -> [w2 -> [w3]] -> 4, widths multiples of 16 up to 128 --------------------
+// What a teacher checkpoint in the reference's HDF5 layout may hold (`sequential` of `dense` layers, README.md:211-216) beyond the
+// register-stationary family above: one or three hidden layers, widths up to 128.  Such a teacher's operands do not fit a wave's
+// registers (22-128-128-128-4: 146 KB), so they are STREAMED: every hidden layer is padded to HP = 64 or 128 units (zero rows and
+// columns: exact), the image holds the A operands in the order the loop consumes them - four row tiles of one K-step per lane as one
+// 16-byte load - and stays in L2 for the tile's slice of the trajectory.  Same tile / step-slice mapping, same layouts and the same
+// exact-f32 MFMA as k_teacher_relabel_f32; fp32 only.  Image (floats, per teacher; M = HP / 16, K = HP / 4):
+//   layer 1      [6][M / 4][64 lanes][4]   A(row 16 m + i, feature 4 s + q), feature in_dim = the bias (B operand 1)
+//   per further hidden layer: [K][M / 4][64][4] A(row 16 m + i, unit 16 (k / 4) + 4 q + k % 4), then [M][4][64] the bias quads
+//   output       [K][64] (rows >= 4 zero), then [4][64] its bias quad (lane group 0 only)
+template <int HP, int ACT, int OUT_ACT>
+__global__ __launch_bounds__(64, 2) void k_teacher_relabel_layers(uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
+                                                                  uint32_t image_floats, const float* __restrict__ images,
+                                                                  const uint32_t* __restrict__ tile_teacher,
+                                                                  const uint32_t* __restrict__ tile_env,
+                                                                  const float* __restrict__ obs, float* __restrict__ act) {
+    constexpr int M = HP / 16, K = HP / 4, G = M / 4;
+    typedef float f32q __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t per = (steps + gridDim.y - 1) / gridDim.y;
+    const uint32_t t_begin = blockIdx.y * per, t_end = t_begin + per < steps ? t_begin + per : steps;
+    if (t_begin >= t_end) return;                       // wave-uniform
+    const float* img = images + (size_t)tile_teacher[tile] * image_floats;
+    const uint32_t e0 = tile_env[tile * 16 + j];
+    const bool valid = e0 != 0xFFFFFFFFu;
+    const uint32_t e = valid ? e0 : 0u;
+    const InputPlan in(ld, e, q, in_dim);
+    float X[6];
+    in.load(obs, t_begin, X);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        float Xn[6];
+        in.load(obs, t + 1 < t_end ? t + 1 : t, Xn);
+        in.finish(X);
+        f32x4 y[M];
+        {
+            const f32q* a1 = reinterpret_cast<const f32q*>(img) + lane;
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const f32q a = a1[(s * G + g) * 64];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        y[4 * g + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], X[s], s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : y[4 * g + u], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[m][r] = teacher_act<ACT>(y[m][r]);
+        const float* p = img + 6 * M * 64;
+        for (uint32_t layer = 1; layer < n_hidden; ++layer) {          // wave-uniform trip count
+            f32x4 z[M];
+            const float* pb = p + K * M * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[m][r] = pb[(m * 4 + r) * 64];
+            const f32q* a = reinterpret_cast<const f32q*>(p) + lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const f32q w = a[(k * G + g) * 64];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) z[4 * g + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], y[k / 4][k % 4], z[4 * g + u], 0, 0, 0);
+                }
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[m][r] = teacher_act<ACT>(z[m][r]);
+            p += K * M * 64 + M * 4 * 64;
+        }
+        const float* po = p + lane;
+        f32x4 o = {po[(K + 0) * 64], po[(K + 1) * 64], po[(K + 2) * 64], po[(K + 3) * 64]};
+#pragma unroll
+        for (int k = 0; k < K; ++k) o = __builtin_amdgcn_mfma_f32_16x16x4f32(po[k * 64], y[k / 4][k % 4], o, 0, 0, 0);
+        if (valid && q == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[r]);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) X[s] = Xn[s];
+    }
+}
+
+hipError_t launch_teacher_relabel_layers(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
+                                         uint32_t hp, int act, int out_act, const float* images, const uint32_t* tile_teacher,
+                                         const uint32_t* tile_env, const float* obs, float* actions) {
+    if (n_tiles == 0 || steps == 0) return hipSuccess;
+    if ((hp != 64 && hp != 128) || n_hidden < 1 || n_hidden > 3) return hipErrorInvalidValue;
+    uint32_t slices = (16384u + n_tiles - 1) / n_tiles;          // as launch_hh: >= 8 rounds of waves, slices of >= 64 steps
+    if (slices > steps / 64u) slices = steps / 64u;
+    if (slices < 1u) slices = 1u;
+    const dim3 grid(n_tiles, slices);
+    const uint32_t image_floats = (uint32_t)teacher_layers_image_floats((int)hp, (int)n_hidden);
+#define RQ_TL(HP, A, O) k_teacher_relabel_layers<HP, A, O><<<grid, 64, 0, s>>>(ld, steps, in_dim, n_hidden, image_floats, images, tile_teacher, tile_env, obs, actions)
+#define RQ_TL_ACT(HP)                                                                                           \
+    do {                                                                                                        \
+        if (act == RQ_ACT_RELU) { if (out_act == RQ_ACT_TANH) RQ_TL(HP, RQ_ACT_RELU, RQ_ACT_TANH); else RQ_TL(HP, RQ_ACT_RELU, RQ_ACT_IDENTITY); } \
+        else                    { if (out_act == RQ_ACT_TANH) RQ_TL(HP, RQ_ACT_TANH, RQ_ACT_TANH); else RQ_TL(HP, RQ_ACT_TANH, RQ_ACT_IDENTITY); } \
+    } while (0)
+    if (hp == 64) RQ_TL_ACT(64); else RQ_TL_ACT(128);
+#undef RQ_TL_ACT
+#undef RQ_TL
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- launcher ---
 template <int H1, int H2>
 static hipError_t launch_hh(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim, int act,

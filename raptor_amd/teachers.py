@@ -4,8 +4,10 @@ The distillation step of rl-tools/raptor (/root/reference/README.md:208-216) lab
 visits with the action of the teacher that was trained for that quadrotor - about 1000 MLP teachers, one per
 sampled dynamics.  ``TeacherBank`` holds such a set on the device and ``Trajectory.relabel_teachers`` evaluates
 teacher ``teacher_ids[i]`` on every recorded step of env ``i``.  The teachers'
-architecture is not in the reference tree: this is the plain MLP family input -> h1 -> h2 -> 4
-[UPSTREAM-UNVERIFIED], h1, h2 in {16, 32, 64}.
+architecture is not in the reference tree [UPSTREAM-UNVERIFIED]: what is supported is any stack of dense layers
+input -> w1 [-> w2 [-> w3]] -> 4 with widths that are multiples of 16 up to 128 - two hidden layers of 16 / 32 / 64 units
+take register-stationary kernels in three precisions, everything else a streaming fp32 kernel - and
+``TeacherBank.from_checkpoints`` loads such teachers from files in the reference's HDF5 layout (``h5:/actor/layers/*``).
 """
 import ctypes as C
 import weakref
@@ -29,7 +31,75 @@ def flatten_teacher(W1, b1, W2, b2, W3, b3):
     return np.concatenate(parts)
 
 
+def layers_parameter_count(in_dim, widths):
+    """floats per teacher of the stack in_dim -> widths[0] -> ... -> 4: [W1 | b1 | ... | W_out | b_out]"""
+    n, prev = 0, int(in_dim)
+    for h in list(widths) + [4]:
+        n += int(h) * prev + int(h)
+        prev = int(h)
+    return n
+
+
 class TeacherBank:
+    @classmethod
+    def from_layers(cls, device, weights, in_dim, widths, hidden_activation="relu", output_activation="identity", precision="fp32"):
+        """Teachers of the stack in_dim -> widths[0] -> ... -> widths[-1] -> 4 (1 to 3 hidden layers, widths multiples of 16 up
+        to 128); ``weights`` [n_teachers, layers_parameter_count(in_dim, widths)].  Two hidden layers of 16 / 32 / 64 units are the
+        fast family (``TeacherBank(...)``, three precisions); anything else is evaluated in fp32 by the streaming kernel."""
+        widths = [int(h) for h in widths]
+        if len(widths) == 2 and all(h in (16, 32, 64) for h in widths):
+            return cls(device, weights, in_dim, widths[0], widths[1], hidden_activation, output_activation, precision)
+        if not 1 <= len(widths) <= 3 or any(h % 16 or not 16 <= h <= 128 for h in widths):
+            raise ValueError(f"unsupported teacher topology {in_dim}-{'-'.join(map(str, widths))}-4: one to three hidden layers, "
+                             "widths multiples of 16 from 16 to 128")
+        w = np.ascontiguousarray(weights, np.float32)
+        per = layers_parameter_count(in_dim, widths)
+        if w.ndim != 2 or w.shape[1] != per:
+            raise ValueError(f"weights must be [n_teachers, {per}] for {in_dim}-{'-'.join(map(str, widths))}-4")
+        self = cls.__new__(cls)
+        self.n_teachers, self.in_dim, self.widths = int(w.shape[0]), int(in_dim), widths
+        self.h1, self.h2 = widths[0], widths[1] if len(widths) > 1 else 0
+        self.hidden_activation, self.output_activation = hidden_activation, output_activation
+        self._device = device
+        wd = np.asarray(widths, np.uint32)
+        h = C.c_void_p()
+        _lib.call("rq_teacher_bank_create_layers", device._h, _lib.fptr(w), self.n_teachers, self.in_dim, len(widths),
+                  wd.ctypes.data_as(C.POINTER(C.c_uint32)), ACTIVATIONS[hidden_activation], ACTIVATIONS[output_activation], C.byref(h))
+        self._h = h
+        self._fin = weakref.finalize(self, _lib.load().rq_teacher_bank_destroy, h)
+        self.set_precision(precision)
+        return self
+
+    @classmethod
+    def from_checkpoints(cls, device, paths, in_dim=None, precision="fp32", group="actor"):
+        """One teacher per file, each a `sequential` of `dense` layers in the reference's HDF5 layout (what
+        ``extract_checkpoints.sh`` gathers, README.md:211-216; ``raptor_amd.checkpoint.load_mlp_checkpoint_h5``).  All files must
+        describe the same topology: 1 to 3 hidden layers with one activation, 4 outputs; the first ``in_dim`` recorded observation
+        features are the input (default: the first layer's input width, at most 22).  -> TeacherBank, teacher k = paths[k]."""
+        from .checkpoint import load_mlp_checkpoint_h5
+        paths = list(paths)
+        if not paths:
+            raise ValueError("no checkpoint files")
+        blocks, topo = [], None
+        for path in paths:
+            layers, acts = load_mlp_checkpoint_h5(path, group)
+            shape = ([lay[0].shape for lay in layers], acts)
+            if topo is None:
+                topo = shape
+                if len(layers) < 2 or layers[-1][0].shape[0] != 4:
+                    raise ValueError(f"{path}: a teacher ends in a dense layer with 4 outputs (found {shape[0]})")
+                if len(set(acts[:-1])) != 1:
+                    raise ValueError(f"{path}: the hidden layers use different activations {acts[:-1]}")
+            elif shape != topo:
+                raise ValueError(f"{path}: topology {shape} differs from the first file's {topo}")
+            blocks.append(np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for W, b in layers]))
+        first_in = topo[0][0][1]
+        in_dim = first_in if in_dim is None else int(in_dim)
+        if in_dim != first_in or in_dim > 22:
+            raise ValueError(f"the teachers read {first_in} inputs; the recorded observation offers its first {min(in_dim, 22)}")
+        widths = [sh[0] for sh in topo[0][:-1]]
+        return cls.from_layers(device, np.stack(blocks).astype(np.float32), in_dim, widths, topo[1][0], topo[1][-1], precision)
+
     def __init__(self, device, weights, in_dim=22, h1=64, h2=64, hidden_activation="relu",
                  output_activation="identity", precision="fp32"):
         w = np.ascontiguousarray(weights, np.float32)
@@ -37,6 +107,7 @@ class TeacherBank:
         if w.ndim != 2 or w.shape[1] != per:
             raise ValueError(f"weights must be [n_teachers, {per}] for {in_dim}-{h1}-{h2}-4")
         self.n_teachers, self.in_dim, self.h1, self.h2 = int(w.shape[0]), int(in_dim), int(h1), int(h2)
+        self.widths = [int(h1), int(h2)]
         self.hidden_activation, self.output_activation = hidden_activation, output_activation
         self._device = device
         h = C.c_void_p()

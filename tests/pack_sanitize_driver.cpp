@@ -19,6 +19,16 @@ int main(int argc, char** argv) {
         rq::pack_teacher_f16x2(tw.data(), in, h1, h2, 1, 2, isp.data());
         s += i32[5] + i16[7] + isp[9];
     }
+    // the generic dense stack's streamed images (round 5): one, two and three hidden layers, both paddings, ragged widths
+    for (int nh : {1, 2, 3}) for (int wmax : {48, 128}) for (int in : {7, 22}) {
+        uint32_t widths[3] = {(uint32_t)wmax, 16u, (uint32_t)(wmax > 64 ? 112 : 32)};
+        const int hp = wmax <= 64 ? 64 : 128;
+        const size_t per = rq::teacher_layers_param_count(in, nh, widths);
+        std::vector<float> tw(per); for (size_t i = 0; i < per; ++i) tw[i] = 0.002f * (float)(i % 89) - 0.05f;
+        std::vector<float> img(rq::teacher_layers_image_floats(hp, nh));
+        rq::pack_teacher_layers(tw.data(), in, nh, widths, hp, nh == 2 ? 2 : 1, nh == 3 ? 2 : 0, img.data());
+        s += img[3] + img[img.size() - 1];
+    }
     printf("pack under sanitizers ok %.3f %.3f\n", a[100] + b[100] + c[100], s);
     return 0;
 }

@@ -190,6 +190,60 @@ def test_oracle_teacher_mlp_matches_numpy(oracle):
             assert np.abs(got[:, i] - ref).max() < 2e-5
 
 
+def test_oracle_dense_stack_matches_numpy(oracle):
+    """The oracle's generic dense stack (round 5: one to three hidden layers, widths up to 128 - the checker of
+    k_teacher_relabel_layers) against a float64 numpy evaluation, and against the two-hidden-layer restatement bit for bit."""
+    rng = np.random.default_rng(6)
+    obs = rng.standard_normal((3, 24, 22)).astype(np.float32)
+    for in_dim, widths, act, out_act, f, g in ((22, [128, 48, 112], 2, 2, np.tanh, np.tanh), (17, [96], 1, 0, lambda x: np.maximum(x, 0), lambda x: x),
+                                               (22, [64, 32], 1, 2, lambda x: np.maximum(x, 0), np.tanh)):
+        dims = [in_dim] + widths + [4]
+        per = sum(dims[i + 1] * dims[i] + dims[i + 1] for i in range(len(dims) - 1))
+        W = (rng.standard_normal((4, per)) * 0.25).astype(np.float32)
+        ids = rng.integers(0, 4, 24).astype(np.uint32)
+        got = oracle.mlp_relabel(W, in_dim, widths, act, out_act, obs, ids)
+        for i in range(24):
+            w, o = W[ids[i]].astype(np.float64), 0
+            x = obs[:, i, :in_dim].astype(np.float64)
+            for l in range(len(dims) - 1):
+                M = w[o:o + dims[l + 1] * dims[l]].reshape(dims[l + 1], dims[l]); o += M.size
+                b = w[o:o + dims[l + 1]]; o += dims[l + 1]
+                x = (f if l < len(widths) else g)(x @ M.T + b)
+            assert np.abs(got[:, i] - x).max() < 3e-5
+        if len(widths) == 2:
+            assert np.array_equal(got, oracle.teacher_relabel(W, in_dim, widths[0], widths[1], act, out_act, obs, ids))
+
+
+def test_teacher_checkpoints_in_the_references_hdf5_layout(tmp_path):
+    """A teacher = a `sequential` of `dense` layers in the layout of h5:/actor/layers/* (what the reference's
+    extract_checkpoints.sh gathers, README.md:211-216): written by this package's dependency-free writer, read back bit for bit,
+    accepted by libhdf5's h5dump (the same attribute conventions as the reference's own checkpoint.h5) - and the reference's
+    student checkpoint, which holds a GRU, is refused with the reason."""
+    import subprocess
+    from raptor_amd.checkpoint import load_mlp_checkpoint_h5, write_mlp_checkpoint_h5
+    rng = np.random.default_rng(9)
+    dims = [22, 128, 64, 128, 4]
+    layers = [((rng.standard_normal((dims[i + 1], dims[i])) * 0.2).astype(np.float32), rng.standard_normal(dims[i + 1]).astype(np.float32))
+              for i in range(4)]
+    path = str(tmp_path / "teacher_0.h5")
+    write_mlp_checkpoint_h5(path, layers, ["relu", "relu", "relu", "identity"], meta='{"teacher": 0}')
+    got, acts = load_mlp_checkpoint_h5(path)
+    assert acts == ["relu", "relu", "relu", "identity"] and len(got) == 4
+    for (W, b), (W0, b0) in zip(got, layers):
+        assert np.array_equal(W, W0) and np.array_equal(b, b0)
+    h5dump = _hdf5_tool("h5dump")
+    if h5dump:
+        raw = str(tmp_path / "w2.bin")
+        subprocess.run([h5dump, "-d", "/actor/layers/2/weights/parameters", "-b", "LE", "-o", raw, path], check=True, stdout=subprocess.DEVNULL)
+        assert np.array_equal(np.fromfile(raw, "<f4").reshape(128, 64), layers[2][0])
+        head = subprocess.run([h5dump, "-A", path], capture_output=True, text=True, check=True).stdout
+        assert '"dense"' in head and '"RELU"' in head and '"sequential"' in head
+    with pytest.raises(ValueError, match="gru"):
+        load_mlp_checkpoint_h5(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint.h5"))
+    with pytest.raises(ValueError):
+        write_mlp_checkpoint_h5(path, [(np.zeros((4, 3), np.float32), np.zeros(5, np.float32))], ["identity"])
+
+
 def test_operand_packers_under_sanitizers(tmp_path):
     """The host code that builds every operand image the kernels keep in registers (raptor_amd/csrc/rq_pack.cpp: the
     f32, bf16 and split-f16 policy images, the log-std head, the three teacher images for all nine hidden-width pairs

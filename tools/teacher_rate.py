@@ -56,4 +56,24 @@ for prec, peak in (("fp32", 157.3), ("bf16", 2500.0), ("f16x2", 2500.0)):    # f
     out[prec] = {"ms": round(best * 1e3, 3), "wall_ms_incl_host_grouping": round(wall_ms, 3), "labels_per_s": round(args.envs * args.steps / best, 1),
                  "TFLOPs": round(flop / best / 1e12, 2), "peak_TFLOPs": peak, "frac_of_mfma_peak": round(flop / best / 1e12 / peak, 4),
                  "obs_GBps": round(args.envs * args.steps * (88 + 16) / best / 1e9, 1)}
+# the streaming kernel for stacks outside the register-stationary family (round 5): fp32 only
+from raptor_amd.teachers import layers_parameter_count          # noqa: E402
+for widths in ([128, 128, 128], [128, 128], [64, 64, 64], [128]):
+    Wl = (rng.standard_normal((args.teachers, layers_parameter_count(22, widths))) * 0.05).astype(np.float32)
+    bank = TeacherBank.from_layers(device, Wl, 22, widths, "relu", "identity")
+    dims = [22] + widths + [4]
+    fl = 2 * sum(dims[i + 1] * dims[i] for i in range(len(dims) - 1))
+    for _ in range(2):
+        tr.relabel_teachers(bank, ids, fetch=False)
+    device.synchronize()
+    best = 1e9
+    for _ in range(4):
+        device.timer_start()
+        tr.relabel_teachers(bank, ids, fetch=False)
+        best = min(best, device.timer_stop() * 1e-3)
+    tf = fl * args.envs * args.steps / best / 1e12
+    out["layers_22-" + "-".join(map(str, widths)) + "-4"] = {"ms": round(best * 1e3, 3), "labels_per_s": round(args.envs * args.steps / best, 1),
+                                                            "flop_per_label": fl, "TFLOPs": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / 157.3, 4)
+                                                            }
+    del bank
 print(json.dumps(out))
