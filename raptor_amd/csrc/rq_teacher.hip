@@ -410,80 +410,118 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, ui
 //   layer 1      [6][M / 4][64 lanes][4]   A(row 16 m + i, feature 4 s + q), feature in_dim = the bias (B operand 1)
 //   per further hidden layer: [K][M / 4][64][4] A(row 16 m + i, unit 16 (k / 4) + 4 q + k % 4), then [M][4][64] the bias quads
 //   output       [K][64] (rows >= 4 zero), then [4][64] its bias quad (lane group 0 only)
+// Round 5, second version.  The first streamed every operand from L2 per wave and step (22-128-128-128-4: 146 KB per tile-step, four
+// step-slices of a tile each on their own: 0.33 of the f32 MFMA peak, L2-bound).  Now a WORKGROUP of four waves owns a tile - wave w
+// labels step-slice w of it - and shares the teacher's operands through LDS: a layer's image (HP = 128: 64 KB + 8 KB of bias quads) is
+// copied in once per workgroup and PAIR of steps, read back as 16-byte quads (a lane's four row tiles of one K-step), and every A operand
+// feeds two MFMAs (the wave's two steps in flight): a quarter of the L2 traffic per wave for sharing, half again for pairing.  Two
+// workgroups per CU (2 x 72 KB of LDS): one computes while the other copies.
 template <int HP, int ACT, int OUT_ACT>
-__global__ __launch_bounds__(64, 2) void k_teacher_relabel_layers(uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
-                                                                  uint32_t image_floats, const float* __restrict__ images,
-                                                                  const uint32_t* __restrict__ tile_teacher,
-                                                                  const uint32_t* __restrict__ tile_env,
-                                                                  const float* __restrict__ obs, float* __restrict__ act) {
+__global__ __launch_bounds__(256, 2) void k_teacher_relabel_layers(uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
+                                                                   uint32_t image_floats, const float* __restrict__ images,
+                                                                   const uint32_t* __restrict__ tile_teacher,
+                                                                   const uint32_t* __restrict__ tile_env,
+                                                                   const float* __restrict__ obs, float* __restrict__ act) {
     constexpr int M = HP / 16, K = HP / 4, G = M / 4;
+    constexpr int kLayerFloats = K * M * 64 + M * 4 * 64;          // the largest piece staged at once: a hidden layer + its bias quads
     typedef float f32q __attribute__((ext_vector_type(4)));
-    const uint32_t lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    __shared__ f32q stage[kLayerFloats / 4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
     const uint32_t tile = blockIdx.x;
-    const uint32_t per = (steps + gridDim.y - 1) / gridDim.y;
-    const uint32_t t_begin = blockIdx.y * per, t_end = t_begin + per < steps ? t_begin + per : steps;
-    if (t_begin >= t_end) return;                       // wave-uniform
+    const uint32_t slices = gridDim.y * 4u;
+    const uint32_t per = (steps + slices - 1) / slices;                 // steps per wave: the same trip count for the four waves
+    const uint32_t t_begin = (blockIdx.y * 4u + wave) * per;
+    const uint32_t t_end = t_begin + per < steps ? t_begin + per : steps;          // may be <= t_begin: that wave only helps copying
     const float* img = images + (size_t)tile_teacher[tile] * image_floats;
     const uint32_t e0 = tile_env[tile * 16 + j];
     const bool valid = e0 != 0xFFFFFFFFu;
     const uint32_t e = valid ? e0 : 0u;
     const InputPlan in(ld, e, q, in_dim);
-    float X[6];
-    in.load(obs, t_begin, X);
-    for (uint32_t t = t_begin; t < t_end; ++t) {
-        float Xn[6];
-        in.load(obs, t + 1 < t_end ? t + 1 : t, Xn);
-        in.finish(X);
-        f32x4 y[M];
-        {
-            const f32q* a1 = reinterpret_cast<const f32q*>(img) + lane;
+    auto copy_in = [&](const float* src, int floats) {                  // every thread of the workgroup: 16 bytes per turn
+        const f32q* s4 = reinterpret_cast<const f32q*>(src);
+        for (int i = threadIdx.x; i < floats / 4; i += 256) stage[i] = s4[i];
+    };
+    auto clamp_t = [&](uint32_t t) { return t < steps ? t : steps - 1; };
+    for (uint32_t it = 0; it < per; it += 2) {                          // workgroup-uniform
+        const uint32_t t0 = t_begin + it, t1 = t0 + 1;
+        float X[2][6];
+        in.load(obs, clamp_t(t0), X[0]);
+        in.load(obs, clamp_t(t1), X[1]);
+        __syncthreads();                                                // the previous pair is done with the staging buffer
+        copy_in(img, 6 * M * 64);
+        in.finish(X[0]);
+        in.finish(X[1]);
+        __syncthreads();
+        f32x4 y[2][M];
 #pragma unroll
-            for (int s = 0; s < 6; ++s)
+        for (int s = 0; s < 6; ++s)
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const f32q a = a1[(s * G + g) * 64];
+            for (int g = 0; g < G; ++g) {
+                const f32q a = stage[(s * G + g) * 64 + lane];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        y[4 * g + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], X[s], s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : y[4 * g + u], 0, 0, 0);
-                }
-        }
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int m = 0; m < M; ++m)
+                    for (int p = 0; p < 2; ++p)
+                        y[p][4 * g + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], X[p][s], s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : y[p][4 * g + u], 0, 0, 0);
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[m][r] = teacher_act<ACT>(y[m][r]);
-        const float* p = img + 6 * M * 64;
-        for (uint32_t layer = 1; layer < n_hidden; ++layer) {          // wave-uniform trip count
-            f32x4 z[M];
-            const float* pb = p + K * M * 64 + lane;
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[m][r] = pb[(m * 4 + r) * 64];
-            const f32q* a = reinterpret_cast<const f32q*>(p) + lane;
+                for (int r = 0; r < 4; ++r) y[p][m][r] = teacher_act<ACT>(y[p][m][r]);
+        const float* src = img + 6 * M * 64;
+        for (uint32_t layer = 1; layer < n_hidden; ++layer) {          // workgroup-uniform trip count
+            __syncthreads();
+            copy_in(src, kLayerFloats);
+            __syncthreads();
+            f32x4 z[2][M];
+            const float* pb = reinterpret_cast<const float*>(stage) + K * M * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[0][m][r] = z[1][m][r] = pb[(m * 4 + r) * 64];
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const f32q w = a[(k * G + g) * 64];
+                    const f32q w = stage[(k * G + g) * 64 + lane];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) z[4 * g + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], y[k / 4][k % 4], z[4 * g + u], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            z[p][4 * g + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], y[p][k / 4][k % 4], z[p][4 * g + u], 0, 0, 0);
                 }
 #pragma unroll
-            for (int m = 0; m < M; ++m)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[m][r] = teacher_act<ACT>(z[m][r]);
-            p += K * M * 64 + M * 4 * 64;
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[p][m][r] = teacher_act<ACT>(z[p][m][r]);
+            src += kLayerFloats;
         }
-        const float* po = p + lane;
-        f32x4 o = {po[(K + 0) * 64], po[(K + 1) * 64], po[(K + 2) * 64], po[(K + 3) * 64]};
+        __syncthreads();
+        copy_in(src, K * 64 + 4 * 64);
+        __syncthreads();
+        const float* po = reinterpret_cast<const float*>(stage) + lane;
+        f32x4 o[2];
+        o[0] = o[1] = f32x4{po[(K + 0) * 64], po[(K + 1) * 64], po[(K + 2) * 64], po[(K + 3) * 64]};
 #pragma unroll
-        for (int k = 0; k < K; ++k) o = __builtin_amdgcn_mfma_f32_16x16x4f32(po[k * 64], y[k / 4][k % 4], o, 0, 0, 0);
+        for (int k = 0; k < K; ++k) {
+            const float w = po[k * 64];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) o[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, y[p][k / 4][k % 4], o[p], 0, 0, 0);
+        }
         if (valid && q == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[r]);
-        }
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t t = t0 + p;
+                if (t < t_end) {
 #pragma unroll
-        for (int s = 0; s < 6; ++s) X[s] = Xn[s];
+                    for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[p][r]);
+                }
+            }
+        }
     }
 }
 
@@ -492,12 +530,13 @@ hipError_t launch_teacher_relabel_layers(hipStream_t s, uint32_t n_tiles, uint32
                                          const uint32_t* tile_env, const float* obs, float* actions) {
     if (n_tiles == 0 || steps == 0) return hipSuccess;
     if ((hp != 64 && hp != 128) || n_hidden < 1 || n_hidden > 3) return hipErrorInvalidValue;
-    uint32_t slices = (16384u + n_tiles - 1) / n_tiles;          // as launch_hh: >= 8 rounds of waves, slices of >= 64 steps
-    if (slices > steps / 64u) slices = steps / 64u;
-    if (slices < 1u) slices = 1u;
-    const dim3 grid(n_tiles, slices);
+    // a workgroup = four step-slices of one tile; enough workgroups for >= 4 rounds over the chip's 512 resident ones, slices of >= 32 steps
+    uint32_t groups = (2048u + n_tiles - 1) / n_tiles;
+    if (groups > steps / 128u) groups = steps / 128u;
+    if (groups < 1u) groups = 1u;
+    const dim3 grid(n_tiles, groups);
     const uint32_t image_floats = (uint32_t)teacher_layers_image_floats((int)hp, (int)n_hidden);
-#define RQ_TL(HP, A, O) k_teacher_relabel_layers<HP, A, O><<<grid, 64, 0, s>>>(ld, steps, in_dim, n_hidden, image_floats, images, tile_teacher, tile_env, obs, actions)
+#define RQ_TL(HP, A, O) k_teacher_relabel_layers<HP, A, O><<<grid, 256, 0, s>>>(ld, steps, in_dim, n_hidden, image_floats, images, tile_teacher, tile_env, obs, actions)
 #define RQ_TL_ACT(HP)                                                                                           \
     do {                                                                                                        \
         if (act == RQ_ACT_RELU) { if (out_act == RQ_ACT_TANH) RQ_TL(HP, RQ_ACT_RELU, RQ_ACT_TANH); else RQ_TL(HP, RQ_ACT_RELU, RQ_ACT_IDENTITY); } \
