@@ -191,10 +191,9 @@ RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
 /* Kernel-level timing of fused rollouts, off by default: while enabled every wave of a fused rollout kernel records the
  * wall-clock tick (constant 100 MHz) at which it came in and went out, and rq_device_last_rollout_ms returns, after waiting
  * for the most recent one, first-wave-in to last-wave-out on one die (the eight dies' counters are offset against one
- * another; the longest die counts).  Against rocprofv3's per-dispatch duration of the same launches (command processor
- * takes the dispatch -> the kernel's writes are released) the waves' own span reads ~2.6 us short: 63.3 against 65.9 us
- * for a 20-step launch of 65 536 envs, the same few us of a 1-step launch's 12 (profiles/r04_summary.md).  Round 2 used
- * hipExtLaunchKernel's begin / end events: they read ~8 us long and the launches carrying them ran ~4 us longer. */
+ * another; the longest die counts).  rocprofv3's per-dispatch duration of the same launches (command processor takes the
+ * dispatch -> the kernel's writes are released) reads a few microseconds more, by definition: bench.py carries both
+ * (`roofline` / `roofline.wave_span`). */
 RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
 RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
 /* The records themselves (a diagnostic: tools/wave_timeline.py): per wave w of the most recent timed fused rollout four
@@ -203,11 +202,10 @@ RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
  * only.  `records` = NULL: *n_waves only; otherwise it holds 4 * capacity values. */
 RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint32_t capacity, uint32_t* n_waves);
 /* The core clock (GHz) the most recent timed fused rollout ran its steps at: per wave, shader-clock cycles between its
- * first step's start and its last step's end over the same span in constant-rate ticks; the median wave.  The clock
- * follows the chip's load averaged over about a millisecond (tools/idle_clock.py, MI355X): 2.37-2.38 GHz under launches
- * back to back or up to ~200 us apart, 2.07 GHz for a launch behind 5 ms of idling - and more than a millisecond of load
- * to come back, so a lone 20-step launch behind a long pause takes 71 us where the same launch in a busy loop takes 62.
- * (The three readers below share one copy of the records per launch.) */
+ * first step's start and its last step's end over the same span in constant-rate ticks; the median over the waves that
+ * stepped for at least a microsecond.  The clock follows the chip's load averaged over about a millisecond
+ * (tools/idle_clock.py; measured: profiles/r04_idle_clock.txt), so a launch behind an idle gap runs slower than the same
+ * launch in a busy loop.  (The three readers share one copy of the records per launch.) */
 RQ_API int rq_device_last_rollout_clock(rq_device* dev, float* core_ghz);
 /* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
  * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves
@@ -495,16 +493,11 @@ RQ_API int rq_comm_describe(const rq_comm* comm, rq_comm_description* out);
 /* ENQUEUE the all-gather of this rank's rq_env_get_finished_returns: the copy on the env's own stream (right
  * behind the rollout that produced the returns), the collective on a side stream behind an event, double-
  * buffered; the host does not block.  Every rank must call it the same number of times with envs of the same size.
- * What "beside the next rollout" costs, measured (round 4, one MI355X, the REAL librccl with one rank, an exchange posted
- * after every 500-step fused launch with the next launch enqueued right behind it; bench.py `native_exchange_1rank`):
- *   65 536 envs  (1 416 us per episode): + 18 us per episode (1.3 %); the rollout kernel's own span with an exchange in
- *                flight beside it 1 412 us against 1 423 us without (no slowdown); exchange alone on an idle device, post
- *                to gathered: 28 us; the posting call itself: 9 us of host time
- *   262 144 envs (5 618 us per episode): + 38 us per episode (0.7 %); kernel span unchanged (5 648 us both ways)
- * The fused kernel holds every SIMD with one 512-register wave, so the collective's own kernel can only start as waves
- * retire - which is what these figures contain: the copy + events + ncclAllGather + completion ride in the gap between two
- * launches.  With N ranks the xGMI transfer of N x 4 B x n_envs (2 MiB at 8 x 65 536) comes on top; that part has not run
- * on hardware here (one GPU per box). */
+ * What "beside the next rollout" costs is measured in every default bench record (`native_exchange_1rank`: the real librccl
+ * with one rank, an exchange posted after every 500-step launch with the next launch enqueued behind it; DESIGN.md
+ * section 6): the fused kernel holds every SIMD, so the collective's own kernel starts as waves retire and the exchange
+ * rides in the gap between two launches.  With N ranks the xGMI transfer of N x 4 B x n_envs comes on top; that part has
+ * not run on hardware (one GPU per box). */
 RQ_API int rq_allgather_returns(rq_env* env, rq_comm* comm);
 /* Wait for the most recently enqueued all-gather: device pointer to the [n_ranks * n_envs] result in global env
  * order (valid until the second next rq_allgather_returns), its length, and optionally a host copy. */

@@ -1219,7 +1219,7 @@ struct ActorBF16 {
 
 #ifdef RQ_BF16_FUSED_LEAN
 // Experiment builds only (tools/hazard_variants.sh): the same arithmetic compiled for two waves per SIMD (256 registers).  Rounds
-// 3-4 shipped it for large batches; it left the product in round 5 (rq_kernels_16bit.hip, DESIGN.md section 9).
+// 3-4 shipped it for large batches; it left the product in round 5 (rq_kernels_16bit.hip, DESIGN.md section 5).
 struct ActorBF16Lean : ActorBF16 {};
 #endif
 

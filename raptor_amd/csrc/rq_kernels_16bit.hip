@@ -9,7 +9,7 @@ hipError_t launch_rollout_fused_16bit(hipStream_t s, const FusedArgs& a, bool no
     // The bf16 actor runs its one-wave-per-SIMD (512-register) build at EVERY batch size and with every output stage.
     // Round 4 kept a two-waves-per-SIMD (256-register) build, ActorBF16Lean, for the SampleAndSquash stage and for large batches;
     // under another instruction scheduler (-amdgpu-sched-strategy=max-ilp) that build gave run-to-run different results and round
-    // 5 could not name the cause (DESIGN.md section 9, profiles/r05_bf16_two_wave_hunt.md: what it is NOT is measured).  A kernel
+    // 5 could not name the cause (DESIGN.md section 5, profiles/r05_bf16_two_wave_hunt.md: what it is NOT is measured).  A kernel
     // whose correctness depends on an instruction order nobody can justify does not ship: the type exists in experiment builds
     // only (-DRQ_BF16_FUSED_LEAN, tools/hazard_variants.sh), no product launcher names it, tests/test_capi_cpu.py checks that.
     if (a.sas.mode != RQ_SAS_OFF) {

@@ -20,4 +20,5 @@ bash tools/profile_extras.sh $TAG > $DST/profile_extras.log 2>&1; echo "profile_
   python tools/kernel_time.py
 } > $DST/${TAG}_side_rates.txt 2>&1
 echo "side rates rc=$?"
+python tools/determinism_soak.py --steps 1500 > $DST/${TAG}_determinism_soak.txt 2>&1; echo "soak rc=$?"
 ls -la $DST
