@@ -501,6 +501,27 @@ def teacher_probe(device, n, steps=500, hidden=64):
                                                  "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": PEAK_FP32_TFLOPS,
                                                  "frac": round(tf / PEAK_FP32_TFLOPS, 4)}
         del bank
+    # a teacher topology outside the register-stationary family (round 5: what TeacherBank.from_checkpoints may meet): three hidden
+    # layers of 128 units through the streaming kernel (operands shared through LDS by the four step-slices of a tile), fp32
+    from raptor_amd.teachers import layers_parameter_count
+    widths = [128, 128, 128]
+    W = (rng.standard_normal((1000, layers_parameter_count(22, widths))) * 0.05).astype(np.float32)
+    bank = TeacherBank.from_layers(device, W, 22, widths, "relu", "identity")
+    ids = balanced_teacher_assignment(n, 1000)
+    for _ in range(2):
+        tr.relabel_teachers(bank, ids, fetch=False)
+    per = []
+    for _ in range(3):
+        device.synchronize()
+        device.timer_start()
+        tr.relabel_teachers(bank, ids, fetch=False)
+        per.append(device.timer_stop())
+    ms = float(np.median(per))
+    fl = 2 * (22 * 128 + 128 * 128 * 2 + 128 * 4)
+    tf = fl * n * steps / (ms * 1e-3) / 1e12
+    out["dense_stack_22-128-128-128-4_teachers_1000"] = {"ms": round(ms, 3), "labels_per_s": round(n * steps / (ms * 1e-3), 1), "flop_per_label": fl,
+                                                         "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": PEAK_FP32_TFLOPS, "frac": round(tf / PEAK_FP32_TFLOPS, 4)}
+    del bank
     return out
 
 

@@ -95,6 +95,41 @@ __device__ __forceinline__ void test_waw(uint32_t seed, unsigned& bad2, unsigned
     bad4 += (t0 == b && t1 == b) ? 0 : 1;
 }
 
+// bursts: what spill code really looks like - many reloads of mixed widths in flight at once (no wait between them), spill stores to
+// OTHER slots in between, global loads in flight beside them - checked after ONE wait
+__device__ __forceinline__ void test_burst(uint32_t seed, const uint32_t* __restrict__ gsrc, unsigned& bad) {
+    const uint32_t salt = threadIdx.x * 2246822519u;
+    uint32_t r1[4], r2a[2], r2b[2], r4a[4], r4b[4], g0, g1;
+    // slots (byte offsets): x1 at 68, 76, 340, 348; x2 at 100 and 268 (not 8-aligned); x4 at 140 and 188 (not 16-aligned); stores to 400.., 448..
+    asm volatile(
+        "global_load_dword %[g0], %[ga], off\n\t"
+        "scratch_load_dwordx4 %[r4a], off, off offset:140\n\t"
+        "scratch_load_dword %[r10], off, off offset:68\n\t"
+        "scratch_store_dword off, %[s0], off offset:400\n\t"
+        "scratch_load_dwordx2 %[r2a], off, off offset:100\n\t"
+        "scratch_load_dword %[r11], off, off offset:76\n\t"
+        "scratch_store_dwordx2 off, %[s1], off offset:452\n\t"
+        "scratch_load_dwordx4 %[r4b], off, off offset:188\n\t"
+        "global_load_dword %[g1], %[ga], off offset:256\n\t"
+        "scratch_load_dword %[r12], off, off offset:340\n\t"
+        "scratch_load_dwordx2 %[r2b], off, off offset:268\n\t"
+        "scratch_store_dwordx4 off, %[s2], off offset:404\n\t"
+        "scratch_load_dword %[r13], off, off offset:348\n\t"
+        "s_waitcnt vmcnt(0)"
+        : [g0] "=&v"(g0), [g1] "=&v"(g1), [r4a] "=&v"(*(__attribute__((ext_vector_type(4))) uint32_t*)r4a), [r4b] "=&v"(*(__attribute__((ext_vector_type(4))) uint32_t*)r4b),
+          [r2a] "=&v"(*(uint64_t*)r2a), [r2b] "=&v"(*(uint64_t*)r2b), [r10] "=&v"(r1[0]), [r11] "=&v"(r1[1]), [r12] "=&v"(r1[2]), [r13] "=&v"(r1[3])
+        : [ga] "v"(gsrc + threadIdx.x), [s0] "v"(seed), [s1] "v"((uint64_t)seed * 3u), [s2] "v"((__attribute__((ext_vector_type(4))) uint32_t){seed, seed + 1, seed + 2, seed + 3})
+        : "memory");
+    auto want = [&](int off) { return mix(seed + off / 4) ^ (threadIdx.x * 2654435761u); };
+    (void)salt;
+    bool ok = r1[0] == want(68) && r1[1] == want(76) && r1[2] == want(340) && r1[3] == want(348);
+    ok &= r2a[0] == want(100) && r2a[1] == want(104) && r2b[0] == want(268) && r2b[1] == want(272);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ok &= r4a[k] == want(140 + 4 * k) && r4b[k] == want(188 + 4 * k);
+    ok &= g0 == gsrc[threadIdx.x] && g1 == gsrc[threadIdx.x + 64];
+    bad += ok ? 0 : 1;
+}
+
 static constexpr int kTests = 12;
 template <int T> struct Case;
 #define CASE(T, W, O) template <> struct Case<T> { static constexpr int width = W, off = O; }
@@ -106,10 +141,10 @@ __device__ __forceinline__ void all_tests(uint32_t seed, unsigned (&st)[kTests],
     (test<Case<Ts>::width, Case<Ts>::off>(seed, st[Ts], ld[Ts]), ...);
 }
 
-__global__ __launch_bounds__(64) void k_probe(int iters, unsigned long long* out, uint32_t* sink) {
+__global__ __launch_bounds__(64) void k_probe(int iters, unsigned long long* out, uint32_t* sink, const uint32_t* __restrict__ gsrc) {
     volatile uint32_t own[128];                      // 512 B of private memory per lane: dynamically indexed, so it stays in scratch (offset 0)
     for (int k = 0; k < 128; ++k) own[(k + threadIdx.x) & 127] = k;
-    unsigned st[kTests] = {}, ld[kTests] = {}, waw[4] = {};
+    unsigned st[kTests] = {}, ld[kTests] = {}, waw[4] = {}, burst = 0;
     const uint32_t lane_salt = threadIdx.x * 2654435761u;
     for (int it = 0; it < iters; ++it) {
         const uint32_t seed = mix(blockIdx.x * 977u + (uint32_t)it * 131071u);      // wave-uniform
@@ -122,6 +157,8 @@ __global__ __launch_bounds__(64) void k_probe(int iters, unsigned long long* out
         all_tests(seed, st, ld, std::make_integer_sequence<int, kTests>{});
         test_waw<0>(seed, waw[0], waw[1]);
         test_waw<2>(seed, waw[2], waw[3]);
+        // (the tests above restored the first pattern in their windows; the burst's stores go to 400 .. 467, which nothing reads)
+        test_burst(seed, gsrc + (size_t)(blockIdx.x & 1023) * 128, burst);
     }
     const uint32_t q = (threadIdx.x & 63) >> 4;
 #pragma unroll
@@ -132,6 +169,7 @@ __global__ __launch_bounds__(64) void k_probe(int iters, unsigned long long* out
 #pragma unroll
     for (int t = 0; t < 4; ++t)
         if (waw[t]) atomicAdd(&out[(2 * kTests + t) * 4 + q], (unsigned long long)waw[t]);
+    if (burst) atomicAdd(&out[(2 * kTests + 4) * 4 + q], (unsigned long long)burst);
     sink[blockIdx.x * 64 + threadIdx.x] = own[threadIdx.x & 127];
 }
 
@@ -139,13 +177,16 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 500;
     unsigned long long* dout;
     uint32_t* sink;
-    (void)hipMalloc(&dout, (kTests * 8 + 16) * 8);
+    (void)hipMalloc(&dout, (kTests * 8 + 20) * 8);
+    uint32_t* gsrc;
+    (void)hipMalloc(&gsrc, 1024 * 128 * 4);
+    (void)hipMemset(gsrc, 0x5a, 1024 * 128 * 4);
     (void)hipMalloc(&sink, 8192 * 64 * 4);
     const int widths[kTests] = {2, 2, 2, 2, 3, 3, 4, 4, 4, 4, 4, 4}, offs[kTests] = {96, 100, 252, 260, 96, 100, 96, 100, 104, 108, 140, 244};
     for (int blocks : {512, 1024, 2048, 8192}) {
-        (void)hipMemset(dout, 0, (kTests * 8 + 16) * 8);
-        hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(64), 0, 0, iters, dout, sink);
-        unsigned long long h[kTests * 8 + 16];
+        (void)hipMemset(dout, 0, (kTests * 8 + 20) * 8);
+        hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(64), 0, 0, iters, dout, sink, gsrc);
+        unsigned long long h[kTests * 8 + 20];
         (void)hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost);
         printf("== %d waves of 64 lanes (%g per CU), %d iterations: mismatching lane-iterations per quarter of the wave (0-15|16-31|32-47|48-63)\n", blocks, blocks / 256.0, iters);
         for (int t = 0; t < kTests; ++t)
@@ -156,6 +197,8 @@ int main(int argc, char** argv) {
                              "dwordx2 then dword into its upper register, two loads between", "dwordx4 then two dwords (same as above)"};
         for (int t = 0; t < 4; ++t)
             printf("  load after load, other slot, no wait: %-62s %llu|%llu|%llu|%llu\n", wn[t], h[kTests * 8 + t * 4], h[kTests * 8 + t * 4 + 1], h[kTests * 8 + t * 4 + 2], h[kTests * 8 + t * 4 + 3]);
+        printf("  burst: 10 reloads of mixed widths, 3 spill stores and 2 global loads in flight at once, one wait:         %llu|%llu|%llu|%llu\n",
+               h[kTests * 8 + 16], h[kTests * 8 + 17], h[kTests * 8 + 18], h[kTests * 8 + 19]);
     }
     hipError_t e = hipDeviceSynchronize();
     printf("%s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
