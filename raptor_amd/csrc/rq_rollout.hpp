@@ -392,7 +392,11 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             rec[0] = t_in;
             rec[1] = ((unsigned long long)wall_clock64() & 0x0FFFFFFFFFFFFFFFull) | (xcd << 60);
             rec[2] = t_loop;          // prologue issued (its loads may still be in flight), first step about to start
+#ifdef RQ_DEBUG_HWID         // experiment builds only (tools/hazard_diag.py --hwid): where the wave ran - HW_REG_HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+            rec[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#else
             rec[3] = t_done;          // last step done, the epilogue's stores not yet issued
+#endif
             span[4 * (size_t)gridDim.x + blockIdx.x] = c_done - c_loop;      // core-clock cycles between rec[2] and rec[3]
         }
     }
