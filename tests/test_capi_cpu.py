@@ -235,6 +235,45 @@ def test_no_mfma_result_is_touched_before_it_is_final():
     assert "0 hazard(s)" in r.stdout
 
 
+def test_no_kernel_is_exposed_to_the_packed_op_sel_fault():
+    """tools/opsel_lint.py over the listings of every kernel source.  Measured in round 5 (profiles/r05_bf16_two_wave_hunt.md,
+    tools/hazard_probe7.hip): on gfx950 a v_pk_add/mul/fma_f32 whose low result takes src0's low and src1's HIGH dword
+    (op_sel:[0,1,..]) reads that dword as 0 in lanes 48..63 while ANOTHER wave of the same SIMD executes a 16- or 8-bit MFMA - the
+    cause of the run-to-run differences of the two-waves-per-SIMD bf16 rollout build of rounds 3 - 4.  A kernel that holds such an
+    instruction, holds such MFMAs, and fits twice into a SIMD must not ship."""
+    import subprocess
+    import sys
+    from raptor_amd import build
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "opsel_lint.py")] + build.listings(), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 exposed kernel(s)" in r.stdout
+
+
+def test_the_op_sel_lint_and_its_rewrite():
+    """The lint flags exactly the measured form, and tools/opsel_rewrite.py turns it into the sound twin (operands and their
+    modifiers exchanged: the same sum / product)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import opsel_lint
+    import opsel_rewrite
+    risky = ["v_pk_add_f32 v[18:19], v[20:21], v[34:35] op_sel:[0,1]", "v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]",
+             "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,1] neg_lo:[0,0,1]", "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[0,1]"]
+    sound = ["v_pk_add_f32 v[18:19], v[20:21], v[34:35] op_sel:[1,0]", "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,1]",
+             "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]", "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]",
+             "v_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]", "v_pk_add_f16 v0, v1, v2 op_sel:[0,1]", "v_pk_add_f32 v[0:1], v[2:3], v[4:5]"]
+    for x in risky:
+        assert opsel_lint.RISKY.search(x), x
+        y, changed = opsel_rewrite.rewrite("\t" + x)
+        assert changed and not opsel_lint.RISKY.search(y.strip()), (x, y)
+    for x in sound:
+        assert not opsel_lint.RISKY.search(x), x
+        assert opsel_rewrite.rewrite("\t" + x) == ("\t" + x, False)
+    assert opsel_rewrite.rewrite("\tv_pk_mul_f32 v[0:1], v[4:5], v[2:3] op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]")[0] == \
+        "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[0,1]"
+    # a constant or scalar source has no high half to exchange into: left alone (and reported by the lint)
+    assert opsel_rewrite.rewrite("\tv_pk_add_f32 v[0:1], v[2:3], s[4:5] op_sel:[0,1]")[1] is False
+
+
 def test_the_hazard_lint_sees_a_move_behind_a_taken_branch():
     """The lint on a reduced rendition of the build it was written for: the move on the taken path (4 and 5 wait states behind
     the MFMA) is reported, the padded variant is not."""

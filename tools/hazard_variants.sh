@@ -10,6 +10,8 @@
 #   G  A + two wait states on either side inside every asm (still differs)
 #   H  A + scalar spills to memory instead of VGPR lanes   (still differs)
 #   K / L  F / A with v8 .. v247 zeroed at kernel entry    (still differs: not a read of an uninitialised register)
+#   FH F + -DRQ_DEBUG_HWID (every wave records HW_REG_HW_ID: tools/hazard_diag.py --hwid)
+# Listing-level experiments on top of F / A: tools/asm_edit.py, tools/asm_instrument.py, tools/opsel_rewrite.py + tools/asm_build.sh.
 # RQ_DEBUG_FUSED_LDS=<bytes> (any of these builds) gives every workgroup that much LDS and so bounds the waves per CU.
 set -e
 cd "$(dirname "$0")/.."
@@ -27,5 +29,6 @@ FLAGS="$M -mllvm -amdgpu-spill-sgpr-to-vgpr=0" build H env
 FLAGS="$M -DRQ_PK_PLAIN_C -DRQ_DEBUG_ZERO_VGPRS" build K env
 wait
 FLAGS="$M -DRQ_DEBUG_ZERO_VGPRS" build L env
+FLAGS="$M -DRQ_PK_PLAIN_C -DRQ_DEBUG_HWID" build FH env
 wait
-for t in hazard_probe hazard_probe2 scratch_probe; do hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/$t.hip -o tools/$t 2>/dev/null && echo "built tools/$t"; done
+for t in hazard_probe hazard_probe2 hazard_probe3 hazard_probe4 hazard_probe5 hazard_probe6 hazard_probe7 scratch_probe; do hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/$t.hip -o tools/$t 2>/dev/null && echo "built tools/$t"; done
