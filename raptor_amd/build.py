@@ -28,11 +28,9 @@ if os.environ.get("RQ_NO_MFMA_VGPR_FORM"):                                 # (an
     del DEVICE_FLAGS[_i - 1:_i + 1]
 SOURCES = ["rq_kernels.hip", "rq_kernels_16bit.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
 HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_rollout.hpp", "rq_host.hpp", os.path.join(INCLUDE, "raptor_quad.h")]
-# per-source flags.  Round 4 built rq_kernels_16bit.hip with -mllvm -amdgpu-sched-strategy=max-ilp (a lone wave stalls ~3 cycles
-# when an instruction reads the result of the one right before it, tools/lonewave.hip; 24 -> 5 such pairs in the bf16 loop).  With
-# it the TWO-waves-per-SIMD bf16 build (ActorBF16Lean, > 65 536 envs) gave run-to-run different results - whole 16-env tiles, with
-# and without auto-reset, default scheduler: never (tests/test_gpu_parity.py::test_fused_rollout_is_deterministic) - and the gain
-# on the one-wave build was inside the box-to-box spread (1.449 -> 1.406 us/step on one box, nothing on the next): dropped.
+# per-source flags (none today).  Round 4 built rq_kernels_16bit.hip with -mllvm -amdgpu-sched-strategy=max-ilp; the gain on the bf16 build
+# that ships was inside the box-to-box spread, and the two-waves-per-SIMD bf16 build gave run-to-run different results with it - the
+# gfx950 fault round 5 found (gfx950_errata.py), which _compile() now rewrites out of every listing whatever the scheduler.
 SOURCE_FLAGS = {}
 
 def _hipcc():

@@ -154,9 +154,10 @@ def test_comm_entry_points_validate_and_fail_loudly_without_a_gpu():
 
 
 def test_product_library_holds_no_two_wave_bf16_kernel():
-    """Round 5: the two-waves-per-SIMD bf16 actor build (ActorBF16Lean) gave run-to-run different results under another instruction
-    schedule and its cause was not found (profiles/r05_bf16_two_wave_hunt.md): it exists in experiment builds only.  The product
-    library must not contain a kernel instantiated with it, and rq_comm_describe / rq_comm_info refuse null handles."""
+    """The two-waves-per-SIMD bf16 actor build (ActorBF16Lean) gave run-to-run different results under another instruction schedule;
+    round 5 found the cause (a gfx950 fault only two waves of a SIMD with 16-bit MFMAs can meet, profiles/r05_bf16_two_wave_hunt.md)
+    and the build was the slower one anyway: it exists in experiment builds only.  The product library must not contain a kernel
+    instantiated with it, and rq_comm_describe / rq_comm_info refuse null handles."""
     from raptor_amd import _lib
     lib = _lib.load()
     blob = open(_lib.LIB_PATH, "rb").read()
