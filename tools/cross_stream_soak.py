@@ -27,6 +27,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=200, help="steps of the fp32 workload per repetition")
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--victim", default="fp32", help="precision of the workload that is checked (fp32 | bf16 | f16x2)")
+ap.add_argument("--mode", default="chained", help="chained (API-granular kernels under a hipGraph) | fused")
 ap.add_argument("--aggressor", default="bf16", help="precision of the other stream's fused rollouts (bf16 | f16x2 | fp32 | none)")
 args = ap.parse_args()
 tag = os.path.basename(os.environ.get("RAPTOR_QUAD_LIB", "product"))
@@ -35,8 +37,8 @@ dev_a, dev_b = l2f.Device(0), l2f.Device(0)        # two engines on one GPU: a s
 
 
 def workload():
-    sh = Shard(dev_b, args.envs, 0, seed=7)
-    sh.rollout(args.steps, "chained")
+    sh = Shard(dev_b, args.envs, 0, seed=7, precision=args.victim)
+    sh.rollout(args.steps, args.mode)
     return np.concatenate([sh.state.numpy(), sh.policy.hidden_state(args.envs)], axis=1)
 
 
@@ -72,6 +74,6 @@ for rep in range(args.reps):
 stop.set()
 if t is not None:
     t.join()
-print(f"[{tag}] {args.reps} repetitions of {args.steps} fp32 steps on {args.envs} envs beside {launched[0]} {args.aggressor} rollouts on another stream: "
+print(f"[{tag}] {args.reps} repetitions of {args.steps} {args.victim} {args.mode} steps on {args.envs} envs beside {launched[0]} {args.aggressor} rollouts on another stream: "
       f"{bad_reps} repetitions differ from the idle-GPU result, {bad_envs} envs; by quarter of the wave {dict(sorted(quarters.items()))}")
 sys.exit(1 if bad_envs else 0)
