@@ -128,9 +128,8 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True, variant=_variant, extra_flags=_extra)
 
 
-def listings(variant=None):
+def listings():
     """The gfx950 assembly listings the library was assembled from (one per kernel source, written by the build: the compiler's device
     listing after the op_sel pass) -> [paths].  What tools/mfma_hazard_lint.py, tools/opsel_lint.py and the instruction-mix tools read."""
-    build(variant=variant)
-    obj_dir = OBJ if not variant else os.path.join(os.path.dirname(PKG), "scratch", "variants", "_obj_" + variant)
-    return [os.path.join(obj_dir, os.path.splitext(src)[0] + ".s") for src in SOURCES if src.endswith(".hip")]
+    build()
+    return [os.path.join(OBJ, os.path.splitext(src)[0] + ".s") for src in SOURCES if src.endswith(".hip")]
