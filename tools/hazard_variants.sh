@@ -31,4 +31,4 @@ wait
 FLAGS="$M -DRQ_DEBUG_ZERO_VGPRS" build L env
 FLAGS="$M -DRQ_PK_PLAIN_C -DRQ_DEBUG_HWID" build FH env
 wait
-for t in hazard_probe hazard_probe2 hazard_probe3 hazard_probe4 hazard_probe5 hazard_probe6 hazard_probe7 scratch_probe; do hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/$t.hip -o tools/$t 2>/dev/null && echo "built tools/$t"; done
+for t in opsel_repro hazard_probe hazard_probe2 hazard_probe3 hazard_probe4 hazard_probe5 hazard_probe6 hazard_probe7 scratch_probe; do hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/$t.hip -o tools/$t 2>/dev/null && echo "built tools/$t"; done
