@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void k_observe(Batch b, NoiseCfg nc, uint64
         o[22] = fmaf(y.R01[0] - rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - rmin, inv, -1.0f);
         o[24] = fmaf(y.R23[0] - rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - rmin, inv, -1.0f);
 #pragma unroll
-        for (int k = 0; k < RQ_OBSERVATION_DIM; ++k) field(obs, k, b.ld)[i] = o[k];
+        for (int k = 0; k < RQ_OBSERVATION_DIM; ++k) put<kNtObs>(&field(obs, k, b.ld)[i], o[k]);
         if (mb.rows_out != nullptr) {            // wave-uniform (kernel argument)
 #pragma unroll
             for (int k = 0; k < RQ_OBSERVATION_DIM; ++k) mb.rows_out[(size_t)i * RQ_OBSERVATION_DIM + k] = o[k];
@@ -449,7 +449,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
         o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
         o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
 #pragma unroll
-        for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) field(on.obs, j, ld)[i] = o[j];
+        for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) put<kNtObs>(&field(on.obs, j, ld)[i], o[j]);
         if (mb.rows_out != nullptr) {
 #pragma unroll
             for (int j = 0; j < RQ_OBSERVATION_DIM; ++j) mb.rows_out[(size_t)i * RQ_OBSERVATION_DIM + j] = o[j];
@@ -651,9 +651,9 @@ __global__ __launch_bounds__(kBlock) void k_record(Batch b, const float* __restr
     if (i >= b.n) return;
     const size_t ld = b.ld, tt = traj.t0;
 #pragma unroll
-    for (int j = 0; j < 22; ++j) traj.obs[(tt * 22 + j) * ld + i] = field(obs, j, ld)[i];
+    for (int j = 0; j < 22; ++j) put<kNtTraj>(&traj.obs[(tt * 22 + j) * ld + i], field(obs, j, ld)[i]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) traj.act[(tt * 4 + j) * ld + i] = field(act, j, ld)[i];
+    for (int j = 0; j < 4; ++j) put<kNtTraj>(&traj.act[(tt * 4 + j) * ld + i], field(act, j, ld)[i]);
     traj.rew[tt * ld + i] = st.last_reward[i];
     traj.done[tt * ld + i] = st.last_done[i];
 }

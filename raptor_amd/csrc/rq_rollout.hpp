@@ -22,6 +22,19 @@ namespace rq {
 static constexpr int kBlock = 256;      // 4 waves; streaming kernels
 static constexpr int kFusedBlock = 64;  // 1 wave per workgroup: spreads 65 536 envs as 1024 WGs over 256 CUs
 
+// Stores of write-once streams leave as NON-TEMPORAL stores (round 5, same-box A/B, profiles/r05_ab_nt_stores.txt): the observation
+// k_observe / k_step write (k_observe at 2 097 152 envs 84 -> 63 us = 0.61 -> 0.82 of 8 TB/s, at 262 144 envs 8.2 -> 6.2 us, at
+// 65 536 envs inside the noise) and the trajectory recorder's (2.5 - 4 % on the recorded rollout).  NOT the next state, the policy
+// state or the actions (k_step, k_actor_step / k_actor_stream, the fused kernel's epilogue: measured, nothing), and not loads
+// (round 5's first experiment: non-temporal LOADS cost k_actor_stream 10 - 25 %).
+template <bool NT, class T>
+__device__ __forceinline__ void put(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+static constexpr bool kNtObs = true, kNtTraj = true;
+static constexpr int kNtTrajAux = 2;           // the `nt` cache-policy bit of a raw buffer store
+
 __device__ __forceinline__ uint32_t env_index() { return blockIdx.x * blockDim.x + threadIdx.x; }
 
 // Field f of a field-major SoA buffer: env i of the batch is element i of this row.
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             actor.template step_fused<22>(o, hn, a, carry, [&] {
 #pragma unroll
                 for (int j = 0; j < 22; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[j]), ro, lane_off, (uint32_t)j * row, kNtTrajAux);
             });
         } else {
             actor.template step_fused<0>(o, hn, a, carry, [] {});
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(traj.act + tt * 4 * ld, 0, 4u * row, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a[j]), ra, lane_off, (uint32_t)j * row, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a[j]), ra, lane_off, (uint32_t)j * row, kNtTrajAux);
         }
         if (AUTORESET) {
 #pragma unroll
@@ -315,8 +328,8 @@ __global__ __launch_bounds__(kFusedBlock, WavesPerSimd<ACTOR>::value) void k_rol
             const size_t tt = traj.t0 + t;
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(traj.rew + tt * ld, 0, row, 0x00020000);
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(traj.done + tt * ld, 0, (uint32_t)ld, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rr, valid ? i * 4u : 0xFFFFFFFFu, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b8(done_code, rd, valid ? i : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rr, valid ? i * 4u : 0xFFFFFFFFu, 0, kNtTrajAux);
+            __builtin_amdgcn_raw_buffer_store_b8(done_code, rd, valid ? i : 0xFFFFFFFFu, 0, kNtTrajAux);
         }
         if (AUTORESET) {   // the envs whose episode ended: record, next initial state, h <- initial_hidden_state
             const uint64_t ended_mask = __builtin_amdgcn_ballot_w64(ended);
