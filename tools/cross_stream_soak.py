@@ -49,20 +49,31 @@ stop = threading.Event()
 launched = [0]
 
 
+failed = []
+
+
 def aggressor():
-    sh = Shard(dev_a, args.envs, 0, seed=3, precision=args.aggressor)
-    while not stop.is_set():
-        sh.rollout(2000, "fused")              # a few milliseconds per launch, auto-reset: the stream is busy almost all the time
-        dev_a.synchronize()
-        launched[0] += 1
+    try:
+        sh = Shard(dev_a, args.envs, 0, seed=3, precision=args.aggressor)
+        while not stop.is_set():
+            sh.rollout(2000, "fused")          # a few milliseconds per launch, auto-reset: the stream is busy almost all the time
+            dev_a.synchronize()
+            launched[0] += 1
+    except Exception as e:                     # noqa: BLE001  (reported by the main thread)
+        failed.append(repr(e))
 
 
 t = None
 if args.aggressor != "none":
     t = threading.Thread(target=aggressor, daemon=True)
     t.start()
-    while launched[0] < 3:
-        pass
+    import time
+    deadline = time.monotonic() + 120.0
+    while launched[0] < 3 and not failed and time.monotonic() < deadline:
+        time.sleep(0.001)
+    if failed or launched[0] < 3:
+        stop.set()
+        sys.exit("the other stream's rollouts did not start: " + (failed[0] if failed else "timeout"))
 bad_envs, bad_reps, quarters = 0, 0, collections.Counter()
 for rep in range(args.reps):
     got = workload()
@@ -73,7 +84,9 @@ for rep in range(args.reps):
         quarters.update((np.nonzero(d)[0] % 64 // 16).tolist())
 stop.set()
 if t is not None:
-    t.join()
+    t.join(60.0)
+if failed:
+    sys.exit("the other stream's rollouts failed: " + failed[0])
 print(f"[{tag}] {args.reps} repetitions of {args.steps} {args.victim} {args.mode} steps on {args.envs} envs beside {launched[0]} {args.aggressor} rollouts on another stream: "
       f"{bad_reps} repetitions differ from the idle-GPU result, {bad_envs} envs; by quarter of the wave {dict(sorted(quarters.items()))}")
 sys.exit(1 if bad_envs else 0)
