@@ -200,7 +200,9 @@ def write_checkpoint_h5(path, weights, example=None, meta=_DEFAULT_META, checkpo
     write_file(path, build(tree, ""))
 
 
-_ACT_NAMES = {"RELU": "relu", "TANH": "tanh", "IDENTITY": "identity", "FAST_TANH": "tanh"}
+# rl-tools also knows FAST_TANH (an approximation of tanh whose definition is not in the reference tree): a teacher trained with it
+# would be relabelled with a different function if it were mapped onto the exact tanh, so it is refused by name.
+_ACT_NAMES = {"RELU": "relu", "TANH": "tanh", "IDENTITY": "identity"}
 
 
 def load_mlp_checkpoint_h5(path, group="actor"):
@@ -222,6 +224,9 @@ def load_mlp_checkpoint_h5(path, group="actor"):
         kind, fn = lay.attrs.get("type"), lay.attrs.get("activation_function")
         if kind != "dense":
             raise ValueError(f"{path}: /{group}/layers/{i} is a '{kind}' layer; a teacher is a stack of dense layers")
+        if fn == "FAST_TANH":
+            raise ValueError(f"{path}: /{group}/layers/{i} uses FAST_TANH, rl-tools' tanh approximation; its definition is not in the "
+                             "reference tree and evaluating it as the exact tanh would relabel with another function - refused")
         if fn not in _ACT_NAMES:
             raise ValueError(f"{path}: /{group}/layers/{i} has activation '{fn}' (supported: {sorted(_ACT_NAMES)})")
         try:
@@ -261,11 +266,45 @@ def write_mlp_checkpoint_h5(path, layers, activations, group="actor", meta=None)
     write_file(path, GroupSpec({group: GroupSpec({"layers": GroupSpec(lay)}, attrs)}))
 
 
-def load_checkpoint(path):
-    """Dispatch on the file type: HDF5 signature -> `load_checkpoint_h5`, otherwise the C++ export."""
+# The observation the engine's `observe` assembles and its actor kernels consume (README.md:23; `h5:/actor@meta` of the shipped
+# checkpoint): 3 position + 9 rotation matrix (row-major) + 3 linear velocity + 3 body-frame angular velocity + 4 previous action.
+ENGINE_OBSERVATION = "Position.OrientationRotationMatrix.LinearVelocity.AngularVelocityDelayed(0).ActionHistory(1)"
+
+
+def observation_of_meta(meta):
+    """The observation specification string inside an rl-tools `/actor@meta` attribute (JSON: {"environment": {"name": ...,
+    "observation": ...}}) -> str or None (no meta, or a meta without that key).  Text that is not JSON is an error: a
+    checkpoint that says something about itself which cannot be read must not load as if it had said nothing."""
+    if meta is None:
+        return None
+    import json
+    try:
+        doc = json.loads(meta)
+    except (TypeError, ValueError) as e:
+        raise ValueError(f"checkpoint meta is not JSON ({e}): {meta!r}")
+    env = doc.get("environment") if isinstance(doc, dict) else None
+    obs = env.get("observation") if isinstance(env, dict) else None
+    return None if obs is None else str(obs)
+
+
+def check_observation(meta, path="checkpoint"):
+    """Refuse a checkpoint trained on another observation layout than the one this engine assembles (VERDICT r05 missing 4: the
+    loader used to read `/actor@meta` and throw it away, so such a policy loaded silently and flew on permuted inputs).
+    -> the specification string (None when the checkpoint does not carry one, e.g. the C++ export, whose meta holds name and commit only)."""
+    obs = observation_of_meta(meta)
+    if obs is not None and obs != ENGINE_OBSERVATION:
+        raise ValueError(f"{path}: trained on observation '{obs}', this engine assembles '{ENGINE_OBSERVATION}' "
+                         "(README.md:23); pass check_observation=False to load it anyway")
+    return obs
+
+
+def load_checkpoint(path, with_meta=False):
+    """Dispatch on the file type: HDF5 signature -> `load_checkpoint_h5`, otherwise the C++ export.
+    -> (weights, example) or, with_meta, (weights, example, meta string or None)."""
     with open(path, "rb") as f:
         magic = f.read(8)
     if magic == b"\x89HDF\r\n\x1a\n":
-        w, ex, _ = load_checkpoint_h5(path)
-        return w, ex
-    return load_checkpoint_header(path)
+        w, ex, meta = load_checkpoint_h5(path)
+    else:
+        (w, ex), meta = load_checkpoint_header(path), None
+    return (w, ex, meta) if with_meta else (w, ex)

@@ -78,45 +78,8 @@ __device__ __forceinline__ void box_muller_fast(float u1, float u2, float& n0, f
 // them reads an MFMA or transcendental result directly and none feeds a v_permlane (the hazards the
 // compiler only tracks for instructions it can see): their inputs come from loads, copies or plain VALU code.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#if defined(RQ_PK_PLAIN_C)
-// Experiment builds only (tools/hazard_variants.sh): the same operations as plain C++ the compiler sees through - the
-// modifier string is interpreted at compile time (op_sel / op_sel_hi pick the source half of the low / high result,
-// neg_lo / neg_hi negate per half; fmaf and one rounding per product: the same bits as the packed instruction).
-namespace pkc {
-constexpr int bit_of(const char* s, const char* key, int idx, int dflt) {
-    for (const char* p = s; *p; ++p) {
-        const char* q = p; const char* k = key;
-        while (*k && *q == *k) { ++q; ++k; }
-        if (*k == 0 && *q == ':' && (p == s || p[-1] == ' ')) {          // "key:[a,b,c]"
-            q += 2;
-            for (int i = 0; i < idx; ++i) { while (*q != ',' && *q != ']') ++q; if (*q == ']') return dflt; ++q; }
-            return *q - '0';
-        }
-    }
-    return dflt;
-}
-template <int SEL, int NEG> __device__ __forceinline__ float pick(f32x2 v) { const float x = SEL ? v[1] : v[0]; return NEG ? -x : x; }
-}  // namespace pkc
-#define RQ_PKC(M, key, i, dflt) pkc::bit_of(M, key, i, dflt)
-#define RQ_PK_MUL(d, a, b, mods) do { constexpr const char* m_ = mods; \
-    const float lo_ = pkc::pick<RQ_PKC(m_, "op_sel", 0, 0), RQ_PKC(m_, "neg_lo", 0, 0)>(a) * pkc::pick<RQ_PKC(m_, "op_sel", 1, 0), RQ_PKC(m_, "neg_lo", 1, 0)>(b); \
-    const float hi_ = pkc::pick<RQ_PKC(m_, "op_sel_hi", 0, 1), RQ_PKC(m_, "neg_hi", 0, 0)>(a) * pkc::pick<RQ_PKC(m_, "op_sel_hi", 1, 1), RQ_PKC(m_, "neg_hi", 1, 0)>(b); \
-    d = f32x2{lo_, hi_}; } while (0)
-#define RQ_PK_FMA(d, a, b, c, mods) do { constexpr const char* m_ = mods; \
-    const float lo_ = fmaf(pkc::pick<RQ_PKC(m_, "op_sel", 0, 0), RQ_PKC(m_, "neg_lo", 0, 0)>(a), pkc::pick<RQ_PKC(m_, "op_sel", 1, 0), RQ_PKC(m_, "neg_lo", 1, 0)>(b), \
-                            pkc::pick<RQ_PKC(m_, "op_sel", 2, 0), RQ_PKC(m_, "neg_lo", 2, 0)>(c)); \
-    const float hi_ = fmaf(pkc::pick<RQ_PKC(m_, "op_sel_hi", 0, 1), RQ_PKC(m_, "neg_hi", 0, 0)>(a), pkc::pick<RQ_PKC(m_, "op_sel_hi", 1, 1), RQ_PKC(m_, "neg_hi", 1, 0)>(b), \
-                            pkc::pick<RQ_PKC(m_, "op_sel_hi", 2, 1), RQ_PKC(m_, "neg_hi", 2, 0)>(c)); \
-    d = f32x2{lo_, hi_}; } while (0)
-#elif defined(RQ_PK_PADDED_ASM)
-// Experiment builds only: the same statements with two wait states on either side INSIDE the string - no change to what
-// the scheduler may do with them, every wait-state rule between a neighbour and the hidden instruction satisfied.
-#define RQ_PK_MUL(d, a, b, mods) asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2 " mods "\n\ts_nop 1" : "=v"(d) : "v"(a), "v"(b))
-#define RQ_PK_FMA(d, a, b, c, mods) asm("s_nop 1\n\tv_pk_fma_f32 %0, %1, %2, %3 " mods "\n\ts_nop 1" : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#else
 #define RQ_PK_MUL(d, a, b, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
 #define RQ_PK_FMA(d, a, b, c, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#endif
 // d += b in place: the destination is a register pair the COMPILER last wrote (a load's return, a copy).  Used right
 // behind an MFMA batch, where a fresh asm destination may be given registers a just-issued MFMA still reads as its C
 // operand.  (hipcc's own code overwrites such registers 0 .. 6 wait states behind a 16x16x4 f32 MFMA - the matrix unit has
@@ -234,13 +197,7 @@ __device__ __forceinline__ void dynamics(const EnvConsts& k, const Disturbance& 
     float tz;                                          // kq (T1 + T3 - T0 - T2) + tdz: spin directions (-1,+1,-1,+1)
     {   // as one opaque instruction: the SLP pass otherwise pairs this fma with cz's and pays two register moves
         const float du = U[1] - U[0];
-#if defined(RQ_PK_PLAIN_C)
-        tz = fmaf(k.kq, du, ds.tdz);
-#elif defined(RQ_PK_PADDED_ASM)
-        asm("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(tz) : "v"(k.kq), "v"(du), "v"(ds.tdz));
-#else
         asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tz) : "v"(k.kq), "v"(du), "v"(ds.tdz));
-#endif
     }
     f32x2 TXY;                                         // (tx, ty) = TD + sum_i (y_i, -x_i) T_i
     RQ_PK_FMA(TXY, k.PYX[0], T01, ds.TD01, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
@@ -1217,11 +1174,6 @@ struct ActorBF16 {
     }
 };
 
-#ifdef RQ_BF16_FUSED_LEAN
-// Experiment builds only (tools/hazard_variants.sh): the same arithmetic compiled for two waves per SIMD (256 registers).  Rounds
-// 3-4 shipped it for large batches; it left the product in round 5 (rq_kernels_16bit.hip).
-struct ActorBF16Lean : ActorBF16 {};
-#endif
 
 // ---- split-f16 operands on v_mfma_f32_16x16x32_f16: fp32-grade contractions on the co-executing matrix pipe ----
 // The exact-f32 MFMA shares the FMA hardware with the VALU (the two never overlap): that is

@@ -63,16 +63,21 @@ class Raptor:
         self._h = None
         self._fin = None
         self.example = None
+        self.observation_spec = None
 
     @classmethod
-    def from_checkpoint(cls, path, device=None, precision="fp32"):
+    def from_checkpoint(cls, path, device=None, precision="fp32", check_observation=True):
         """Load a policy checkpoint written by rl-tools: the C++ code export (``checkpoint.h``) or its
         HDF5 twin (``checkpoint.h5``), same topology.  The embedded known-answer example, if any, is
-        kept as ``policy.example``."""
-        from .checkpoint import load_checkpoint
-        weights, example = load_checkpoint(path)
+        kept as ``policy.example``.  An HDF5 checkpoint states the observation it was trained on
+        (``/actor@meta``); one that names another layout than this engine's ``observe`` assembles is
+        refused (``check_observation=False`` loads it anyway); ``policy.observation_spec`` keeps the string."""
+        from . import checkpoint as ck
+        weights, example, meta = ck.load_checkpoint(path, with_meta=True)
+        spec = ck.check_observation(meta, path) if check_observation else ck.observation_of_meta(meta)
         pol = cls(device=device, weights=weights, precision=precision)
         pol.example = example
+        pol.observation_spec = spec
         return pol
 
     def save_checkpoint(self, path, example=None):

@@ -157,13 +157,54 @@ def test_nominal_crazyflie_statistics_of_this_specification(oracle, weights):
     assert abs(len_term - REFERENCE_LOG_CRAZYFLIE["terminated_episode_length_implied"]) < 9.0, len_term
 
 
-@pytest.mark.xfail(strict=True, reason="stated mismatch (DESIGN.md section 2): the log's nominal-Crazyflie evaluation "
-                                       "terminates 3.4 % of its episodes (last 100 epochs), this specification 1 %; strict, so that a "
-                                       "specification change that closes the gap is noticed and documented")
-def test_nominal_crazyflie_statistics_against_the_reference_training_log(oracle, weights):
-    share, length, _, _ = _nominal_crazyflie(oracle, weights)
-    assert abs(share - REFERENCE_LOG_CRAZYFLIE["share_terminated"]) < 0.012
-    assert abs(length - REFERENCE_LOG_CRAZYFLIE["episode_length"]) < 5.0
+def test_the_reference_log_is_not_reproduced_and_the_record_says_so():
+    """Round 6 closed the topic: tools/policy_competence.py mapped where the shipped policy is competent over
+    scale, thrust-to-weight, motor time constants, torque constant and inertia, read candidate training ranges off that boundary by
+    a rule fixed before the comparison, and ran the log's two evaluations with them and NO fitted constant
+    (profiles/r06_policy_competence.json): neither share terminated nor time to failure of `evaluation/*` or `crazyflie/*` falls
+    out.  The strict xfail rounds 3 - 5 kept on the crazyflie share (log 0.034, this specification 0.010) is retired with it: the
+    mismatch is a stated property of this specification, pinned by test_nominal_crazyflie_statistics_of_this_specification above,
+    and only the l2f sources - absent from the reference tree - can remove it."""
+    with open(_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "profiles", "r06_policy_competence.json")) as fh:
+        rec = _json.load(fh)
+    assert rec["verdict"].startswith("NOT REPRODUCED")
+    p = rec["predictions"]["no_fitted_constant_3m"]
+    for key in ("evaluation_competence_ranges", "evaluation_specification_ranges", "crazyflie_nominal"):
+        assert not (p[key]["fits_log"]["share"] and p[key]["fits_log"]["time_to_failure"]), key
+    assert rec["log"]["crazyflie"]["share_terminated"] == pytest.approx(REFERENCE_LOG_CRAZYFLIE["share_terminated"])
+    # the rule was applied as written: every range is a run of competent cells around the centre
+    for ax, r in rec["competence_ranges"].items():
+        one = rec["one_at_a_time"][ax]
+        inside = [c for v, c in zip(one["values"], one["competent"]) if r["range"][0] <= v <= r["range"][1]]
+        assert inside and all(inside), ax
+        assert r["range"][0] <= rec["centre"][ax] <= r["range"][1]
+
+
+def test_policy_competence_boundary_of_record(oracle, weights):
+    """Three cells of profiles/r06_policy_competence.json re-measured (same builder, same rule, fewer envs): the shipped policy
+    hovers the centre cell to 1.5 cm, loses vehicles below a thrust-to-weight of ~1.5 and cannot hold position beyond a torque
+    constant of ~0.03 s - where this specification's randomisation ranges end."""
+    import sys
+    sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
+    import policy_competence as pc
+    cfg = oracle.default_config()
+    cfg.termination_position = pc.LOST_M
+    rows = {}
+    for name, change in (("centre", {}), ("low_thrust", dict(t2w=1.3396)), ("high_kq", dict(kq=0.0528))):
+        cell = dict(pc.CENTRE)
+        cell.update(change)
+        rows[name] = pc.run(oracle, weights, cfg, pc.params_cell(1024, **cell), 11)
+    assert pc.competent(rows["centre"], 0.0) and rows["centre"]["steady_state_p_median"] < 0.02
+    assert not pc.competent(rows["low_thrust"], 0.0) and 0.2 < rows["low_thrust"]["share_terminated"] < 0.45
+    assert not pc.competent(rows["high_kq"], 0.0) and rows["high_kq"]["share_terminated"] > 0.7
+    # the cell builder against the specification's own sampler: the nominal Crazyflie differs from the centre cell only in its
+    # thrust constant and rotor speed range (same thrust-to-weight to 0.2 %)
+    cfg.domain_randomization = 0
+    P0 = oracle.sample_initial_parameters(cfg, 0, 0, 0, 1)[0]
+    Pc = pc.params_cell(1, **pc.CENTRE)[0]
+    assert np.allclose(Pc[:16], P0[:16], rtol=1e-6) and np.allclose(Pc[19:22], [0.006, 0.15, 0.15], rtol=1e-6)
+    t2w = lambda P: 4 * P[18] * P[23] ** 2 / (P[0] * 9.81)
+    assert abs(t2w(Pc) - 2.25) < 1e-3 and abs(t2w(P0) - 2.25) < 0.01
 
 
 # tolerance of the two crazyflie/* comparisons below: three standard errors of the log's pool plus this sample's own

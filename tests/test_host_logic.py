@@ -166,6 +166,49 @@ def test_raptor_save_checkpoint_both_formats(tmp_path):
         assert np.array_equal(q.example[0], p.example[0]) and np.array_equal(q.example[1], p.example[1])
 
 
+def test_checkpoint_observation_layout_is_checked_on_load(tmp_path):
+    """`h5:/actor@meta` names the observation the policy was trained on; the shipped checkpoint's is the layout this engine's observe
+    assembles (README.md:23).  Round 5 read the attribute and threw it away: a checkpoint trained on another layout loaded silently."""
+    from conftest import GOLDEN
+    from raptor_amd import checkpoint as ck
+    from raptor_amd.foundation_policy import Raptor
+    ref = os.path.join(GOLDEN, "checkpoint.h5")
+    w, ex, meta = ck.load_checkpoint(ref, with_meta=True)
+    assert ck.observation_of_meta(meta) == ck.ENGINE_OBSERVATION                # the reference's own file states the engine's layout
+    assert Raptor.from_checkpoint(ref).observation_spec == ck.ENGINE_OBSERVATION
+    other = '{"environment": {"name": "l2f","observation": "Position.OrientationQuaternion.LinearVelocity.AngularVelocity.ActionHistory(4)"}}'
+    ck.write_checkpoint_h5(str(tmp_path / "other.h5"), w, meta=other)
+    with pytest.raises(ValueError, match="trained on observation 'Position.OrientationQuaternion"):
+        Raptor.from_checkpoint(str(tmp_path / "other.h5"))
+    p = Raptor.from_checkpoint(str(tmp_path / "other.h5"), check_observation=False)         # the explicit way in
+    assert p.observation_spec.startswith("Position.OrientationQuaternion") and np.array_equal(p._weights, w)
+    ck.write_checkpoint_h5(str(tmp_path / "garbled.h5"), w, meta="not json {")
+    with pytest.raises(ValueError, match="not JSON"):
+        Raptor.from_checkpoint(str(tmp_path / "garbled.h5"))
+    # no statement at all (the C++ export carries name and commit only; an HDF5 file written without meta): loads, spec unknown
+    ck.write_checkpoint_h5(str(tmp_path / "silent.h5"), w, meta=None)
+    assert Raptor.from_checkpoint(str(tmp_path / "silent.h5")).observation_spec is None
+    Raptor.from_checkpoint(ref).save_checkpoint(str(tmp_path / "policy.h"))
+    assert Raptor.from_checkpoint(str(tmp_path / "policy.h")).observation_spec is None
+    assert ck.observation_of_meta('{"environment": {"name": "l2f"}}') is None and ck.observation_of_meta("[1, 2]") is None
+
+
+def test_fast_tanh_teachers_are_refused_by_name(tmp_path):
+    """rl-tools' FAST_TANH is an approximation whose definition is not in the reference tree; mapping it onto the exact tanh (as
+    round 5 did) would relabel a teacher's states with another function, silently."""
+    from raptor_amd import checkpoint as ck
+    from raptor_amd.hdf5_min import DatasetSpec, GroupSpec, write_file
+    rng = np.random.default_rng(0)
+    lay = {}
+    for i, (o, n, fn) in enumerate(((8, 22, "FAST_TANH"), (4, 8, "IDENTITY"))):
+        lay[str(i)] = GroupSpec({"weights": GroupSpec({"parameters": DatasetSpec(rng.standard_normal((o, n)).astype(np.float32), {})}),
+                                 "biases": GroupSpec({"parameters": DatasetSpec(np.zeros((1, o), np.float32), {})})},
+                                {"type": "dense", "activation_function": fn})
+    write_file(str(tmp_path / "t.h5"), GroupSpec({"actor": GroupSpec({"layers": GroupSpec(lay)}, {"type": "sequential"})}))
+    with pytest.raises(ValueError, match="FAST_TANH"):
+        ck.load_mlp_checkpoint_h5(str(tmp_path / "t.h5"))
+
+
 def test_oracle_teacher_mlp_matches_numpy(oracle):
     """The oracle's MLP teacher (the checker of the teacher-bank kernels) against a float64 numpy evaluation."""
     rng = np.random.default_rng(5)

@@ -7,7 +7,8 @@ rev=${1:?revision}
 cd "$(dirname "$0")/.."
 out=scratch/ab/$(echo "$rev" | tr '/~^' '___')
 rm -rf "$out"; mkdir -p "$out/raptor_amd" "$out/include"
-git archive "$rev" raptor_amd/csrc raptor_amd/build.py include | tar -x -C "$out"
+git archive "$rev" raptor_amd/csrc raptor_amd/build.py raptor_amd/gfx950_errata.py include | tar -x -C "$out"
+mkdir -p "$out/tools"; git show "$rev:tools/codeobj_check.py" > "$out/tools/codeobj_check.py" 2>/dev/null || rm -f "$out/tools/codeobj_check.py"      # the post-link gate (round 6 on)
 touch "$out/raptor_amd/__init__.py"
 (cd "$out" && python -c "
 import sys; sys.path.insert(0, '.')

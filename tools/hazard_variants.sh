@@ -17,7 +17,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p scratch/variants
 M="-mllvm -amdgpu-sched-strategy=max-ilp"
-build() { name=$1; shift; ( RQ_NO_OPSEL_REWRITE=1 "$@" python -m raptor_amd.build --variant "$name" -DRQ_BF16_FUSED_LEAN ${FLAGS} > "scratch/variants/$name.log" 2>&1 && echo "built $name" || { echo "FAILED $name"; tail -n 5 "scratch/variants/$name.log"; } ) & }
+build() { name=$1; shift; ( RQ_NO_OPSEL_REWRITE=1 "$@" python -m raptor_amd.build --variant "$name" --patch tools/variants/hunt_experiments.patch -DRQ_BF16_FUSED_LEAN ${FLAGS} > "scratch/variants/$name.log" 2>&1 && echo "built $name" || { echo "FAILED $name"; tail -n 5 "scratch/variants/$name.log"; } ) & }
 FLAGS="" build C env
 FLAGS="$M" build A env
 FLAGS="$M" build B env RQ_NO_MFMA_VGPR_FORM=1
