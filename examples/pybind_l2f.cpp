@@ -6,7 +6,7 @@
 //   g++ -O2 -std=c++17 -shared -fPIC $(python -m pybind11 --includes) -Iinclude examples/pybind_l2f.cpp \
 //       -Lraptor_amd -lraptor_quad -Wl,-rpath,$PWD/raptor_amd -o l2f_mi355x$(python3-config --extension-suffix)
 //
-// tests/test_gpu_parity.py::test_pybind11_binding_runs_the_readme_loop builds it and runs the README loop through
+// tests/test_gpu_boundary.py::test_pybind11_binding_runs_the_readme_loop builds it and runs the README loop through
 // it on the GPU, against the ctypes binding.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>

@@ -38,6 +38,9 @@
  *   (the reference is single-process) env shards over
  *     GPUs + all-gather of episode returns (RCCL)                rq_env_create(global_env_offset) / rq_comm_* / rq_allgather_returns
  *
+ * The entry points under "DIAGNOSTICS" at the end of this header (timers, per-wave records, launch floor, speculation knobs)
+ * replace nothing of the reference: they are this engine's own instrumentation and stand outside the drop-in table.
+ *
  * Conventions
  *   - Every function returns an int status: RQ_OK (0) or a negative rq_status; the message of
  *     the last failure on the calling thread is available from rq_last_error().  Nothing
@@ -185,44 +188,6 @@ RQ_API int rq_device_count(int* count);
 RQ_API int rq_device_create(int hip_device_ordinal, rq_device** out);
 RQ_API int rq_device_destroy(rq_device* dev);
 RQ_API int rq_device_synchronize(rq_device* dev);
-/* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
-RQ_API int rq_device_timer_start(rq_device* dev);
-RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
-/* Kernel-level timing of fused rollouts, off by default: while enabled every wave of a fused rollout kernel records the
- * wall-clock tick (constant 100 MHz) at which it came in and went out, and rq_device_last_rollout_ms returns, after waiting
- * for the most recent one, first-wave-in to last-wave-out on one die (the eight dies' counters are offset against one
- * another; the longest die counts).  rocprofv3's per-dispatch duration of the same launches (command processor takes the
- * dispatch -> the kernel's writes are released) reads a few microseconds more, by definition: bench.py carries both
- * (`roofline` / `roofline.wave_span`, DESIGN.md section 6). */
-RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
-RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
-/* The records themselves (a diagnostic: tools/wave_timeline.py): per wave w of the most recent timed fused rollout four
- * ticks, records[4 w + 0] = the wave came in, [4 w + 1] = it went out (bits 0..59; bits 60..62 = the die (XCD) it ran on),
- * [4 w + 2] = its first step was about to start, [4 w + 3] = its last step was done; 100 MHz, comparable within one die
- * only.  `records` = NULL: *n_waves only; otherwise it holds 4 * capacity values. */
-RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint32_t capacity, uint32_t* n_waves);
-/* The core clock (GHz) the most recent timed fused rollout ran its steps at: per wave, shader-clock cycles between its
- * first step's start and its last step's end over the same span in constant-rate ticks; the median over the waves that
- * stepped for at least a microsecond.  The clock follows the chip's load averaged over about a millisecond
- * (tools/idle_clock.py; measured: profiles/r04_idle_clock.txt), so a launch behind an idle gap runs slower than the same
- * launch in a busy loop.  (The three readers share one copy of the records per launch.) */
-RQ_API int rq_device_last_rollout_clock(rq_device* dev, float* core_ghz);
-/* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
- * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves
- * its own data (bench.py reports it beside the API-granular kernels' HBM fractions). */
-RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, float* us_per_launch);
-/* The small-batch loop's speculative policy step (README.md:96-99 at N < 1024 with host arrays): after a host-array
- * evaluate_step, every rq_step with a host action ALSO launches the policy the device last evaluated on the observation
- * the step just cached - next hidden state into a spare buffer of the policy, action rows into pinned memory - and the
- * following evaluate_step takes that result iff it is handed bit-identical rows, the same policy and an untouched policy
- * state.  Side effects a caller may see: one extra kernel launch per step on the device's stream, and the policy's
- * device-side action buffer overwritten by the speculated step.  A caller whose loop has another shape (perturbed
- * observations, alternating policies, env-only stepping) pays launches nobody uses: after 4 unused ones in a row the device
- * suspends speculation by itself and resumes when evaluate_step is again handed exactly the cached rows; enable = 0
- * switches it off for this device (RQ_NO_SPECULATION in the environment: off at rq_device_create), 1 on again.
- * rq_device_get_speculation: any out pointer may be NULL. */
-RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
-RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* suspended, uint32_t* consecutive_misses);
 /* raw hipStream_t of the device, for callers that enqueue their own work behind ours */
 RQ_API int rq_device_stream(rq_device* dev, void** hip_stream);
 
@@ -502,6 +467,50 @@ RQ_API int rq_allgather_returns(rq_env* env, rq_comm* comm);
 /* Wait for the most recently enqueued all-gather: device pointer to the [n_ranks * n_envs] result in global env
  * order (valid until the second next rq_allgather_returns), its length, and optionally a host copy. */
 RQ_API int rq_comm_gathered(rq_comm* comm, const float** dev_ptr, uint32_t* count, float* host_out);
+
+/* ==== DIAGNOSTICS - not part of the drop-in boundary =======================================================================
+ * Everything below is measurement instrumentation of THIS engine (bench.py, tools/): stopwatches, per-wave timing records of
+ * the fused kernel, the launch floor, and the knobs of the small-batch loop.  No call site of the reference corresponds to any
+ * of them and a reference-side binding would not bind them; they may change without an ABI bump
+ * of the drop-in entry points above. */
+/* HIP-event stopwatch on the device's own stream (what bench.py times kernels with). */
+RQ_API int rq_device_timer_start(rq_device* dev);
+RQ_API int rq_device_timer_stop(rq_device* dev, float* elapsed_ms);
+/* Kernel-level timing of fused rollouts, off by default: while enabled every wave of a fused rollout kernel records the
+ * wall-clock tick (constant 100 MHz) at which it came in and went out, and rq_device_last_rollout_ms returns, after waiting
+ * for the most recent one, first-wave-in to last-wave-out on one die (the eight dies' counters are offset against one
+ * another; the longest die counts).  rocprofv3's per-dispatch duration of the same launches (command processor takes the
+ * dispatch -> the kernel's writes are released) reads a few microseconds more, by definition: bench.py carries both
+ * (`roofline` / `roofline.wave_span`, DESIGN.md section 6). */
+RQ_API int rq_device_set_rollout_timing(rq_device* dev, int enable);
+RQ_API int rq_device_last_rollout_ms(rq_device* dev, float* kernel_ms);
+/* The records themselves (a diagnostic: tools/wave_timeline.py): per wave w of the most recent timed fused rollout four
+ * ticks, records[4 w + 0] = the wave came in, [4 w + 1] = it went out (bits 0..59; bits 60..62 = the die (XCD) it ran on),
+ * [4 w + 2] = its first step was about to start, [4 w + 3] = its last step was done; 100 MHz, comparable within one die
+ * only.  `records` = NULL: *n_waves only; otherwise it holds 4 * capacity values. */
+RQ_API int rq_device_last_rollout_waves(rq_device* dev, uint64_t* records, uint32_t capacity, uint32_t* n_waves);
+/* The core clock (GHz) the most recent timed fused rollout ran its steps at: per wave, shader-clock cycles between its
+ * first step's start and its last step's end over the same span in constant-rate ticks; the median over the waves that
+ * stepped for at least a microsecond.  The clock follows the chip's load averaged over about a millisecond
+ * (tools/idle_clock.py; measured: profiles/r04_idle_clock.txt), so a launch behind an idle gap runs slower than the same
+ * launch in a busy loop.  (The three readers share one copy of the records per launch.) */
+RQ_API int rq_device_last_rollout_clock(rq_device* dev, float* core_ghz);
+/* Diagnostic: average time per launch (us, HIP events) of `reps` back-to-back launches of a kernel that only
+ * stores one float per thread over n threads - what any standalone launch of that grid costs before it moves
+ * its own data (bench.py reports it beside the API-granular kernels' HBM fractions). */
+RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, float* us_per_launch);
+/* The small-batch loop's speculative policy step (README.md:96-99 at N < 1024 with host arrays): after a host-array
+ * evaluate_step, every rq_step with a host action ALSO launches the policy the device last evaluated on the observation
+ * the step just cached - next hidden state into a spare buffer of the policy, action rows into pinned memory - and the
+ * following evaluate_step takes that result iff it is handed bit-identical rows, the same policy and an untouched policy
+ * state.  Side effects a caller may see: one extra kernel launch per step on the device's stream, and the policy's
+ * device-side action buffer overwritten by the speculated step.  A caller whose loop has another shape (perturbed
+ * observations, alternating policies, env-only stepping) pays launches nobody uses: after 4 unused ones in a row the device
+ * suspends speculation by itself and resumes when evaluate_step is again handed exactly the cached rows; enable = 0
+ * switches it off for this device (RQ_NO_SPECULATION in the environment: off at rq_device_create), 1 on again.
+ * rq_device_get_speculation: any out pointer may be NULL. */
+RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
+RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* suspended, uint32_t* consecutive_misses);
 
 #ifdef __cplusplus
 }

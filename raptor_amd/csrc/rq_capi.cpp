@@ -30,7 +30,7 @@ thread_local std::string g_last_error;
 thread_local int tl_scope_depth = 0, tl_scope_device = -1;     // innermost live DeviceScope of this thread
 
 int fail(int status, const std::string& msg) {
-    g_last_error = msg;
+    try { g_last_error = msg; } catch (...) { g_last_error.clear(); }     // nothing throws across the boundary, not even the message
     return status;
 }
 
@@ -1215,7 +1215,12 @@ static int policy_upload(rq_policy* p) {
             p->w_eff[352 + o] = p->w_host[352 + o] - shift;
         }
     }
-    std::vector<float> packed(rq::RQ_PACKED_FLOATS), packed16(rq::RQ_PACKED_BF16_FLOATS), packed_split(rq::RQ_PACKED_F16X2_FLOATS);
+    std::vector<float> packed, packed16, packed_split;
+    try {                                   // nothing throws across the boundary
+        packed.resize(rq::RQ_PACKED_FLOATS); packed16.resize(rq::RQ_PACKED_BF16_FLOATS); packed_split.resize(rq::RQ_PACKED_F16X2_FLOATS);
+    } catch (const std::bad_alloc&) {
+        return fail(RQ_ERR_OUT_OF_MEMORY, "policy upload: host allocation failed");
+    }
     rq::pack_policy(p->w_eff, packed.data());
     rq::pack_policy_bf16(p->w_eff, packed16.data());
     rq::pack_policy_f16x2(p->w_eff, packed_split.data());
@@ -1324,7 +1329,8 @@ RQ_API int rq_policy_set_sample_and_squash(rq_policy* pol, int mode, const float
     RQ_REQUIRE(mode == RQ_SAS_OFF || mode == RQ_SAS_MEAN || mode == RQ_SAS_SAMPLE, RQ_ERR_INVALID_ARGUMENT, "unknown mode");
     if (mode == RQ_SAS_SAMPLE) {
         DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
-        std::vector<float> image(rq::RQ_LOGSTD_FLOATS);
+        std::vector<float> image;
+        try { image.resize(rq::RQ_LOGSTD_FLOATS); } catch (const std::bad_alloc&) { return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_set_sample_and_squash: host allocation failed"); }
         rq::pack_logstd_head(log_std_weights, log_std_bias, image.data());
         RQ_HIP(hipStreamSynchronize(pol->dev->stream));
         if (!pol->ls_image) RQ_HIP(hipMalloc(&pol->ls_image, image.size() * sizeof(float)));
@@ -1503,7 +1509,8 @@ RQ_API int rq_policy_selftest(rq_policy* pol, const float* input, const float* e
         rc = policy_upload(tmp);
         if (rc) { rq_policy_destroy(tmp); return rc; }
     }
-    std::vector<float> act((size_t)batch * RQ_ACTION_DIM);
+    std::vector<float> act;
+    try { act.resize((size_t)batch * RQ_ACTION_DIM); } catch (const std::bad_alloc&) { rq_policy_destroy(tmp); return fail(RQ_ERR_OUT_OF_MEMORY, "rq_policy_selftest: host allocation failed"); }
     float worst = 0.0f;
     for (uint32_t t = 0; t < steps && rc == RQ_OK; ++t) {
         rc = rq_policy_evaluate_step(tmp, nullptr, input + (size_t)t * batch * RQ_POLICY_INPUT_DIM, batch,
@@ -1627,9 +1634,14 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                     (void)hipGraphExecDestroy(env->graphs.front().exec);
                     env->graphs.erase(env->graphs.begin());
                 }
-                env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, env->obs, flags,
-                                       policy->precision, env->cfg, rng->seed, policy->sas_mode, policy->sas_seed,
-                                       policy->ls_image, exec});
+                try {                       // nothing throws across the boundary
+                    env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, env->obs, flags,
+                                           policy->precision, env->cfg, rng->seed, policy->sas_mode, policy->sas_seed,
+                                           policy->ls_image, exec});
+                } catch (const std::bad_alloc&) {
+                    (void)hipGraphExecDestroy(exec);
+                    return fail(RQ_ERR_OUT_OF_MEMORY, "rollout: host allocation failed");
+                }
             }
             RQ_HIP(rq::launch_set_u32(dev->stream, env->epoch_dev, rng->epoch));
             for (; done_steps + kGraphSteps <= n_steps; done_steps += kGraphSteps)

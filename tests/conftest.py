@@ -85,3 +85,10 @@ def kat(request):
 def device():
     import raptor_amd.l2f as l2f
     return l2f.Device(0)
+
+
+@pytest.fixture(scope="module")
+def w1k(device, oracle):
+    """A 1 000-env world on the GPU with its oracle mirror (tests/gpu_common.py), shared by the tests of a module."""
+    from gpu_common import World
+    return World(device, oracle, 1000)

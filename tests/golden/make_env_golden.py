@@ -3,7 +3,7 @@
 vector: nothing under /root/reference can produce one).  It records what oracle/raptor_oracle.c
 computes today for a small closed loop, so that a later change of the specification (operation order, a constant, the
 RNG layout) cannot happen silently: tests/test_oracle_env.py::test_env_spec_fixture replays it on the CPU bit for bit,
-tests/test_gpu_parity.py::test_env_spec_fixture_on_the_gpu feeds its (state, action) pairs to the HIP kernels.
+tests/test_gpu_env.py::test_env_spec_fixture_on_the_gpu feeds its (state, action) pairs to the HIP kernels.
 
     python tests/golden/make_env_golden.py        # rewrites tests/golden/env_spec.npz; commit it with the change
 """

@@ -3,7 +3,7 @@
 mixed length, every actor precision with and without the SampleAndSquash stage, every build that ships (fp32: one and two
 waves per SIMD; bf16 / split-f16: one) - the final state, policy state and episode statistics must agree bit for bit (round 4
 found a two-waves-per-SIMD bf16 build differing from run to run under another instruction scheduler; round 5 took it out of
-the product, profiles/r05_bf16_two_wave_hunt.md; tests/test_gpu_parity.py::test_fused_rollout_is_deterministic is the short
+the product, profiles/r05_bf16_two_wave_hunt.md; tests/test_gpu_fused.py::test_fused_rollout_is_deterministic is the short
 version of this).
     python tools/determinism_soak.py [--steps 3000]"""
 import argparse

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import raptor_amd.l2f as l2f                    # noqa: E402
 from oracle import oracle as O                  # noqa: E402   (World mirrors its inputs on the oracle side; nothing is computed there)
-from test_gpu_parity import World               # noqa: E402
+from gpu_common import World               # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=131072)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import raptor_amd.l2f as l2f
 from oracle import oracle as O
-from test_gpu_parity import World
+from gpu_common import World
 device = l2f.Device(0)
 n = 131072
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
