@@ -157,13 +157,15 @@ def pmc_key(kernel, n):
     return f"{kernel.replace(' ', '')}#n{n}"          # no blanks: demanglers differ in "> >" against ">>"
 
 
-def pmc_traffic(kernel, n):
+def pmc_traffic(kernel, n, library=None):
     """HBM bytes per launch of EXACTLY the kernel instantiation `kernel` (profiled name without its argument
     list, e.g. "rq::k_rollout_fused<false, true, false, rq::ActorF32T<false> >") at `n` envs, from the
     newest committed rocprofv3 PMC summary that has it (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE
     passes of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; the
     median over that kernel's launches, so the handful of warm-up launches of another length do not count).
-    None when no profile covers it."""
+    None when no profile covers it.  `same_library`: whether that summary was collected from the build loaded now (round 6: the
+    file carries `_library_sha256`); counters are not re-collected live, so a figure from another build is reported as such
+    and does not become the record's `traffic`."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
@@ -175,34 +177,69 @@ def pmc_traffic(kernel, n):
             legacy = f"{kernel}@{launch_grid(kernel, n)}".replace(" ", "")
             d = next((v for k, v in table.items() if k.replace(" ", "") == legacy and v.get("envs", n) == n), None)
         if d and d.get("hbm_bytes_per_launch_corrected"):
-            return {"bytes_per_launch": d["hbm_bytes_per_launch_corrected"],
+            return {"same_library": (table.get("_library_sha256") == library) if library else None,
+                    "bytes_per_launch": d["hbm_bytes_per_launch_corrected"],
                     "bytes_per_env": round(d["hbm_bytes_per_launch_corrected"] / n, 2), "source": os.path.basename(path),
                     "kernel": kernel, "profiled_launch_us": d.get("median_dur_us", d.get("avg_dur_us_fetch")),
                     "profiled_launches": d.get("calls_fetch")}
     return None
 
 
-def rocprof_launch_stats(kernel, n, steps):
+_library_hash = None
+
+
+def library_sha256():
+    """sha256 of the libraptor_quad.so this process loads (RAPTOR_QUAD_LIB honoured): what ties a committed profile to a build."""
+    global _library_hash
+    if _library_hash is None:
+        import hashlib
+        from raptor_amd import _lib
+        h = hashlib.sha256()
+        with open(_lib.LIB_PATH, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        _library_hash = h.hexdigest()
+    return _library_hash
+
+
+def traffic_of(tr):
+    """`traffic` of a record from pmc_traffic()'s answer: the counters' bytes per launch when the summary was collected from the
+    build loaded now; None (with the reason left in `traffic_source`) when it covers another build or nothing."""
+    if tr is None or tr.get("same_library") is False:
+        return None
+    return tr["bytes_per_launch"]
+
+
+def rocprof_launch_stats(kernel, n, steps, library=None, profiles_dir=None):
     """What rocprofv3 printed for the launches of `kernel` in the timed regions of this same command (newest committed
     profiles/rNN_fused_launch_stats.json, written by tools/summarize_profiles.py from the kernel trace: End - Start per
     dispatch).  The profiler's duration begins when the command processor takes the dispatch and ends when the kernel's
     writes are released; the waves' own clocks (`avg_launch_ms`) begin with their first instruction and end with their
-    last - ~2.6 us less for a 20-step launch.  None when no profile covers this kernel / step count."""
+    last - ~2.6 us less for a 20-step launch.
+    Round 6: a trace counts only for the BUILD it was taken from - the file carries the sha256 of the library that ran under
+    the profiler (`library_sha256`), and it is used iff that equals `library`, the hash of the library loaded now.  Rounds 1-5
+    matched on kernel NAME, env count and step count only, so a changed kernel with the same name inherited an old fraction.
+    -> (stats or None, reason why not)"""
     import glob
     import re
-    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_fused_launch_stats.json"))
+    paths = [p for p in glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*_fused_launch_stats.json"))
              if re.fullmatch(r"r\d+_fused_launch_stats\.json", os.path.basename(p))]
+    reason = "no committed rocprofv3 trace of this command (kernel, env count and steps per region must all match)"
     for path in sorted(paths, reverse=True):
         try:
             d = json.load(open(path))
             if int(d.get("steps", -1)) != int(steps) or int(d.get("envs_per_gpu") or -1) != int(n):
                 continue
             row = d[kernel.replace(" ", "")]["timed_region_launches"]
+            if library is not None and d.get("library_sha256") != library:
+                reason = (f"profiles/{os.path.basename(path)} was taken from another build of the library "
+                          f"(its sha256 {str(d.get('library_sha256'))[:12]}..., loaded {library[:12]}...)")
+                continue
             return {"launches": row["launches"], "mean_us": row["mean_us"], "median_us": row["median_us"],
-                    "source": os.path.basename(path), "command": d.get("command")}
+                    "source": os.path.basename(path), "command": d.get("command"), "library_sha256": d.get("library_sha256")}, None
         except Exception:
             continue
-    return None
+    return None, reason
 
 
 def fused_kernel_name(precision, n, steps_per_launch):
@@ -271,10 +308,10 @@ def sixteen_bit_roofline(precision, n, steps_per_launch, avg_launch_s):
     valu = (FLOP_GATES + FLOP_ENV) * n * steps_per_launch / avg_launch_s / 1e12
     mfma = FLOP_ACTOR * n * steps_per_launch / avg_launch_s / 1e12
     kname = fused_kernel_name(precision, n, steps_per_launch)
-    tr = pmc_traffic(kname, n)
+    tr = pmc_traffic(kname, n, library_sha256())
     return {"kernel": kname, "bound": "valu_issue", "achieved": round(valu, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / PEAK_FP32_TFLOPS, 4),
-            "traffic": None if tr is None else tr["bytes_per_launch"], "traffic_source": tr,
+            "traffic": traffic_of(tr), "traffic_source": tr,
             "note": f"fp32 VALU work only ({FLOP_GATES + FLOP_ENV} FLOP/env-step: gates + env) against the fp32 "
                     f"vector peak; the actor's {FLOP_ACTOR} FLOP/env-step run on the 16-bit MFMA pipe at "
                     f"{mfma:.1f} TFLOP/s = {mfma / PEAK_BF16_TFLOPS:.3f} of its 2.5 PFLOP/s dense peak"
@@ -335,14 +372,15 @@ def kernel_probe(device, n, reps):
         us, us_min, us_max = timed(fn)
         gbps = nbytes * n / (us * 1e-6) / 1e9
         tr = pmc_traffic({"k_observe": "rq::k_observe<false>", "k_actor_step": actor_step_kernel_name(n),
-                          "k_step": "rq::k_step<false>"}[name], n)
+                          "k_step": "rq::k_step<false>"}[name], n, library_sha256())
         out[name] = {"bound": "hbm", "us_per_launch": round(us, 3),
                      "us_per_launch_min_max": [round(us_min, 3), round(us_max, 3)], "statistic": "median of 20 batches",
                      "bytes_per_env": nbytes,
                      "achieved_GBps": round(gbps, 1), "peak_GBps": PEAK_HBM_GBPS,
                      "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                     "traffic": None if tr is None else tr["bytes_per_launch"],
-                     "traffic_bytes_per_env": None if tr is None else tr["bytes_per_env"]}
+                     "traffic": traffic_of(tr),
+                     "traffic_bytes_per_env": None if traffic_of(tr) is None else tr["bytes_per_env"],
+                     "traffic_same_library": None if tr is None else tr["same_library"]}
     # A standalone launch at 65 536 envs is launch-latency-bound and its 20-30 MB working set sits in the 256 MiB
     # Infinity Cache, so its fraction of the HBM peak is not a bandwidth statement.  Split it instead: back-to-back
     # launches of a kernel that only stores one float per thread on the same grid take `near_empty_launch_us` each
@@ -673,7 +711,10 @@ def cpu_baseline(seconds):
             "effective_cores": round(busy, 1),      # CPU-seconds per wall-second of the all-threads run: the container's quota
             "extras": extras,
             "sample": f"{n} envs x {steps} steps of the same workload (domain-randomised, auto-reset), "
-                      f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads_all} threads"
+                      f"oracle/raptor_oracle.c, gcc -O2 -march=x86-64-v3 -fopenmp, {threads_all} threads "
+                      "(deviation from BASELINE.md section 2, which planned -O3 -march=native: the oracle's .so is built once and "
+                      "travels to the GPU box, whose host CPU is another one - x86-64-v3 is the portable AVX2/FMA level - and -O2 "
+                      "because the env arithmetic is contract-ordered scalar fp32 (-ffp-contract=off) that -O3 does not vectorise further)"
                       + ("" if value_eff is None else f"; again with {eff} threads ({max(20, steps // 2)} steps); `value` is the faster run")}
 
 
@@ -1159,6 +1200,19 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
     stride = periods + max(1, periods // samples)
     launch_ms = kernel_probe_ms(plan, samples if args.mode == "fused" else min(len(walls), 50), stride=stride)
     launch_clock_ghz = probe_clock[0]
+    # the same launch between two HIP events on the engine's stream (torch's events would see torch's stream only): regions like the
+    # timed ones, every one bracketed; the events add their own ~2 us of stream work to what they measure
+    event_launch_ms = None
+    if args.mode == "fused" and hasattr(engine, "timer_start"):
+        ev = []
+        for _ in range(min(max(samples, 20), 60)):
+            sync_all()
+            engine.timer_start()
+            run(plan)
+            ev.append(engine.timer_stop() / len(plan))
+            finish()
+        sync_all()
+        event_launch_ms = float(np.mean(ev))
 
     flop_step = FLOP_PER_ENV_STEP if args.precision == "fp32" else FLOP_GATES + FLOP_ENV
 
@@ -1293,11 +1347,11 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         flop_per_launch = FLOP_PER_ENV_STEP * n * steps_per_launch
         achieved = flop_per_launch / avg_launch_s / 1e12
         kname = fused_kernel_name("fp32", n, steps_per_launch)
-        tr = pmc_traffic(kname, n)
+        tr = pmc_traffic(kname, n, library_sha256())
         result["roofline"] = {
             "kernel": kname, "bound": "mfma", "achieved": round(achieved, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-            "traffic": None if tr is None else tr["bytes_per_launch"],
+            "traffic": traffic_of(tr),
             "traffic_source": tr,
             "note": "compute-bound: state, hidden and constants stay in VGPRs for the whole launch; "
                     f"algorithmic {FLOP_PER_ENV_STEP} FLOP/env-step (actor {FLOP_ACTOR} + gates {FLOP_GATES} + "
@@ -1314,26 +1368,48 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
             "steps_per_launch": steps_per_launch,
             "hbm_bytes_per_env_step": round(BYTES_FUSED_LAUNCH / steps_per_launch, 3),
             "sq_counters": sq_profile("fp32")}
-        rp = rocprof_launch_stats(fused_kernel_name(args.precision, n, steps_per_launch), n, args.steps) if launches == 1 else None
-        result["roofline"]["frac_basis"] = ("wave span measured in this run (no committed rocprofv3 trace of this command: "
-                                            "kernel, env count and steps per region must all match)")
+        # ---- which clock the headline fraction is on (round 6: a record that cannot go stale) ----
+        # Three measurements of THIS run, flat so that the driver's `parsed` keeps them:
+        #   frac_in_run / avg_launch_ms_in_run       the kernel's own first-wave-in -> last-wave-out span (per-wave records)
+        #   frac_hip_events / avg_launch_ms_hip_events  HIP events on the engine's stream around the region's launch
+        #   frac_by_region                            the same flops over the timed region itself (= over ms_per_step x steps)
+        # and one from profiles/: rocprofv3's per-dispatch duration of this kernel in the timed regions of this same command.  The
+        # committed trace is the headline ONLY when it was taken from the very build loaded now (sha256 of the library recorded at
+        # profile time) - then a reader can recompute `frac` from profiles/ - otherwise the headline is this run's own span and
+        # `frac_basis` says why.  Rounds 1-5 matched the trace by kernel name, so a changed kernel kept an old fraction.
+        rl = result["roofline"]
+        rl["avg_launch_ms_in_run"] = round(avg_launch_s * 1e3, 4)
+        rl["frac_in_run"] = round(achieved / PEAK_FP32_TFLOPS, 4)
+        region_s = elapsed / len(plan)
+        rl["frac_by_region"] = round(flop_per_launch / region_s / 1e12 / PEAK_FP32_TFLOPS, 4)
+        if event_launch_ms:
+            rl["avg_launch_ms_hip_events"] = round(event_launch_ms, 4)
+            rl["frac_hip_events"] = round(flop_per_launch / (event_launch_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)
+        lib_hash = library_sha256() if engine.name == "hip" else None
+        rl["library_sha256"] = lib_hash
+        rp, why_not = (rocprof_launch_stats(kname, n, args.steps, lib_hash) if launches == 1 and lib_hash
+                       else (None, "not the one-launch-per-region command the committed traces are of"))
+        rl["frac_basis"] = f"wave span measured in this run ({why_not})"
         if rp:
-            # Round 5: the HEADLINE fraction is the one a reader can recompute from profiles/ - rocprofv3's per-dispatch duration
-            # (command processor takes the dispatch -> the kernel's writes are released) of this kernel in the timed regions of
-            # this same command, mean over the committed trace.  The kernel's own first-wave-in / last-wave-out span measured
-            # in THIS run (~2.6 us shorter per 20-step launch; it cannot see the dispatch and the end-of-kernel release) moves
-            # to `wave_span`, with the agreement between the two.
             rp_flops = flop_step * n * steps_per_launch / (rp["mean_us"] * 1e-6) / 1e12
-            result["roofline"]["wave_span"] = {"avg_launch_ms": round(avg_launch_s * 1e3, 4), "achieved": round(achieved, 3),
-                                               "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                                               "method": "rq_device_set_rollout_timing: first wave in -> last wave out on one die, "
-                                                         "mean over launches of this run's own regions",
-                                               "rocprofv3_mean_minus_wave_span_us": round(rp["mean_us"] - avg_launch_s * 1e6, 2)}
-            result["roofline"].update({"achieved": round(rp_flops, 3), "frac": round(rp_flops / PEAK_FP32_TFLOPS, 4),
-                                       "avg_launch_ms": round(rp["mean_us"] * 1e-3, 4),
-                                       "frac_basis": f"rocprofv3 --kernel-trace of this command, profiles/{rp['source']}: mean End - Start "
-                                                     f"of {rp['launches']} timed-region launches of this kernel"})
-            result["roofline"]["rocprofv3"] = rp
+            gap_us = rp["mean_us"] - avg_launch_s * 1e6
+            rl["wave_span"] = {"avg_launch_ms": round(avg_launch_s * 1e3, 4), "achieved": round(achieved, 3),
+                               "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                               "method": "rq_device_set_rollout_timing: first wave in -> last wave out on one die, "
+                                         "mean over launches of this run's own regions",
+                               "rocprofv3_mean_minus_wave_span_us": round(gap_us, 2)}
+            rl["rocprofv3"] = rp
+            # the profiler's clock also counts the dispatch and the end-of-kernel release: 2 - 5 us more than the waves' own span
+            # (measured 2.6 - 3.3).  Outside that window the trace and this run disagree about the kernel and the trace is not used.
+            if 0.0 <= gap_us <= 8.0:
+                rl.update({"achieved": round(rp_flops, 3), "frac": round(rp_flops / PEAK_FP32_TFLOPS, 4),
+                           "avg_launch_ms": round(rp["mean_us"] * 1e-3, 4),
+                           "frac_basis": f"rocprofv3 --kernel-trace of this command on this build (library sha256 {lib_hash[:12]}...), "
+                                         f"profiles/{rp['source']}: mean End - Start of {rp['launches']} timed-region launches of this kernel; "
+                                         f"this run's own span reads {gap_us:.1f} us less (frac_in_run)"})
+            else:
+                rl["frac_basis"] = (f"wave span measured in this run (profiles/{rp['source']} is of this build but reads {gap_us:.1f} us "
+                                    "away from this run's span: outside the 0 - 8 us the profiler's dispatch-to-release clock explains)")
         if launch_clock_ghz:
             # the peak assumes 2.4 GHz.  The clock these launches really ran their steps at (rq_device_last_rollout_clock:
             # shader-clock cycles over constant-rate ticks, median wave, mean over the probed launches): a launch that

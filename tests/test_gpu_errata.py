@@ -28,3 +28,25 @@ def test_fp32_results_do_not_depend_on_another_streams_16bit_rollouts():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 repetitions differ" in r.stdout
+
+
+def test_a_foreign_16bit_aggressor_and_a_foreign_fp32_victim_on_the_same_gpu(tmp_path):
+    """tools/foreign_soak.py (round 6): the fault has two directions when the GPU is shared with a learner.
+    (1) PyTorch's bf16 matmuls run without pause on torch's stream while this library repeats an fp32 chained rollout: bit for bit the
+    idle-GPU result (the product build holds no instruction of the form, tools/codeobj_check.py).  (2) This library's bf16 fused
+    rollouts - 16-bit MFMAs, one wave per SIMD with room for a small foreign wave beside it - run without pause while PyTorch repeats
+    fp32 workloads (an Adam-style elementwise update, layer_norm + gelu + softmax, an fp32 matmul): each must give, bit for bit, what
+    it gives on an idle GPU.  The measured outcome of both directions is profiles/r06_foreign_soak.json; INTEGRATION.md section 6
+    states what a learner sharing the GPU can rely on."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "soak.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "foreign_soak.py"), "--reps", "4", "--json", out],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))["results"]
+    ran = [x for x in res if "skipped" not in x]
+    assert any(x["direction"] == "torch_aggressor" for x in ran) and sum(x["direction"] == "torch_victim" for x in ran) >= 2
+    assert all(x["repetitions_that_differ"] == 0 for x in ran), ran

@@ -85,7 +85,11 @@ for (name, grid), d in sorted(pmc.items()):
                              "hbm_bytes_per_launch_corrected": traffic,
                              "envs": envs_of(name, grid),
                              "hbm_bytes_per_env": None if traffic is None else round(traffic / envs_of(name, grid), 2)}
+# which build ran under the profiler (round 6): bench.py uses a committed summary only for the build it was taken from
+from bench import library_sha256                   # noqa: E402
+out["_library_sha256"] = library_sha256()
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+out.pop("_library_sha256")
 
 for fn in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
     p = os.path.join(src, fn)
@@ -111,7 +115,10 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
                 per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         f.write("\n## `k_rollout_fused`, per instantiation (us per launch, from the kernel trace)\n\n"
                 "| instantiation | launches | mean | median | min | max |\n|---|---|---|---|---|---|\n")
-        launch_stats = {"command": cmd, "steps": b["steps"], "envs_per_gpu": b.get("config", {}).get("envs_per_gpu"), "source": "rocprofv3 --kernel-trace, End - Start per dispatch (us)"}
+        launch_stats = {"command": cmd, "steps": b["steps"], "envs_per_gpu": b.get("config", {}).get("envs_per_gpu"), "source": "rocprofv3 --kernel-trace, End - Start per dispatch (us)",
+                        # the build that ran under the profiler, as the profiled run itself reported it; bench.py takes its headline
+                        # fraction from this file only when the library it has loaded hashes to the same value
+                        "library_sha256": b.get("roofline", {}).get("library_sha256") or library_sha256()}
         for name, d in sorted(per.items()):
             ds = sorted(d)
             f.write(f"| `{name}` | {len(d)} | {sum(d) / len(d):.2f} | {ds[len(ds) // 2]:.2f} | {ds[0]:.2f} | {ds[-1]:.2f} |\n")
