@@ -232,8 +232,10 @@ def rocprof_launch_stats(kernel, n, steps, library=None, profiles_dir=None):
                 continue
             row = d[kernel.replace(" ", "")]["timed_region_launches"]
             if library is not None and d.get("library_sha256") != library:
-                reason = (f"profiles/{os.path.basename(path)} was taken from another build of the library "
-                          f"(its sha256 {str(d.get('library_sha256'))[:12]}..., loaded {library[:12]}...)")
+                if "another build" not in reason:          # the newest such trace is the one worth naming
+                    theirs = d.get("library_sha256")
+                    reason = (f"profiles/{os.path.basename(path)} was taken from another build of the library "
+                              f"({'it records no sha256' if not theirs else 'its sha256 ' + theirs[:12] + '...'}; loaded {library[:12]}...)")
                 continue
             return {"launches": row["launches"], "mean_us": row["mean_us"], "median_us": row["median_us"],
                     "source": os.path.basename(path), "command": d.get("command"), "library_sha256": d.get("library_sha256")}, None

@@ -216,8 +216,8 @@ struct rq_teacher_bank {
     float* images_f32 = nullptr;     // [n_teachers][teacher_image_regs_f32 * 64]
     float* images_bf16 = nullptr;    // [n_teachers][teacher_image_regs_bf16 * 64]
     float* images_f16x2 = nullptr;   // [n_teachers][teacher_image_regs_f16x2 * 64]
-    uint32_t* tiles = nullptr;       // device: tile_teacher [cap] followed by tile_env [cap][16]
-    uint32_t tile_capacity = 0;
+    uint32_t* tiles = nullptr;       // device: tile_teacher [tiles] followed by tile_env [tiles][16]; dense stacks: teacher_start | sorted_env
+    size_t tile_words = 0;           // its capacity in 32-bit words
     // the generic dense stack (rq_teacher_bank_create_layers outside the register-stationary family): fp32, operands streamed
     bool layers = false;
     uint32_t n_hidden = 2, widths[3] = {0, 0, 0}, hp = 0;
@@ -1922,28 +1922,43 @@ RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* ban
     // order kept inside a teacher, so sorted inputs give contiguous tiles and coalesced rows)
     for (uint32_t i = 0; i < n; ++i)
         RQ_REQUIRE(teacher_id[i] < bank->n_teachers, RQ_ERR_INVALID_ARGUMENT, "teacher id out of range");
-    std::vector<uint32_t> host;             // tile_teacher [n_tiles] | tile_env [n_tiles][16]
+    // register-stationary family: tile_teacher [n_tiles] | tile_env [n_tiles][16] (a tile = up to 16 envs of ONE teacher);
+    // dense stacks (round 6): teacher_start [n_teachers + 1] | sorted_env [n] - the kernel forms its 16-wide tiles out of (env, step) pairs
+    std::vector<uint32_t> host;
     uint32_t n_tiles = 0;
+    if (bank->layers)
+        RQ_REQUIRE((uint64_t)n * t->length < (1ull << 32), RQ_ERR_INVALID_ARGUMENT, "envs x steps must stay below 2^32 for a dense-stack bank");
     try {                                   // nothing throws across the boundary
         std::vector<uint32_t> count(bank->n_teachers, 0), start(bank->n_teachers, 0), filled(bank->n_teachers, 0);
         for (uint32_t i = 0; i < n; ++i) ++count[teacher_id[i]];
-        for (uint32_t k = 0; k < bank->n_teachers; ++k) { start[k] = n_tiles; n_tiles += (count[k] + 15u) / 16u; }
-        host.assign((size_t)n_tiles * 17, 0xFFFFFFFFu);
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t k = teacher_id[i], pos = filled[k]++;
-            const uint32_t tile = start[k] + pos / 16u;
-            host[tile] = k;
-            host[(size_t)n_tiles + (size_t)tile * 16 + pos % 16u] = i;
+        if (bank->layers) {
+            host.assign((size_t)bank->n_teachers + 1 + n, 0u);
+            uint32_t at = 0;
+            for (uint32_t k = 0; k < bank->n_teachers; ++k) { host[k] = start[k] = at; at += count[k]; }
+            host[bank->n_teachers] = at;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t k = teacher_id[i];
+                host[(size_t)bank->n_teachers + 1 + start[k] + filled[k]++] = i;
+            }
+        } else {
+            for (uint32_t k = 0; k < bank->n_teachers; ++k) { start[k] = n_tiles; n_tiles += (count[k] + 15u) / 16u; }
+            host.assign((size_t)n_tiles * 17, 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t k = teacher_id[i], pos = filled[k]++;
+                const uint32_t tile = start[k] + pos / 16u;
+                host[tile] = k;
+                host[(size_t)n_tiles + (size_t)tile * 16 + pos % 16u] = i;
+            }
         }
     } catch (const std::bad_alloc&) {
         return fail(RQ_ERR_OUT_OF_MEMORY, "rq_trajectory_relabel_teachers: host allocation failed");
     }
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;
-    if (bank->tile_capacity < n_tiles) {
+    if (bank->tile_words < host.size()) {
         RQ_HIP(hipStreamSynchronize(dev->stream));
-        if (bank->tiles) { RQ_HIP(hipFree(bank->tiles)); bank->tiles = nullptr; bank->tile_capacity = 0; }
-        RQ_HIP(hipMalloc(&bank->tiles, (size_t)n_tiles * 17 * sizeof(uint32_t)));
-        bank->tile_capacity = n_tiles;
+        if (bank->tiles) { RQ_HIP(hipFree(bank->tiles)); bank->tiles = nullptr; bank->tile_words = 0; }
+        RQ_HIP(hipMalloc(&bank->tiles, host.size() * sizeof(uint32_t)));
+        bank->tile_words = host.size();
     }
     RQ_HIP(hipMemcpyAsync(bank->tiles, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev->stream));
     RQ_HIP(hipStreamSynchronize(dev->stream));                // `host` is pageable and about to go out of scope
@@ -1960,8 +1975,9 @@ RQ_API int rq_trajectory_relabel_teachers(rq_trajectory* t, rq_teacher_bank* ban
     const float* images = bank->precision == RQ_POLICY_BF16_MFMA ? bank->images_bf16
                         : bank->precision == RQ_POLICY_F16X2_MFMA ? bank->images_f16x2 : bank->images_f32;
     if (bank->layers)
-        RQ_HIP(rq::launch_teacher_relabel_layers(dev->stream, n_tiles, env->ld, t->length, bank->in_dim, bank->n_hidden, bank->hp, bank->act,
-                                                 bank->out_act, bank->images_layers, bank->tiles, bank->tiles + n_tiles, t->obs, d_act));
+        RQ_HIP(rq::launch_teacher_relabel_layers(dev->stream, bank->n_teachers, n, env->ld, t->length, bank->in_dim, bank->n_hidden, bank->hp,
+                                                 bank->act, bank->out_act, bank->images_layers, bank->tiles, bank->tiles + bank->n_teachers + 1,
+                                                 t->obs, d_act));
     else
     RQ_HIP(rq::launch_teacher_relabel(dev->stream, n_tiles, env->ld, t->length, bank->in_dim, bank->h1, bank->h2, bank->act,
                                       bank->out_act, bank->precision, images, bank->tiles, bank->tiles + n_tiles, t->obs,

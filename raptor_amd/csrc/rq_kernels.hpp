@@ -226,9 +226,10 @@ constexpr int teacher_image_regs_f16x2(int h1, int h2) {
 void pack_teacher_f32(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
 void pack_teacher_bf16(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
 void pack_teacher_f16x2(const float* w, int in_dim, int h1, int h2, int act, int out_act, float* image);
-// the generic dense stack (rq_teacher.hip k_teacher_relabel_layers): hidden layers padded to hp = 64 or 128 units, fp32 operands streamed
+// the generic dense stack (rq_teacher.hip k_teacher_relabel_layers): hidden layers padded to hp = 64 or 128 units, the fp32 image resident in LDS
+// (layer 1 [6][hp/16][64] | per further hidden layer [hp/4][hp/16][64] + [hp] biases | output [hp/16][64][4] + [4] biases)
 constexpr size_t teacher_layers_image_floats(int hp, int n_hidden) {
-    return (size_t)6 * (hp / 16) * 64 + (size_t)(n_hidden - 1) * ((size_t)(hp / 4) * (hp / 16) * 64 + (size_t)(hp / 16) * 4 * 64) + (size_t)(hp / 4) * 64 + 4 * 64;
+    return (size_t)6 * (hp / 16) * 64 + (size_t)(n_hidden - 1) * ((size_t)(hp / 4) * (hp / 16) * 64 + (size_t)hp) + (size_t)(hp / 16) * 64 * 4 + 4;
 }
 inline size_t teacher_layers_param_count(int in_dim, int n_hidden, const uint32_t* widths) {
     size_t n = 0;
@@ -238,9 +239,10 @@ inline size_t teacher_layers_param_count(int in_dim, int n_hidden, const uint32_
 }
 // one teacher's parameters [W1 | b1 | ... | W_out | b_out] (rows = outputs) -> its streamed image
 void pack_teacher_layers(const float* w, int in_dim, int n_hidden, const uint32_t* widths, int hp, int act, int out_act, float* image);
-hipError_t launch_teacher_relabel_layers(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
-                                         uint32_t hp, int act, int out_act, const float* images, const uint32_t* tile_teacher,
-                                         const uint32_t* tile_env, const float* obs, float* actions);
+// teacher_start [n_teachers + 1] into sorted_env [n_envs] (the envs grouped by teacher): a column of a teacher = one (env, step) pair
+hipError_t launch_teacher_relabel_layers(hipStream_t s, uint32_t n_teachers, uint32_t n_envs, uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                         uint32_t n_hidden, uint32_t hp, int act, int out_act, const float* images,
+                                         const uint32_t* teacher_start, const uint32_t* sorted_env, const float* obs, float* actions);
 inline size_t teacher_param_count(int in_dim, int h1, int h2) {
     return (size_t)h1 * in_dim + h1 + (size_t)h2 * h1 + h2 + (size_t)4 * h2 + 4;
 }

@@ -297,19 +297,20 @@ void pack_teacher_layers(const float* w, int in_dim, int n_hidden, const uint32_
                         const int row = 16 * (4 * g + u) + i, col = 16 * (k / 4) + 4 * q + (k % 4);
                         p[((size_t)(k * G + g) * 64 + l) * 4 + u] = (row < rows[layer] && col < cols[layer]) ? kh * W[layer][(size_t)row * cols[layer] + col] : 0.0f;
                     }
-            float* pb = p + (size_t)K * M * 64;
-            for (int m = 0; m < M; ++m)
-                for (int r = 0; r < 4; ++r) {
-                    const int unit = 16 * m + 4 * q + r;
-                    pb[(size_t)(m * 4 + r) * 64 + l] = unit < rows[layer] ? kh * b[layer][unit] : 0.0f;
-                }
-            p += (size_t)K * M * 64 + (size_t)M * 4 * 64;
+            if (l == 0) {
+                float* pb = p + (size_t)K * M * 64;                       // the layer's biases, one float per (padded) unit
+                for (int unit = 0; unit < hp; ++unit) pb[unit] = unit < rows[layer] ? kh * b[layer][unit] : 0.0f;
+            }
+            p += (size_t)K * M * 64 + (size_t)hp;
         }
-        for (int k = 0; k < K; ++k) {
-            const int col = 16 * (k / 4) + 4 * q + (k % 4);
-            p[(size_t)k * 64 + l] = (i < 4 && col < cols[n_hidden]) ? ko * W[n_hidden][(size_t)i * cols[n_hidden] + col] : 0.0f;
-        }
-        for (int r = 0; r < 4; ++r) p[(size_t)(K + r) * 64 + l] = q == 0 ? ko * b[n_hidden][r] : 0.0f;
+        // output layer for v_mfma_f32_4x4x1_16b_f32: lane 16 q + 4 g + i is row i of block (q, g); element r of quad m multiplies unit 16 m + 4 q + r
+        for (int m = 0; m < M; ++m)
+            for (int r = 0; r < 4; ++r) {
+                const int row = l & 3, col = 16 * m + 4 * q + r;
+                p[((size_t)m * 64 + l) * 4 + r] = col < cols[n_hidden] ? ko * W[n_hidden][(size_t)row * cols[n_hidden] + col] : 0.0f;
+            }
+        if (l == 0)
+            for (int r = 0; r < 4; ++r) p[(size_t)M * 64 * 4 + r] = ko * b[n_hidden][r];
     }
 }
 

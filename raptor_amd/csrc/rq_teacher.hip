@@ -400,64 +400,137 @@ __global__ __launch_bounds__(64, 2) void k_teacher_relabel_f16x2(uint32_t ld, ui
     }
 }
 
-// ---- any stack of dense layers (round 5): in -> w1 -> [w2 -> [w3]] -> 4, widths multiples of 16 up to 128 --------------------
+// ---- any stack of dense layers: in -> w1 -> [w2 -> [w3]] -> 4, widths multiples of 16 up to 128 --------------------------------
 // What a teacher checkpoint in the reference's HDF5 layout may hold (`sequential` of `dense` layers, README.md:211-216) beyond the
 // register-stationary family above: one or three hidden layers, widths up to 128.  Such a teacher's operands do not fit a wave's
-// registers (22-128-128-128-4: 146 KB), so they are STREAMED: every hidden layer is padded to HP = 64 or 128 units (zero rows and
-// columns: exact), the image holds the A operands in the order the loop consumes them - four row tiles of one K-step per lane as one
-// 16-byte load - and stays in L2 for the tile's slice of the trajectory.  Same tile / step-slice mapping, same layouts and the same
-// exact-f32 MFMA as k_teacher_relabel_f32; fp32 only.  Image (floats, per teacher; M = HP / 16, K = HP / 4):
-//   layer 1      [6][M / 4][64 lanes][4]   A(row 16 m + i, feature 4 s + q), feature in_dim = the bias (B operand 1)
-//   per further hidden layer: [K][M / 4][64][4] A(row 16 m + i, unit 16 (k / 4) + 4 q + k % 4), then [M][4][64] the bias quads
-//   output       [K][64] (rows >= 4 zero), then [4][64] its bias quad (lane group 0 only)
-// Round 5, second version.  The first streamed every operand from L2 per wave and step (22-128-128-128-4: 146 KB per tile-step, four
-// step-slices of a tile each on their own: 0.33 of the f32 MFMA peak, L2-bound).  Now a WORKGROUP of four waves owns a tile - wave w
-// labels step-slice w of it - and shares the teacher's operands through LDS: a layer's image (HP = 128: 64 KB + 8 KB of bias quads) is
-// copied in once per workgroup and PAIR of steps, read back as 16-byte quads (a lane's four row tiles of one K-step), and every A operand
-// feeds two MFMAs (the wave's two steps in flight): a quarter of the L2 traffic per wave for sharing, half again for pairing.  Two
-// workgroups per CU (2 x 72 KB of LDS): one computes while the other copies.
+// registers (22-128-128-128-4: 146 KB); every hidden layer is padded to HP = 64 or 128 units (zero rows and columns: exact).  Same
+// layouts and the same exact-f32 MFMA as k_teacher_relabel_f32; fp32 only.
+//
+// Round 6: THE TEACHER IS RESIDENT IN LDS.  Round 5 staged one layer at a time (72 KB) per workgroup and PAIR of steps: the 156 KB
+// image of a 22-128-128-128-4 teacher crossed the fabric once per 8 labelled steps of a 16-env tile - 49.8 GB per launch against 3.4 GB
+// of observations (profiles/r05_pmc.json: 14.6 x the algorithmic traffic), six barriers per pair, and it showed where there is little
+// arithmetic to hide behind (22-128-4: 0.29 of the f32 MFMA peak).  Now a workgroup of eight waves belongs to ONE TEACHER (x one chunk
+// of its labels): it copies the whole image into LDS once - 150 KB for three 128-unit layers, the biases as one float per unit instead
+// of a quad per lane, which is what makes it fit the CU's 160 KB - passes ONE barrier, and labels its columns without ever meeting the
+// other waves again.  Traffic: the image once per workgroup (1 000 teachers x 2 chunks x 150 KB = 0.3 GB) + the observations.
+//
+// A COLUMN is one (env, step) pair of the teacher: column c of teacher k = (step c / n_k, the (c % n_k)-th env of the teacher), so a
+// 16-column MFMA tile takes whatever envs and steps come next - a teacher with 66 envs fills 16-wide tiles to the last one of its
+// 33 000 labels, where round 5's tiles of 16 ENVS left the fifth tile of such a teacher 7/8 empty at every step (contiguous
+// assignment: 0.82 of the tiles' columns used).  Consecutive columns are consecutive envs of one step: the loads stay coalesced.
+//
+// The output layer (HP -> 4) on v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 x 1 blocks per instruction, block b = lane / 4.
+// The hidden activations sit in the "Q layout" (lane 16 q + j holds units 16 m + 4 q + r of column j): read as the B operand of the
+// block instruction, lane 16 q + 4 g + jj is column 4 g + jj of block (q, g), so ONE instruction per (m, r) multiplies the unit
+// 16 m + 4 q + r of every column by the four output rows - 32 instructions of 8 cycles for HP = 128 where the 16x16x4 form spent 32
+// of 32 cycles with twelve of its sixteen rows zero.  Each lane group q ends with its quarter of the sum; two lane-group exchanges add
+// them.  (22-128-4: 80 -> 56 MFMA-equivalents of issue time per tile.)
+//
+// Image (floats, per teacher; M = HP / 16, K = HP / 4, G = M / 4):
+//   layer 1      [6][G][64 lanes][4]   A(row 16 (4 g + u) + i, feature 4 s + q), feature in_dim = the bias (B operand 1)
+//   per further hidden layer: [K][G][64][4] A(row 16 (4 g + u) + i, unit 16 (k / 4) + 4 q + k % 4), then [HP] the biases
+//   output       [M][64][4]: lane 16 q + 4 g + i, element r of quad m = W_out(i, 16 m + 4 q + r); then [4] its biases
+// HP = 128: eight waves share the one image a CU's LDS holds (two per SIMD, 256 registers each); HP = 64: workgroups of four waves,
+// three of them per CU (3 x 43.5 KB of LDS, 153 registers: a fourth wave per SIMD would spill)
+template <int HP> struct LayersBlock { static constexpr int threads = HP == 64 ? 256 : 512, waves_per_simd = HP == 64 ? 3 : 2; };
+
+template <int HP>
+struct LayersImage {
+    static constexpr int M = HP / 16, K = HP / 4, G = M / 4;
+    static constexpr int l1 = 6 * M * 64, hidden = K * M * 64 + HP, out = M * 64 * 4 + 4;
+    static constexpr int total(int n_hidden) { return l1 + (n_hidden - 1) * hidden + out; }
+};
+
 template <int HP, int ACT, int OUT_ACT>
-__global__ __launch_bounds__(256, 2) void k_teacher_relabel_layers(uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
-                                                                   uint32_t image_floats, const float* __restrict__ images,
-                                                                   const uint32_t* __restrict__ tile_teacher,
-                                                                   const uint32_t* __restrict__ tile_env,
+__global__ __launch_bounds__(LayersBlock<HP>::threads, LayersBlock<HP>::waves_per_simd) void k_teacher_relabel_layers(uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
+                                                                   const float* __restrict__ images,
+                                                                   const uint32_t* __restrict__ teacher_start,
+                                                                   const uint32_t* __restrict__ sorted_env,
                                                                    const float* __restrict__ obs, float* __restrict__ act) {
-    constexpr int M = HP / 16, K = HP / 4, G = M / 4;
-    constexpr int kLayerFloats = K * M * 64 + M * 4 * 64;          // the largest piece staged at once: a hidden layer + its bias quads
+    typedef LayersImage<HP> I;
+    constexpr int M = I::M, K = I::K, G = I::G, kLayersBlock = LayersBlock<HP>::threads;
     typedef float f32q __attribute__((ext_vector_type(4)));
-    __shared__ f32q stage[kLayerFloats / 4];
+    __shared__ f32q image[I::total(3) / 4];
+    const uint32_t k_teacher = blockIdx.x;
+    const uint32_t first = teacher_start[k_teacher], count = teacher_start[k_teacher + 1] - first;
+    if (count == 0) return;                                             // workgroup-uniform, before the barrier
+    const uint32_t cols = count * steps;
+    uint32_t per = (cols + gridDim.y - 1) / gridDim.y;
+    per = (per + 15u) & ~15u;
+    const uint32_t c_begin = blockIdx.y * per;
+    if (c_begin >= cols) return;
+    const uint32_t c_end = c_begin + per < cols ? c_begin + per : cols;
+    {   // the teacher moves in: once per workgroup
+        const int floats = I::total((int)n_hidden);
+        const f32q* src = reinterpret_cast<const f32q*>(images + (size_t)k_teacher * floats);
+        for (int i = threadIdx.x; i < floats / 4; i += kLayersBlock) image[i] = src[i];
+    }
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t slices = gridDim.y * 4u;
-    const uint32_t per = (steps + slices - 1) / slices;                 // steps per wave: the same trip count for the four waves
-    const uint32_t t_begin = (blockIdx.y * 4u + wave) * per;
-    const uint32_t t_end = t_begin + per < steps ? t_begin + per : steps;          // may be <= t_begin: that wave only helps copying
-    const float* img = images + (size_t)tile_teacher[tile] * image_floats;
-    const uint32_t e0 = tile_env[tile * 16 + j];
-    const bool valid = e0 != 0xFFFFFFFFu;
-    const uint32_t e = valid ? e0 : 0u;
-    const InputPlan in(ld, e, q, in_dim);
-    auto copy_in = [&](const float* src, int floats) {                  // every thread of the workgroup: 16 bytes per turn
-        const f32q* s4 = reinterpret_cast<const f32q*>(src);
-        for (int i = threadIdx.x; i < floats / 4; i += 256) stage[i] = s4[i];
+    constexpr uint32_t kWaves = kLayersBlock / 64;
+    constexpr uint32_t kStride = 16u * 2u * kWaves;                     // columns between a wave's consecutive tile pairs
+    // this lane's column of the wave's first tile pair, as (step, index into the teacher's env list); later pairs add kStride
+    const uint32_t dq = kStride / count, dr = kStride % count;
+    uint32_t c[2], t[2], idx[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        c[p] = c_begin + (wave * 2u + p) * 16u + j;
+        t[p] = c[p] / count;
+        idx[p] = c[p] - t[p] * count;
+    }
+    uint32_t foff[6];                                                   // feature row offsets (elements); rows >= in_dim read row 0
+    uint32_t fs[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) { fs[s] = 4 * s + q; foff[s] = (fs[s] < in_dim ? fs[s] : 0u) * ld; }
+    const uint32_t last_t = (cols - 1) / count, last_i = (cols - 1) - last_t * count;
+    auto load = [&](int p, float (&x)[6], uint32_t& env, uint32_t& step) {
+        // a column past the end of this workgroup's share reads the teacher's last column (a valid address) and is not stored
+        const bool in = c[p] < c_end;
+        step = in ? t[p] : last_t;
+        env = sorted_env[first + (in ? idx[p] : last_i)];
+        const float* base = obs + (size_t)step * RQ_POLICY_INPUT_DIM * ld + env;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) x[s] = base[foff[s]];
     };
-    auto clamp_t = [&](uint32_t t) { return t < steps ? t : steps - 1; };
-    for (uint32_t it = 0; it < per; it += 2) {                          // workgroup-uniform
-        const uint32_t t0 = t_begin + it, t1 = t0 + 1;
+    auto finish = [&](float (&x)[6]) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) x[s] = fs[s] < in_dim ? x[s] : (fs[s] == in_dim ? 1.0f : 0.0f);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            c[p] += kStride; t[p] += dq; idx[p] += dr;
+            if (idx[p] >= count) { idx[p] -= count; t[p] += 1; }
+        }
+    };
+    const uint32_t wave_c0 = c_begin + wave * 32u;                      // wave-uniform loop bound: the first column of the wave's pair
+    float Xn[2][6];
+    uint32_t env_n[2], step_n[2];
+    load(0, Xn[0], env_n[0], step_n[0]);
+    load(1, Xn[1], env_n[1], step_n[1]);
+    for (uint32_t base_c = wave_c0; base_c < c_end; base_c += kStride) {
         float X[2][6];
-        in.load(obs, clamp_t(t0), X[0]);
-        in.load(obs, clamp_t(t1), X[1]);
-        __syncthreads();                                                // the previous pair is done with the staging buffer
-        copy_in(img, 6 * M * 64);
-        in.finish(X[0]);
-        in.finish(X[1]);
-        __syncthreads();
+        uint32_t env[2], step[2];
+        bool live[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) X[p][s] = Xn[p][s];
+            env[p] = env_n[p]; step[p] = step_n[p]; live[p] = c[p] < c_end;
+        }
+        advance();
+        if (base_c + kStride < c_end) {                                 // the next pair's observations travel while this one computes
+            load(0, Xn[0], env_n[0], step_n[0]);
+            load(1, Xn[1], env_n[1], step_n[1]);
+        }
+        finish(X[0]);
+        finish(X[1]);
         f32x4 y[2][M];
 #pragma unroll
         for (int s = 0; s < 6; ++s)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const f32q a = stage[(s * G + g) * 64 + lane];
+                const f32q a = image[(s * G + g) * 64 + lane];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -470,22 +543,20 @@ __global__ __launch_bounds__(256, 2) void k_teacher_relabel_layers(uint32_t ld, 
             for (int m = 0; m < M; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[p][m][r] = teacher_act<ACT>(y[p][m][r]);
-        const float* src = img + 6 * M * 64;
-        for (uint32_t layer = 1; layer < n_hidden; ++layer) {          // workgroup-uniform trip count
-            __syncthreads();
-            copy_in(src, kLayerFloats);
-            __syncthreads();
+        const f32q* src = image + I::l1 / 4;
+        for (uint32_t layer = 1; layer < n_hidden; ++layer) {          // wave-uniform trip count
             f32x4 z[2][M];
-            const float* pb = reinterpret_cast<const float*>(stage) + K * M * 64 + lane;
+            const f32q* pb = src + K * M * 64 / 4 + q;                   // bias quad of units 16 m + 4 q .. + 3: element m * 4 + q
 #pragma unroll
-            for (int m = 0; m < M; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z[0][m][r] = z[1][m][r] = pb[(m * 4 + r) * 64];
+            for (int m = 0; m < M; ++m) {
+                const f32q b4 = pb[m * 4];
+                z[0][m] = z[1][m] = f32x4{b4[0], b4[1], b4[2], b4[3]};
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const f32q w = stage[(k * G + g) * 64 + lane];
+                    const f32q w = src[(k * G + g) * 64 + lane];
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -498,45 +569,53 @@ __global__ __launch_bounds__(256, 2) void k_teacher_relabel_layers(uint32_t ld, 
                 for (int m = 0; m < M; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[p][m][r] = teacher_act<ACT>(z[p][m][r]);
-            src += kLayerFloats;
+            src += I::hidden / 4;
         }
-        __syncthreads();
-        copy_in(src, K * 64 + 4 * 64);
-        __syncthreads();
-        const float* po = reinterpret_cast<const float*>(stage) + lane;
-        f32x4 o[2];
-        o[0] = o[1] = f32x4{po[(K + 0) * 64], po[(K + 1) * 64], po[(K + 2) * 64], po[(K + 3) * 64]};
+        // output layer on the 4x4x1 block form: two accumulators per column pair so that consecutive instructions are independent
+        f32x4 o[2][2];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float w = po[k * 64];
+        for (int p = 0; p < 2; ++p) o[p][0] = o[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < 2; ++p) o[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, y[p][k / 4][k % 4], o[p], 0, 0, 0);
+        for (int m = 0; m < M; ++m) {
+            const f32q w = src[m * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    o[p][r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[r], y[p][m][r], o[p][r & 1], 0, 0, 0);
         }
-        if (valid && q == 0) {
+        const f32q bo = src[M * 64];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const uint32_t t = t0 + p;
-                if (t < t_end) {
+        for (int p = 0; p < 2; ++p) {
+            f32x4 sum = o[p][0] + o[p][1];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) (act + (size_t)t * RQ_ACTION_DIM * ld)[(uint32_t)r * ld + e0] = teacher_act<OUT_ACT>(o[p][r]);
-                }
+            for (int r = 0; r < 4; ++r) {                               // the four lane groups each hold a quarter of the units
+                sum[r] += __shfl_xor(sum[r], 16);
+                sum[r] += __shfl_xor(sum[r], 32);
+            }
+            if (live[p] && q == 0) {
+                float* dst = act + (size_t)step[p] * RQ_ACTION_DIM * ld + env[p];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(uint32_t)r * ld] = teacher_act<OUT_ACT>(sum[r] + bo[r]);
             }
         }
     }
 }
 
-hipError_t launch_teacher_relabel_layers(hipStream_t s, uint32_t n_tiles, uint32_t ld, uint32_t steps, uint32_t in_dim, uint32_t n_hidden,
-                                         uint32_t hp, int act, int out_act, const float* images, const uint32_t* tile_teacher,
-                                         const uint32_t* tile_env, const float* obs, float* actions) {
-    if (n_tiles == 0 || steps == 0) return hipSuccess;
+hipError_t launch_teacher_relabel_layers(hipStream_t s, uint32_t n_teachers, uint32_t n_envs, uint32_t ld, uint32_t steps, uint32_t in_dim,
+                                         uint32_t n_hidden, uint32_t hp, int act, int out_act, const float* images,
+                                         const uint32_t* teacher_start, const uint32_t* sorted_env, const float* obs, float* actions) {
+    if (n_teachers == 0 || n_envs == 0 || steps == 0) return hipSuccess;
     if ((hp != 64 && hp != 128) || n_hidden < 1 || n_hidden > 3) return hipErrorInvalidValue;
-    // a workgroup = four step-slices of one tile; enough workgroups for >= 4 rounds over the chip's 512 resident ones, slices of >= 32 steps
-    uint32_t groups = (2048u + n_tiles - 1) / n_tiles;
-    if (groups > steps / 128u) groups = steps / 128u;
-    if (groups < 1u) groups = 1u;
-    const dim3 grid(n_tiles, groups);
-    const uint32_t image_floats = (uint32_t)teacher_layers_image_floats((int)hp, (int)n_hidden);
-#define RQ_TL(HP, A, O) k_teacher_relabel_layers<HP, A, O><<<grid, 256, 0, s>>>(ld, steps, in_dim, n_hidden, image_floats, images, tile_teacher, tile_env, obs, actions)
+    if ((uint64_t)n_envs * steps >= (1ull << 32)) return hipErrorInvalidValue;             // column indices are 32-bit
+    // one workgroup = one teacher x one chunk of its columns: about 1 024 workgroups (four rounds over the chip), chunks of >= 4 096 columns
+    const uint64_t avg_cols = (uint64_t)n_envs * steps / n_teachers;
+    uint32_t chunks = (1024u + n_teachers - 1) / n_teachers;
+    if (chunks > avg_cols / 4096u) chunks = (uint32_t)(avg_cols / 4096u);
+    if (chunks < 1u) chunks = 1u;
+    if (chunks > 65535u) chunks = 65535u;
+    const dim3 grid(n_teachers, chunks);
+#define RQ_TL(HP, A, O) k_teacher_relabel_layers<HP, A, O><<<grid, LayersBlock<HP>::threads, 0, s>>>(ld, steps, in_dim, n_hidden, images, teacher_start, sorted_env, obs, actions)
 #define RQ_TL_ACT(HP)                                                                                           \
     do {                                                                                                        \
         if (act == RQ_ACT_RELU) { if (out_act == RQ_ACT_TANH) RQ_TL(HP, RQ_ACT_RELU, RQ_ACT_TANH); else RQ_TL(HP, RQ_ACT_RELU, RQ_ACT_IDENTITY); } \

@@ -93,24 +93,36 @@ if args.direction in ("both", "torch_aggressor"):
     assert (bits(quiet) == bits(rq_workload())).all(), "the fp32 workload is not deterministic on an idle GPU"
     a = torch.randn(4096, 4096, device=cuda, dtype=torch.bfloat16)
     b = torch.randn(4096, 4096, device=cuda, dtype=torch.bfloat16)
+    sa, sb = torch.randn(4096, 64, 64, device=cuda, dtype=torch.bfloat16), torch.randn(4096, 64, 64, device=cuda, dtype=torch.bfloat16)
+    q, k, v = (torch.randn(32, 8, 512, 64, device=cuda, dtype=torch.bfloat16) for _ in range(3))
+    ha, hb = torch.randn(1024, 1024, device=cuda, dtype=torch.float16), torch.randn(1024, 1024, device=cuda, dtype=torch.float16)
 
-    def bf16_matmuls():
-        for _ in range(20):
-            torch.matmul(a, b)
-        torch.cuda.synchronize()
+    def many(fn, times=20):
+        def loop():
+            for _ in range(times):
+                fn()
+            torch.cuda.synchronize()
+        return loop
 
-    bg = Background(bf16_matmuls, "torch's bf16 matmuls")
-    bg.start()
-    bad_reps = bad_envs = 0
-    for _ in range(args.reps):
-        d = (bits(rq_workload()) != bits(quiet)).any(axis=1)
-        bad_reps += int(d.any())
-        bad_envs += int(d.sum())
-    bg.stop()
-    results.append({"direction": "torch_aggressor", "library": tag, "victim": f"{args.steps} fp32 chained steps on {args.envs} envs (this library)",
-                    "aggressor": f"torch.matmul bf16 4096^3, {bg.count * 20} calls on torch's stream", "repetitions": args.reps,
-                    "repetitions_that_differ": bad_reps, "envs_that_differ": bad_envs})
-    print(json.dumps(results[-1]), flush=True)
+    # several shapes of foreign 16-bit MFMA kernel: big GEMM tiles fill a CU's registers and LDS (little room for another wave on their
+    # SIMDs), small batched GEMMs and attention kernels leave more
+    aggressors = {"torch.matmul bf16 4096^3": many(lambda: torch.matmul(a, b)),
+                  "torch.bmm bf16 4096 x 64^3": many(lambda: torch.bmm(sa, sb)),
+                  "scaled_dot_product_attention bf16 [32, 8, 512, 64]": many(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v)),
+                  "torch.matmul f16 1024^3": many(lambda: torch.matmul(ha, hb), 50)}
+    for what, fn in aggressors.items():
+        bg = Background(fn, what)
+        bg.start()
+        bad_reps = bad_envs = 0
+        for _ in range(args.reps):
+            d = (bits(rq_workload()) != bits(quiet)).any(axis=1)
+            bad_reps += int(d.any())
+            bad_envs += int(d.sum())
+        bg.stop()
+        results.append({"direction": "torch_aggressor", "library": tag, "victim": f"{args.steps} fp32 chained steps on {args.envs} envs (this library)",
+                        "aggressor": f"{what}, {bg.count} batches on torch's stream", "repetitions": args.reps,
+                        "repetitions_that_differ": bad_reps, "envs_that_differ": bad_envs})
+        print(json.dumps(results[-1]), flush=True)
 
 # ------------------------------------------------------------------ this library is the aggressor, torch the victim
 if args.direction in ("both", "torch_victim"):

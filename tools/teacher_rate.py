@@ -25,6 +25,7 @@ ap.add_argument("--hidden", type=int, default=64)
 ap.add_argument("--assignment", choices=("balanced", "contiguous"), default="balanced",
                 help="balanced: raptor_amd.teachers.balanced_teacher_assignment (whole 64-env tiles per teacher where the "
                      "counts allow); contiguous: env e -> teacher e*T//n (65.536 envs per teacher at T=1000: ragged tiles)")
+ap.add_argument("--only-layers", action="store_true", help="the dense-stack kernel only (tools/teacher_traffic.sh profiles this)")
 args = ap.parse_args()
 
 device = l2f.Device()
@@ -41,7 +42,7 @@ else:
 flop = 2 * (22 * H + H * H + H * 4) * args.envs * args.steps
 out = {"envs": args.envs, "steps": args.steps, "teachers": args.teachers, "assignment": args.assignment, "topology": f"22-{H}-{H}-4",
        "flop_per_label": 2 * (22 * H + H * H + H * 4)}
-for prec, peak in (("fp32", 157.3), ("bf16", 2500.0), ("f16x2", 2500.0)):    # f16x2: useful FLOP; 3x as many are issued
+for prec, peak in (() if args.only_layers else (("fp32", 157.3), ("bf16", 2500.0), ("f16x2", 2500.0))):    # f16x2: useful FLOP; 3x as many are issued
     bank = TeacherBank(device, W, 22, H, H, "relu", "identity", precision=prec)
     tr.relabel_teachers(bank, ids, fetch=False)
     device.synchronize()
@@ -56,7 +57,7 @@ for prec, peak in (("fp32", 157.3), ("bf16", 2500.0), ("f16x2", 2500.0)):    # f
     out[prec] = {"ms": round(best * 1e3, 3), "wall_ms_incl_host_grouping": round(wall_ms, 3), "labels_per_s": round(args.envs * args.steps / best, 1),
                  "TFLOPs": round(flop / best / 1e12, 2), "peak_TFLOPs": peak, "frac_of_mfma_peak": round(flop / best / 1e12 / peak, 4),
                  "obs_GBps": round(args.envs * args.steps * (88 + 16) / best / 1e9, 1)}
-# the streaming kernel for stacks outside the register-stationary family (round 5): fp32 only
+# the dense-stack kernel for teachers outside the register-stationary family (round 5; LDS-resident since round 6): fp32 only
 from raptor_amd.teachers import layers_parameter_count          # noqa: E402
 for widths in ([128, 128, 128], [128, 128], [64, 64, 64], [128]):
     Wl = (rng.standard_normal((args.teachers, layers_parameter_count(22, widths))) * 0.05).astype(np.float32)
