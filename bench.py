@@ -97,6 +97,10 @@ def parse_args(argv=None):
                     help="'hip' = libraptor_quad.so on this rank's GPU (the product); a module path = a stand-in with "
                          "the same interface (module.create_engine(local_rank, args)): CPU tests of the orchestration")
     ap.add_argument("--no-config4", action="store_true", help="skip the 262 144-envs-per-GPU block")
+    ap.add_argument("--allow-oversubscribe", action="store_true",
+                    help="TESTS ONLY: more ranks than GPUs - rank r drives GPU r %% (GPUs of the node), the rendezvous backend defaults to "
+                         "gloo (RCCL cannot put two ranks on one device; RQ_RCCL_LIBRARY names the tests' stand-in for the native exchange). "
+                         "What the driver's 8-GPU command meets, on the one GPU of a test box; the record says `oversubscribed`")
     return ap.parse_args(argv)
 
 
@@ -906,6 +910,8 @@ class GpuEngine:
         # RQ_BENCH_DEVICE: every rank on ONE device (tests: two ranks share the single GPU of the test box, with the
         # tests-only RCCL of tests/fake_rccl.cpp and the gloo rendezvous); normally rank r of the node drives GPU r
         local_rank = int(os.environ.get("RQ_BENCH_DEVICE", local_rank))
+        if getattr(args, "allow_oversubscribe", False):              # tests only: rank r of more ranks than GPUs drives GPU r % GPUs
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         self.torch, self.local_rank, self.precision = torch, local_rank, args.precision
         self.device = l2f.Device(local_rank)
@@ -1498,7 +1504,7 @@ def spawn_local_ranks(args, argv):
     import subprocess
     n = args.gpus
     have = engine_device_count(args.engine)
-    if "RQ_BENCH_DEVICE" not in os.environ and n > have:
+    if "RQ_BENCH_DEVICE" not in os.environ and not args.allow_oversubscribe and n > have:
         raise SystemExit(f"bench.py --gpus {n}: this node has {have} GPU(s) (engine '{args.engine}'); there is no "
                          "fallback to fewer ranks")
     with socket.socket() as s:
@@ -1553,9 +1559,13 @@ def main(argv=None):
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        engine.init_process_group(dist, args.backend or engine.default_backend)
+        oversubscribed = args.allow_oversubscribe and engine.name == "hip" and world > engine_device_count(args.engine)
+        engine.init_process_group(dist, args.backend or ("gloo" if oversubscribed else engine.default_backend))
     try:
         result = run_benchmark(args, engine, rank, local_rank, world, dist)
+        if rank == 0 and args.allow_oversubscribe:
+            result["config"]["oversubscribed"] = (f"{world} ranks on {engine_device_count(args.engine)} GPU(s): a test of the orchestration, "
+                                                  "not a measurement")
         if rank == 0:
             # RCCL / the HIP runtime print banners through C stdio, which a redirected stdout only flushes at exit:
             # push them out now so that the JSON line is the LAST line of stdout

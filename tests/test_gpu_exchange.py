@@ -323,6 +323,53 @@ def test_bench_py_with_two_ranks_on_one_gpu(device, tmp_path):
           f"exchange share {d['timing']['exchange_share']}")
 
 
+@pytest.mark.timeout(600)
+def test_the_drivers_eight_rank_command_end_to_end_on_one_gpu(device, tmp_path):
+    """What the driver's first SCALE run will execute - `python bench.py --gpus 8 --steps 20 --warmup 5`, eight ranks, the product
+    engine on the GPU - has only ever run through the gloo stand-in engine on CPU (tests/test_bench_orchestration.py) and with two
+    ranks here.  Round 6: all eight ranks on this box's one GPU (`--allow-oversubscribe`, tests only; the native
+    exchange bound to tests/fake_rccl.cpp), typed the way the driver types it when there is no launcher: consensus on the communicator,
+    the verification episode, the timed regions with their share of the all-gather, the config-4 block (8 x 262 144 = 2 097 152 envs),
+    ONE JSON line - inside the driver's time box: the test fails above 120 s of wall time."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", os.path.join(root, "tests", "fake_rccl.cpp"), "-o", fake, "-lrt"],
+                   check=True, capture_output=True)
+    env = dict(os.environ, RQ_RCCL_LIBRARY=fake)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RQ_BENCH_DEVICE"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--allow-oversubscribe"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=500)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.strip()]
+    records = [l for l in lines if l.lstrip().startswith("{")]
+    assert len(records) == 1 and lines[-1] == records[0], lines[-3:]
+    d = json.loads(records[0])
+    assert d["n_gpus"] == 8 and d["config"]["total_envs"] == 8 * 65536 and d["config"]["engine"] == "hip" and "oversubscribed" in d["config"]
+    assert d["config"]["exchange"].startswith("native RCCL"), d["config"]["exchange"]
+    assert d["config"]["gathered_returns"] == 8 * 65536
+    assert d["config"]["exchange_verified"] is True and d["config"]["exchange_check"]["blocks_matching_their_rank_on_rank0"] == 8
+    rccl = d["config"]["rccl"]
+    assert rccl["ranks"] == 8 and [x["rank"] for x in rccl["per_rank"]] == list(range(8)) and rccl["library_path"] == fake and rccl["distinct_gpus"] == 1
+    assert d["config4"]["total_envs"] == 2097152 and d["config4"]["exchange_verified"] is True and d["config4"]["exchanges"] == 4      # BASELINE config 4
+    assert d["timing"]["exchange_share"]["regions_with_extra_exchange"] >= 3
+    assert d["value"] > 1e8 and d["scaling"] == "weak" and d["metric"].startswith("env-steps/sec (whole node) at 65536 quadrotors")
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "eight_ranks_one_gpu.json"), "w") as fh:
+            json.dump({"wall_s": round(wall, 1), "command": "python bench.py --gpus 8 --steps 20 --warmup 5 --allow-oversubscribe", "record": d}, fh, indent=1)
+    print(f"[bench.py --gpus 8 on one GPU, fake RCCL] wall {wall:.1f} s, value {d['value']:.3g} env-steps/s (8 ranks time-share one GPU)")
+    assert wall < 120.0, f"the eight-rank command took {wall:.0f} s on one GPU: over the 120 s box"
+
+
 @pytest.mark.timeout(900)
 def test_plain_bench_command_launches_its_own_ranks_on_the_gpu(device, tmp_path):
     """`python bench.py --gpus 2` typed as is - no RANK / WORLD_SIZE, no torch.distributed.run around it (round 4): the command
