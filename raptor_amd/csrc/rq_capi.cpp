@@ -74,6 +74,8 @@ struct rq_device {
     std::vector<unsigned long long> k_host;      // the records of the last timed rollout on the host (fetched once per launch)
     bool k_fetched = false;
     double k_ticks_per_ms = 1e5;                 // wall clock rate (100 MHz on gfx950)
+    bool graphs_enabled = true;    // RQ_NO_GRAPHS in the environment: chained rollouts never capture
+    uint32_t graph_fallbacks = 0;  // chained rollouts whose hipGraph capture was invalidated from outside and that went out as plain launches
     bool k_timing = false;         // rq_device_set_rollout_timing
     bool k_timed = false;          // a launch carried the two events
     void* staging = nullptr;       // pinned host buffer for transposing device -> host copies
@@ -595,6 +597,7 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
         return fail(RQ_ERR_HIP, "rq_device_create: stream/event creation failed");
     }
     d->speculate = std::getenv("RQ_NO_SPECULATION") == nullptr;
+    d->graphs_enabled = std::getenv("RQ_NO_GRAPHS") == nullptr;
     *out = d;
     return RQ_OK;
 }
@@ -1618,34 +1621,48 @@ static int rollout_impl(rq_device* dev, rq_env* env, const rq_params* params, rq
                     g.sas_seed == policy->sas_seed && g.ls_image == policy->ls_image &&
                     std::memcmp(&g.cfg, &env->cfg, sizeof(rq_env_config)) == 0) { exec = g.exec; break; }
             if (!exec) {
+                // Built node by node (rq_kernels.hpp GraphSink), NOT by stream capture: while any stream of a process captures, HIP
+                // fails hipDeviceSynchronize on every other thread (hipErrorStreamCaptureUnsupported) and invalidates the capture -
+                // a learner's PyTorch thread on the same GPU broke the rollout and was broken by it (tools/foreign_soak.py, round 6).
+                // Should the construction fail all the same, the steps go out as plain launches: same kernels, same order.
                 hipGraph_t graph = nullptr;
-                RQ_HIP(hipStreamBeginCapture(dev->stream, hipStreamCaptureModeThreadLocal));
-                hipError_t ce = hipSuccess;
-                for (uint32_t t = 0; t < kGraphSteps && ce == hipSuccess; ++t) ce = enqueue_step(t, env->epoch_dev, 0);
-                if (ce == hipSuccess) ce = rq::launch_add_u32(dev->stream, env->epoch_dev, kGraphSteps);
-                hipError_t ee = hipStreamEndCapture(dev->stream, &graph);
-                RQ_HIP(ce);
-                RQ_HIP(ee);
-                hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                RQ_HIP(ie);
-                if (env->graphs.size() >= kMaxGraphs) {        // least recently created goes (a replay is cheap to rebuild)
-                    RQ_HIP(hipStreamSynchronize(dev->stream));
-                    (void)hipGraphExecDestroy(env->graphs.front().exec);
-                    env->graphs.erase(env->graphs.begin());
+                hipError_t ce = dev->graphs_enabled ? hipGraphCreate(&graph, 0) : hipErrorNotSupported;
+                if (ce == hipSuccess) {
+                    rq::GraphSink sink;
+                    sink.graph = graph;
+                    rq::set_graph_sink(&sink);
+                    for (uint32_t t = 0; t < kGraphSteps && ce == hipSuccess; ++t) ce = enqueue_step(t, env->epoch_dev, 0);
+                    if (ce == hipSuccess) ce = rq::launch_add_u32(dev->stream, env->epoch_dev, kGraphSteps);
+                    rq::set_graph_sink(nullptr);
+                    if (ce == hipSuccess && sink.nodes != 2 * kGraphSteps + 1) ce = hipErrorUnknown;     // a launcher that bypassed the sink
                 }
-                try {                       // nothing throws across the boundary
-                    env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, env->obs, flags,
-                                           policy->precision, env->cfg, rng->seed, policy->sas_mode, policy->sas_seed,
-                                           policy->ls_image, exec});
-                } catch (const std::bad_alloc&) {
-                    (void)hipGraphExecDestroy(exec);
-                    return fail(RQ_ERR_OUT_OF_MEMORY, "rollout: host allocation failed");
+                if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
+                if (ce != hipSuccess) {
+                    (void)hipGetLastError();         // the failed construction's; the direct launches below report their own
+                    exec = nullptr;
+                    ++dev->graph_fallbacks;
+                } else {
+                    if (env->graphs.size() >= kMaxGraphs) {        // least recently created goes (a replay is cheap to rebuild)
+                        RQ_HIP(hipStreamSynchronize(dev->stream));
+                        (void)hipGraphExecDestroy(env->graphs.front().exec);
+                        env->graphs.erase(env->graphs.begin());
+                    }
+                    try {                       // nothing throws across the boundary
+                        env->graphs.push_back({params->d, state->d, policy->hidden, packed_of(policy), policy->w_dev, env->obs, flags,
+                                               policy->precision, env->cfg, rng->seed, policy->sas_mode, policy->sas_seed,
+                                               policy->ls_image, exec});
+                    } catch (const std::bad_alloc&) {
+                        (void)hipGraphExecDestroy(exec);
+                        return fail(RQ_ERR_OUT_OF_MEMORY, "rollout: host allocation failed");
+                    }
                 }
             }
-            RQ_HIP(rq::launch_set_u32(dev->stream, env->epoch_dev, rng->epoch));
-            for (; done_steps + kGraphSteps <= n_steps; done_steps += kGraphSteps)
-                RQ_HIP(hipGraphLaunch(exec, dev->stream));
+            if (exec) {
+                RQ_HIP(rq::launch_set_u32(dev->stream, env->epoch_dev, rng->epoch));
+                for (; done_steps + kGraphSteps <= n_steps; done_steps += kGraphSteps)
+                    RQ_HIP(hipGraphLaunch(exec, dev->stream));
+            }
         }
         for (uint32_t t = done_steps; t < n_steps; ++t) RQ_HIP(enqueue_step(rng->epoch + t, nullptr, t));
     }

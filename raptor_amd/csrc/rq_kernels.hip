@@ -26,6 +26,32 @@
 
 namespace rq {
 
+// ---- launch or append a graph node (rq_kernels.hpp GraphSink) -----------------------------------------------------------------
+static thread_local GraphSink* tl_graph_sink = nullptr;
+void set_graph_sink(GraphSink* sink) { tl_graph_sink = sink; }
+
+template <typename T> struct arg_of { using type = T; };
+// the kernel's own parameter types decide how each argument is converted and copied (the node stores a copy of every argument)
+template <typename... KArgs>
+static hipError_t graph_add(GraphSink* g, void (*kernel)(KArgs...), dim3 grid, dim3 block, typename arg_of<KArgs>::type... args) {
+    if (g->status != hipSuccess) return g->status;
+    void* ptrs[sizeof...(KArgs)] = {const_cast<void*>(static_cast<const void*>(&args))...};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void*>(kernel);
+    p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = ptrs; p.extra = nullptr;
+    hipGraphNode_t node = nullptr;
+    g->status = hipGraphAddKernelNode(&node, g->graph, g->last ? &g->last : nullptr, g->last ? 1 : 0, &p);
+    if (g->status == hipSuccess) { g->last = node; ++g->nodes; }
+    return g->status;
+}
+// KERNEL<<<GRID, BLOCK, 0, STREAM>>>(args) - or, under a GraphSink, the same launch as a node behind the previous one
+#define RQ_KLAUNCH(KERNEL, GRID, BLOCK, STREAM, ...)                                                         \
+    do {                                                                                                     \
+        if (tl_graph_sink) (void)graph_add(tl_graph_sink, KERNEL, dim3(GRID), dim3(BLOCK), __VA_ARGS__);     \
+        else KERNEL<<<(GRID), (BLOCK), 0, (STREAM)>>>(__VA_ARGS__);                                          \
+    } while (0)
+#define RQ_KLAUNCH_STATUS() (tl_graph_sink ? tl_graph_sink->status : hipGetLastError())
+
 // Publish completion of this launch in the host mailbox: every workgroup makes its stores visible at system
 // scope and counts itself; the last one resets the counter and writes seq to the pinned flag.
 __device__ __forceinline__ void mailbox_signal(const Mailbox& mb) {
@@ -536,8 +562,8 @@ hipError_t launch_set_u32(hipStream_t s, uint32_t* p, uint32_t value) {
     return hipGetLastError();
 }
 hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add) {
-    k_advance_u32<<<1, 64, 0, s>>>(p, add, 0u, 0);
-    return hipGetLastError();
+    RQ_KLAUNCH(k_advance_u32, 1, 64, s, p, add, 0u, 0);
+    return RQ_KLAUNCH_STATUS();
 }
 
 hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, const float* obs, uint32_t ld_obs,
@@ -559,14 +585,14 @@ hipError_t launch_actor_step(hipStream_t s, uint32_t n, const float* packed, con
     const unsigned grid1 = grid_for(groups * 64, kBlock);
 #define RQ_LAUNCH_ACTOR(ACT)                                                                                                            \
     do {                                                                                                                                \
-        if (stream) k_actor_stream<ACT><<<grid, kBlock, 0, s>>>(n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas);   \
-        else        k_actor_step<ACT><<<grid1, kBlock, 0, s>>>(n, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);    \
+        if (stream) RQ_KLAUNCH(k_actor_stream<ACT>, grid, kBlock, s, n, gpw, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas);   \
+        else        RQ_KLAUNCH(k_actor_step<ACT>, grid1, kBlock, s, n, packed, obs, ld_obs, hidden_in, hidden, ld_h, act, ld_act, frozen, sas, mb);    \
     } while (0)
     if (precision == RQ_POLICY_F16X2_MFMA)     RQ_LAUNCH_ACTOR(ActorF16X2);
     else if (precision == RQ_POLICY_BF16_MFMA) RQ_LAUNCH_ACTOR(ActorBF16);
     else                                       RQ_LAUNCH_ACTOR(ActorF32Lean);   // the two-tiles-per-pass build: ~30 registers fewer live, 2-3 % faster at every size
 #undef RQ_LAUNCH_ACTOR
-    return hipGetLastError();
+    return RQ_KLAUNCH_STATUS();
 }
 
 hipError_t launch_actor_sequence(hipStream_t s, uint32_t n, uint32_t steps, const float* packed, const float* obs,
@@ -607,12 +633,12 @@ hipError_t launch_step(hipStream_t s, Batch b, StepCfg c, const float* params, c
     if (b.n == 0) return hipSuccess;
     const ObsNext on{obs_of_next, nc, noise ? 1u : 0u, obs_epoch, obs_epoch_base};
     if (rollout)
-        k_step<true><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                              sc, seed, hidden, weights, mb, on);
+        RQ_KLAUNCH(k_step<true>, grid_for(b.n, kBlock), kBlock, s, b, c, params, state, action, next_state, st, flags,
+                   sc, seed, hidden, weights, mb, on);
     else
-        k_step<false><<<grid_for(b.n, kBlock), kBlock, 0, s>>>(b, c, params, state, action, next_state, st, flags,
-                                                               sc, seed, hidden, weights, mb, on);
-    return hipGetLastError();
+        RQ_KLAUNCH(k_step<false>, grid_for(b.n, kBlock), kBlock, s, b, c, params, state, action, next_state, st, flags,
+                   sc, seed, hidden, weights, mb, on);
+    return RQ_KLAUNCH_STATUS();
 }
 
 hipError_t launch_thaw_frozen(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, const float* params, float* state,

@@ -106,6 +106,21 @@ hipError_t launch_sample_state(hipStream_t s, Batch b, SampleCfg c, uint64_t see
 hipError_t launch_observe(hipStream_t s, Batch b, NoiseCfg nc, bool noise, uint64_t seed, uint32_t epoch,
                           const uint32_t* epoch_base, const float* params, const float* state, float* obs,
                           Mailbox mb = Mailbox{});
+// ---- explicit hipGraph construction (round 6) -------------------------------------------------------------------------------------
+// A chained rollout replays a graph of kGraphSteps steps.  Rounds 2-5 built it by STREAM CAPTURE - and while any stream of a process
+// captures, HIP fails hipDeviceSynchronize (and other calls) on EVERY thread of the process with hipErrorStreamCaptureUnsupported and
+// invalidates the capture: a learner's PyTorch thread on the same GPU both broke the rollout and was broken by it (measured:
+// tools/foreign_soak.py).  Now the graph is built node by node: while a GraphSink is installed on the calling thread, the launchers a
+// chained step uses (launch_actor_step, launch_step, launch_add_u32) append a kernel node - same kernel, same grid, same arguments,
+// each depending on the one before - instead of launching.  No stream is ever in capture mode.
+struct GraphSink {
+    hipGraph_t graph = nullptr;
+    hipGraphNode_t last = nullptr;
+    hipError_t status = hipSuccess;
+    uint32_t nodes = 0;
+};
+void set_graph_sink(GraphSink* sink);      // nullptr: the launchers launch again (thread-local)
+
 hipError_t launch_set_u32(hipStream_t s, uint32_t* p, uint32_t value);
 hipError_t launch_add_u32(hipStream_t s, uint32_t* p, uint32_t add);
 // Raptor.evaluate_step (README.md:97): obs [>=22][ld_obs] -> act [4][ld_act]; hidden [16][ld_h] in/out.

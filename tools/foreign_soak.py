@@ -104,12 +104,22 @@ if args.direction in ("both", "torch_aggressor"):
             torch.cuda.synchronize()
         return loop
 
+    def churn():
+        x = torch.empty(1 << 22, device=cuda)
+        torch.cuda.synchronize()
+        del x
+        torch.cuda.empty_cache()
+
     # several shapes of foreign 16-bit MFMA kernel: big GEMM tiles fill a CU's registers and LDS (little room for another wave on their
     # SIMDs), small batched GEMMs and attention kernels leave more
     aggressors = {"torch.matmul bf16 4096^3": many(lambda: torch.matmul(a, b)),
                   "torch.bmm bf16 4096 x 64^3": many(lambda: torch.bmm(sa, sb)),
                   "scaled_dot_product_attention bf16 [32, 8, 512, 64]": many(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v)),
-                  "torch.matmul f16 1024^3": many(lambda: torch.matmul(ha, hb), 50)}
+                  "torch.matmul f16 1024^3": many(lambda: torch.matmul(ha, hb), 50),
+                  # no MFMA at all: a thread that allocates, frees and synchronises the device the whole time - what invalidates another
+                  # thread's open hipGraph capture (the chained rollout captures one per new env): the rollout must fall back to plain
+                  # launches, not fail (rq_capi.cpp rollout_impl)
+                  "hipMalloc / hipFree / hipDeviceSynchronize churn": many(churn, 5)}
     for what, fn in aggressors.items():
         bg = Background(fn, what)
         bg.start()
