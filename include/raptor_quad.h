@@ -69,11 +69,12 @@
 extern "C" {
 #endif
 
-#define RQ_ABI_VERSION 4   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
+#define RQ_ABI_VERSION 5   /* 2 (round 3): rq_env_config.action_history_raw; termination_position default 1 m; the entry points added in
                               rounds 2 and 3 (the latter: rq_device_last_rollout_waves)
                               3 (round 4): rq_device_{set,get}_speculation, rq_device_last_rollout_clock; no struct changed
                               4 (round 5): rq_comm_describe (new struct rq_comm_description); rq_comm_info / rq_comm_create ask RCCL for
-                              the communicator's own rank and size; rq_teacher_bank_create_layers */
+                              the communicator's own rank and size; rq_teacher_bank_create_layers
+                              5 (round 6): rq_device_{set,get}_resident; no struct changed */
 
 #if defined(__GNUC__)
 #define RQ_API __attribute__((visibility("default")))
@@ -510,6 +511,17 @@ RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, flo
  * switches it off for this device (RQ_NO_SPECULATION in the environment: off at rq_device_create), 1 on again.
  * rq_device_get_speculation: any out pointer may be NULL. */
 RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
+/* The resident executor of that loop (round 6, ABI 5): once rq_step has been called three times in a row in the loop's own shape (host
+ * actions, an env of at most 512 envs, the observation cached, an fp32 policy to speculate with, next_state != state) and nothing else
+ * was asked of the device in between, the step and the speculated policy step are no longer LAUNCHED: one workgroup stays on the device,
+ * on a stream of its own, polls a 64-byte command line in pinned host memory and does for every command what the two launches did
+ * (same device functions, same bits, same sequence numbers in the same flag).  Any other call on the device retires it first (a few
+ * microseconds); it leaves by itself after 4 ms without a command, and a command it never took is replayed as launches.  Results
+ * never depend on it.  enable = 0 switches it off for this device (RQ_NO_RESIDENT in the environment: off at rq_device_create).
+ * rq_device_get_resident: any out pointer may be NULL; `running` = a kernel is on the device now; starts / commands / replays count
+ * kernels started, commands posted, and commands replayed as launches since the device was created. */
+RQ_API int rq_device_set_resident(rq_device* dev, int enable);
+RQ_API int rq_device_get_resident(const rq_device* dev, int* enabled, int* running, uint64_t* starts, uint64_t* commands, uint64_t* replays);
 RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* suspended, uint32_t* consecutive_misses);
 
 #ifdef __cplusplus

@@ -97,6 +97,8 @@ _SIGNATURES = {
     "rq_device_last_rollout_clock": [_vp, _fp],
     "rq_device_set_speculation": [_vp, C.c_int],
     "rq_device_get_speculation": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p],
+    "rq_device_set_resident": [_vp, C.c_int],
+    "rq_device_get_resident": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "rq_device_stream": [_vp, C.POINTER(_vp)],
     "rq_rng_create": [_vp, C.POINTER(_vp)],
     "rq_rng_destroy": [_vp],
@@ -183,7 +185,7 @@ _RESTYPES = {"rq_last_error": C.c_char_p, "rq_status_string": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class _EnvConfigAbi1(C.Structure):

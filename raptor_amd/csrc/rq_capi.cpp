@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <mutex>
 #include <string>
@@ -45,6 +46,17 @@ inline uint32_t round_up64(uint32_t n) { return (n + 63u) & ~63u; }
 
 // live rq_policy objects: a device remembers the policy it last evaluated (speculative step, rq_step) by pointer, and
 // objects die in any order.  op: +1 register, -1 unregister, 0 query.
+// live rq_device objects, likewise: an env or a policy that is destroyed retires the resident executor of its device if the
+// device is still there (objects die in any order; the parent pointer of a dead device must not be followed)
+bool device_registry(const void* dev, int op) {
+    static std::mutex m;
+    static std::unordered_set<const void*> live;
+    std::lock_guard<std::mutex> lock(m);
+    if (op > 0) { live.insert(dev); return true; }
+    if (op < 0) { live.erase(dev); return false; }
+    return live.count(dev) != 0;
+}
+
 bool policy_registry(const void* pol, int op) {
     static std::mutex m;
     static std::unordered_set<const void*> live;
@@ -126,8 +138,41 @@ struct rq_device {
     bool sp_outstanding = false;         // a speculated step was launched and not taken (yet)
     bool sp_suspended = false;
     uint32_t sp_misses = 0;
+    // Resident executor of the small-batch loop (round 6; kernel: rq_kernels.hip k_resident_loop).  While the host keeps calling
+    // rq_step on the same small env / params / policy, the step and the speculative policy step are not launched: they are posted,
+    // as a 64-byte command in pinned memory, to one workgroup that stays on the device - on a stream of its own - and publishes the
+    // same two sequence numbers in mb_flag.  Anything else the device is asked to do retires it first (resident_scope_hook).
+    hipStream_t res_stream = nullptr;
+    uint32_t* res_mem = nullptr;         // pinned: [0..15] the command line, [16] launch id of the kernel that has left
+    bool res_enabled = true;             // RQ_NO_RESIDENT in the environment: off
+    bool res_running = false;
+    uint32_t res_launch_id = 0, res_packet = 0;     // id of the kernel that is running; commands posted to it
+    uint32_t res_streak = 0;             // eligible rq_step calls in a row with nothing else asked of the device in between
+    uint64_t res_last_post_ns = 0;       // host clock of the last command: a kernel idle for too long may be leaving, it is not posted to
+    uint64_t res_starts = 0, res_posts = 0, res_replays = 0;     // diagnostics
+    const rq_env* res_env = nullptr; uint64_t res_env_uid = 0;   // what the running kernel was started for
+    const rq_params* res_params = nullptr; uint64_t res_params_version = 0;
+    rq_policy* res_policy = nullptr;
+    rq_env_config res_cfg{}; uint64_t res_seed = 0;
+    float* res_obs[2] = {nullptr, nullptr}; float* res_hidden[2] = {nullptr, nullptr}; const float* res_packed = nullptr;
+    bool res_pending = false;            // res_cmd was posted and is not known to have been consumed
+    struct StepPair* res_cmd = nullptr;  // the command most recently posted: what a replay as launches needs
 };
 constexpr uint32_t kSpeculationMissLimit = 4;
+constexpr uint32_t kResidentMaxEnvs = 512;            // one workgroup: eight waves of 64 envs
+constexpr uint32_t kResidentStreak = 3;               // eligible steps in a row before a kernel is started
+constexpr uint64_t kResidentIdleTicks = 400000;       // the kernel leaves after 4 ms without a command (100 MHz ticks) ...
+constexpr uint64_t kResidentHostIdleNs = 1000000;     // ... and the host stops posting to one it has not fed for 1 ms
+
+// the two launches of a small-batch step: k_step (+ the next observation) and the speculative policy step on it
+struct StepPair {
+    rq::Batch b; rq::StepCfg c; rq::SampleCfg sc; uint64_t seed;
+    const float* params; const float* state_in; float* act; float* state_out; rq::StatsPtrs st;
+    rq::Mailbox mb_step; float* obs_alt;
+    bool spec;
+    const float* packed; float* hidden_out; uint32_t ld_h; float* pol_act; int precision; rq::SasArgs sas;
+    rq::Mailbox mb_spec; const float* hidden_in;
+};
 
 struct rq_rng {
     rq_device* dev = nullptr;
@@ -360,14 +405,24 @@ bool obs_cache_holds(const rq_device* dev, const rq_env* env, const rq_params* p
     return false;
 }
 
-// spin until the launch with sequence number seq (or a later one: launches finish in stream order) signalled
+int resident_gone(rq_device* dev);
+
+// spin until the launch with sequence number seq (or a later one: launches finish in stream order) signalled.  While the
+// resident executor runs, the work waited for may be a command posted to it: if it has left (`exited`) without consuming the
+// command, resident_gone() replays the command as launches on the stream and the wait goes on.
 int mailbox_wait(rq_device* dev, uint32_t seq) {
     for (uint64_t spins = 1;; ++spins) {
         const uint32_t f = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
         if ((int32_t)(f - seq) >= 0) return RQ_OK;
+        if (dev->res_running && (spins & 0xFFu) == 0 &&
+            __atomic_load_n(&dev->res_mem[16], __ATOMIC_ACQUIRE) == dev->res_launch_id) {
+            const int rc = resident_gone(dev); if (rc) return rc;
+            continue;
+        }
         if ((spins & 0xFFFFu) == 0) {           // every ~100 us: is the stream still alive?
-            const hipError_t q = hipStreamQuery(dev->stream);
+            const hipError_t q = hipStreamQuery(dev->res_running ? dev->res_stream : dev->stream);
             if (q == hipSuccess) {
+                if (dev->res_running) { const int rc = resident_gone(dev); if (rc) return rc; continue; }
                 const uint32_t g = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
                 if ((int32_t)(g - seq) >= 0) return RQ_OK;
                 return fail(RQ_ERR_HIP, "mailbox_wait: the stream drained without the kernel signalling");
@@ -411,6 +466,90 @@ void mailbox_abort(rq_device* dev, const rq::Mailbox& mb) {
             return fail(RQ_ERR_HIP, std::string(__func__) + ": " #expr " -> " + hipGetErrorString(e_)); \
         }                                                                                         \
     } while (0)
+
+// ---- resident executor (rq_device::res_*; kernel: rq_kernels.hip k_resident_loop) ----------------------------------------------
+uint64_t host_now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+// the two launches of a small-batch step on the device's stream (what rounds 3-5 always did; now also the replay of a command the
+// resident executor never consumed)
+hipError_t launch_step_pair(rq_device* dev, const StepPair& p) {
+    hipError_t e = rq::launch_step(dev->stream, p.b, p.c, p.params, p.state_in, p.act, p.state_out, p.st, /*rollout=*/0, 0u, p.sc, p.seed,
+                                   nullptr, nullptr, p.mb_step, p.obs_alt, rq::NoiseCfg{}, false, 0u, nullptr);
+    if (e == hipSuccess && p.spec)
+        e = rq::launch_actor_step(dev->stream, p.b.n, p.packed, p.obs_alt, p.b.ld, p.hidden_out, p.ld_h, p.pol_act, p.ld_h, nullptr,
+                                  p.precision, p.sas, p.mb_spec, p.hidden_in);
+    return e;
+}
+
+// the resident kernel has left (told to, idle for too long, or never started properly): take note, and if the command posted last
+// was not consumed, run it as launches - nothing will ever publish its sequence numbers otherwise
+int resident_gone(rq_device* dev) {
+    if (!dev->res_running) return RQ_OK;
+    dev->res_running = false;
+    RQ_HIP(hipStreamSynchronize(dev->res_stream));
+    if (dev->res_pending) {
+        dev->res_pending = false;
+        const uint32_t f = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
+        if ((int32_t)(f - dev->res_cmd->mb_spec.seq) < 0) {
+            RQ_REQUIRE((int32_t)(f - dev->res_cmd->mb_step.seq) < 0, RQ_ERR_HIP, "the resident executor left in the middle of a command");
+            ++dev->res_replays;
+            RQ_HIP(launch_step_pair(dev, *dev->res_cmd));
+        }
+    }
+    return RQ_OK;
+}
+
+// wait until the command posted last has been consumed (its first sequence number published) or the kernel has left
+int resident_drain(rq_device* dev) {
+    if (!dev->res_running || !dev->res_pending) return RQ_OK;
+    const int rc = mailbox_wait(dev, dev->res_cmd->mb_step.seq);
+    if (rc == RQ_OK && dev->res_running) dev->res_pending = false;
+    return rc;
+}
+
+void resident_write_packet(rq_device* dev, uint32_t bits, const float* state_in, float* state_out, uint32_t seq_step, uint32_t seq_spec,
+                           uint32_t checksum) {
+    volatile uint32_t* pk = dev->res_mem;
+    const uint32_t id = ++dev->res_packet;
+    const uint64_t a = reinterpret_cast<uint64_t>(state_in), b = reinterpret_cast<uint64_t>(state_out);
+    pk[rq::kRpBits] = bits;
+    pk[rq::kRpStateInLo] = (uint32_t)a; pk[rq::kRpStateInHi] = (uint32_t)(a >> 32);
+    pk[rq::kRpStateOutLo] = (uint32_t)b; pk[rq::kRpStateOutHi] = (uint32_t)(b >> 32);
+    pk[rq::kRpSeqStep] = seq_step; pk[rq::kRpSeqSpec] = seq_spec; pk[rq::kRpChecksum] = checksum;
+    __atomic_store_n(const_cast<uint32_t*>(&pk[rq::kRpTail]), id, __ATOMIC_RELEASE);       // body, then tail, then head: a reader that
+    __atomic_store_n(const_cast<uint32_t*>(&pk[rq::kRpHead]), id, __ATOMIC_RELEASE);       // finds head == tail == id has the body
+}
+
+// tell the kernel to leave and wait until it has
+int resident_retire(rq_device* dev) {
+    if (!dev->res_running) return RQ_OK;
+    int rc = resident_drain(dev); if (rc) return rc;
+    if (!dev->res_running) return RQ_OK;                   // it left by itself meanwhile (resident_gone has dealt with it)
+    resident_write_packet(dev, rq::kRbQuit, nullptr, nullptr, 0, 0, 0);
+    for (uint64_t spins = 1;; ++spins) {
+        if (__atomic_load_n(&dev->res_mem[16], __ATOMIC_ACQUIRE) == dev->res_launch_id) break;
+        if ((spins & 0xFFFFu) == 0 && hipStreamQuery(dev->res_stream) != hipErrorNotReady) break;
+        __builtin_ia32_pause();
+    }
+    return resident_gone(dev);
+}
+
+int ensure_resident_memory(rq_device* dev) {
+    if (dev->res_mem) return RQ_OK;
+    void* mem = nullptr;
+    RQ_HIP(hipHostMalloc(&mem, 256, hipHostMallocDefault));
+    std::memset(mem, 0, 256);
+    const hipError_t e = hipStreamCreateWithFlags(&dev->res_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipHostFree(mem); RQ_HIP(e); }
+    dev->res_mem = static_cast<uint32_t*>(mem);
+    if (!dev->res_cmd) dev->res_cmd = new (std::nothrow) StepPair();
+    RQ_REQUIRE(dev->res_cmd, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    return RQ_OK;
+}
 
 template <typename T>
 int copy_out(const rq_env* env, const T* src, T* dst, int dst_is_device) {
@@ -538,6 +677,11 @@ int state_make_private(rq_state* s, bool keep) {
 }  // namespace
 
 namespace rq {
+int resident_scope_hook(const rq_device* dev_) {
+    rq_device* dev = const_cast<rq_device*>(dev_);
+    dev->res_streak = 0;
+    return dev->res_running ? resident_retire(dev) : RQ_OK;
+}
 int device_ordinal(const rq_device* dev) { return dev->ordinal; }
 hipStream_t device_stream(const rq_device* dev) { return dev->stream; }
 rq_device* env_device(const rq_env* env) { return env->dev; }
@@ -598,6 +742,8 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     }
     d->speculate = std::getenv("RQ_NO_SPECULATION") == nullptr;
     d->graphs_enabled = std::getenv("RQ_NO_GRAPHS") == nullptr;
+    d->res_enabled = std::getenv("RQ_NO_RESIDENT") == nullptr;
+    device_registry(d, +1);
     *out = d;
     return RQ_OK;
 }
@@ -607,6 +753,23 @@ RQ_API int rq_device_set_speculation(rq_device* dev, int enable) {
     dev->speculate = enable != 0;
     dev->sp_suspended = false; dev->sp_misses = 0;
     if (!dev->speculate) { dev->sp_policy = nullptr; dev->sp_outstanding = false; }
+    return RQ_OK;
+}
+
+RQ_API int rq_device_set_resident(rq_device* dev, int enable) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;      // retires a running one
+    dev->res_enabled = enable != 0;
+    return RQ_OK;
+}
+
+RQ_API int rq_device_get_resident(const rq_device* dev, int* enabled, int* running, uint64_t* starts, uint64_t* commands, uint64_t* replays) {
+    RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (enabled) *enabled = dev->res_enabled ? 1 : 0;
+    if (running) *running = dev->res_running && __atomic_load_n(&dev->res_mem[16], __ATOMIC_ACQUIRE) != dev->res_launch_id ? 1 : 0;
+    if (starts) *starts = dev->res_starts;
+    if (commands) *commands = dev->res_posts;
+    if (replays) *replays = dev->res_replays;
     return RQ_OK;
 }
 
@@ -621,6 +784,11 @@ RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* su
 RQ_API int rq_device_destroy(rq_device* dev) {
     if (!dev) return RQ_OK;
     DeviceScope on_device(dev->ordinal);
+    (void)resident_retire(dev);
+    device_registry(dev, -1);
+    if (dev->res_stream) (void)hipStreamDestroy(dev->res_stream);
+    if (dev->res_mem) (void)hipHostFree(dev->res_mem);
+    delete dev->res_cmd;
     if (dev->stream) { (void)hipStreamSynchronize(dev->stream); (void)hipStreamDestroy(dev->stream); }
     if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);
@@ -880,7 +1048,8 @@ RQ_API int rq_env_create(rq_device* dev, uint32_t n_envs, uint64_t global_env_of
 
 RQ_API int rq_env_destroy(rq_env* env) {
     if (!env) return RQ_OK;
-    DeviceScope on_device(env->ordinal);   // hipFree synchronises the device; the parent is not touched
+    DeviceScope on_device(env->ordinal);   // hipFree synchronises the device; the parent is not touched - unless it is alive and
+    if (device_registry(env->dev, 0) && env->dev->res_running) (void)resident_retire(env->dev);     // keeps a resident executor
     if (env->obs) (void)hipFree(env->obs);
     if (env->obs_alt) (void)hipFree(env->obs_alt);
     for (float* b : env->state_pool) (void)hipFree(b);
@@ -995,8 +1164,9 @@ RQ_API int rq_state_assign(rq_state* dst, const rq_state* src) {
     RQ_REQUIRE(dst && src, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(dst->env == src->env, RQ_ERR_SHAPE_MISMATCH, "states belong to different envs");
     if (dst == src) return RQ_OK;
-    DeviceScope on_device(dst->env->dev); int rc = on_device.rc; if (rc) return rc;
+    DeviceScope on_device(dst->env->dev, rq::KeepResident{}); int rc = on_device.rc; if (rc) return rc;
     if (dst->exposed || src->exposed) {                // a raw pointer is out: the buffers stay what they are, real copy
+        rc = rq::resident_scope_hook(dst->env->dev); if (rc) return rc;
         rc = state_make_private(dst, false); if (rc) return rc;
         RQ_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)RQ_STATE_DIM * dst->env->ld * sizeof(float),
                               hipMemcpyDeviceToDevice, dst->env->dev->stream));
@@ -1060,7 +1230,7 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
     RQ_REQUIRE(params && state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(rng->initialized, RQ_ERR_NOT_INITIALIZED, "initialize_rng was not called");
-    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
+    DeviceScope on_device(dev, rq::KeepResident{}); rc = on_device.rc; if (rc) return rc;
     if (env->n < kGpuLayoutMinEnvs && !rq::noise_enabled(env->cfg) && obs_cache_holds(dev, env, params, state)) {
         // the step that produced this state assembled its observation already: obs_alt holds it on the device (swapped
         // in here), the pinned rows hold it for the host - wait for that launch's flag (usually long set) and copy; no launch
@@ -1071,6 +1241,7 @@ RQ_API int rq_observe(rq_device* dev, rq_env* env, const rq_params* params, cons
         std::memcpy(observation, dev->mb_obs, (size_t)env->n * RQ_OBSERVATION_DIM * sizeof(float));
         return RQ_OK;
     }
+    rc = rq::resident_scope_hook(dev); if (rc) return rc;     // a launch on the stream: the resident executor, if any, goes first
     if (dev->oc_env == env) obs_cache_drop(dev);       // a real observation replaces whatever was cached
     const bool mailbox = observation && env->n < kGpuLayoutMinEnvs;
     rq::Mailbox mb{};
@@ -1092,19 +1263,38 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     int rc = check_env_objects(dev, env, params, state); if (rc) return rc;
     RQ_REQUIRE(params && state && next_state && rng, RQ_ERR_INVALID_ARGUMENT, "null argument");
     RQ_REQUIRE(next_state->env == env, RQ_ERR_SHAPE_MISMATCH, "next_state belongs to another env");
-    DeviceScope on_device(dev); rc = on_device.rc; if (rc) return rc;
-    rq::Mailbox mb{};
+    DeviceScope on_device(dev, rq::KeepResident{}); rc = on_device.rc; if (rc) return rc;
     // small batches: the kernel also assembles the observation of the state it writes (device buffer + pinned rows):
     // the observe() of the next loop iteration then needs no launch (obs_cache_holds)
+    const bool cache_obs = env->n < kGpuLayoutMinEnvs && !rq::noise_enabled(env->cfg) && !params->exposed &&
+                           !next_state->exposed && !env->obs_exposed;
+    if (cache_obs) speculation_unused(dev);      // the previous step's speculated policy step, if nobody took it (this may suspend speculation)
+    // the policy a speculative step would evaluate on that observation (see rq_device::sp_*)
+    rq_policy* pol = cache_obs && dev->speculate && !dev->sp_suspended && action ? dev->last_policy : nullptr;
+    if (pol && !(policy_registry(pol, 0) && pol->dev == dev && pol->batch == env->n && pol->ld == env->ld && pol->hidden &&
+                 pol->hidden_alt && !pol->needs_reset && pol->sas_mode != RQ_SAS_SAMPLE))
+        pol = nullptr;
+    // Could the resident executor take this step?  The loop's own shape only: host actions in, observation cached, a speculated
+    // fp32 policy step behind it, out of place, on buffers the library alone writes - and the same objects as the kernel in flight.
+    const bool eligible = dev->res_enabled && pol && env->obs_alt && env->n <= kResidentMaxEnvs && next_state != state && !state->exposed &&
+                          pol->precision == RQ_POLICY_FP32 && pol->sas_mode == RQ_SAS_OFF;
+    dev->res_streak = eligible ? dev->res_streak + 1 : 0;
+    const bool bound = dev->res_running && dev->res_env == env && dev->res_env_uid == env->uid && dev->res_params == params &&
+                       dev->res_params_version == params->version && dev->res_policy == pol && dev->res_seed == rng->seed &&
+                       dev->res_packed == packed_of(pol) && std::memcmp(&dev->res_cfg, &env->cfg, sizeof(rq_env_config)) == 0 &&
+                       (env->obs_alt == dev->res_obs[0] || env->obs_alt == dev->res_obs[1]) &&
+                       (pol->hidden == dev->res_hidden[0] || pol->hidden == dev->res_hidden[1]) &&
+                       host_now_ns() - dev->res_last_post_ns < kResidentHostIdleNs;
+    const bool resident = eligible && (bound || dev->res_streak >= kResidentStreak);
+    if (dev->res_running && !(eligible && bound)) { rc = resident_retire(dev); if (rc) return rc; }
     // next_state is written in full: if it shares its buffer (state.assign(next_state) of the previous iteration) it
     // gets another one; stepping a state in place (next_state == state) keeps the contents it is about to read
     rc = state_make_private(next_state, next_state == state); if (rc) return rc;
-    const bool cache_obs = env->n < kGpuLayoutMinEnvs && !rq::noise_enabled(env->cfg) && !params->exposed &&
-                           !next_state->exposed && !env->obs_exposed;
     if (cache_obs && !env->obs_alt) {
         RQ_HIP(hipMalloc(&env->obs_alt, (size_t)RQ_OBSERVATION_DIM * env->ld * sizeof(float)));
         RQ_HIP(hipMemsetAsync(env->obs_alt, 0, (size_t)RQ_OBSERVATION_DIM * env->ld * sizeof(float), dev->stream));
     }
+    rq::Mailbox mb{};
     if (env->n < kGpuLayoutMinEnvs && (action || cache_obs)) {
         // the kernel reads the actions from the mailbox (and files them in env->act); nothing to wait for
         rc = ensure_mailbox(dev); if (rc) return rc;
@@ -1122,32 +1312,82 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     }
     obs_cache_drop(dev);
     next_state->version = fresh_version();
-    RQ_HIP_MB(rq::launch_step(dev->stream, batch_of(env), rq::step_cfg(env->cfg), params->d, state->d, env->act,
-                              next_state->d, env->st, /*rollout=*/0, 0u, rq::sample_cfg(env->cfg), rng->seed,
-                              nullptr, nullptr, mb, cache_obs ? env->obs_alt : nullptr, rq::NoiseCfg{}, false, 0u, nullptr), dev, mb);
+    StepPair pair{};
+    pair.b = batch_of(env); pair.c = rq::step_cfg(env->cfg); pair.sc = rq::sample_cfg(env->cfg); pair.seed = rng->seed;
+    pair.params = params->d; pair.state_in = state->d; pair.act = env->act; pair.state_out = next_state->d; pair.st = env->st;
+    pair.mb_step = mb; pair.obs_alt = cache_obs ? env->obs_alt : nullptr;
+    pair.spec = pol != nullptr;
+    if (pol) {
+        pair.packed = packed_of(pol); pair.hidden_out = pol->hidden_alt; pair.ld_h = pol->ld; pair.pol_act = pol->act;
+        pair.precision = pol->precision; pair.sas = sas_of(pol, 0, nullptr, 0); pair.hidden_in = pol->hidden;
+        pair.mb_spec = mailbox_for(dev, nullptr, 0, dev->mb_act);
+    }
+    bool posted = false;
+    if (resident) {
+        rc = ensure_resident_memory(dev); if (rc) return rc;
+        if (!dev->res_running) {
+            // nothing of the stream's may still be in flight when a kernel outside it starts reading the same buffers
+            const hipError_t se = hipStreamSynchronize(dev->stream);
+            if (se != hipSuccess) {
+                mailbox_abort(dev, pair.mb_spec); mailbox_abort(dev, mb);
+                return fail(RQ_ERR_HIP, std::string("rq_step: hipStreamSynchronize -> ") + hipGetErrorString(se));
+            }
+            rq::ResidentArgs ra{};
+            ra.b = pair.b; ra.c = pair.c; ra.sc = pair.sc; ra.seed = pair.seed;
+            ra.params = pair.params; ra.act = pair.act; ra.st = pair.st;
+            ra.obs_buf[0] = env->obs; ra.obs_buf[1] = env->obs_alt;
+            ra.packed = pair.packed; ra.hidden[0] = pol->hidden; ra.hidden[1] = pol->hidden_alt; ra.ld_h = pol->ld; ra.pol_act = pol->act;
+            ra.rows_action = dev->mb_in; ra.rows_obs = dev->mb_obs; ra.rows_act = dev->mb_act; ra.flag = dev->mb_flag;
+            ra.packet = dev->res_mem; ra.exited = dev->res_mem + 16;
+            ra.launch_id = ++dev->res_launch_id; if (ra.launch_id == 0) ra.launch_id = ++dev->res_launch_id;
+            ra.first_packet = dev->res_packet + 1;
+            ra.idle_ticks = kResidentIdleTicks;
+            const hipError_t e = rq::launch_resident(dev->res_stream, ra);
+            if (e == hipSuccess) {
+                dev->res_running = true; ++dev->res_starts;
+                dev->res_env = env; dev->res_env_uid = env->uid; dev->res_params = params; dev->res_params_version = params->version;
+                dev->res_policy = pol; dev->res_cfg = env->cfg; dev->res_seed = rng->seed; dev->res_packed = pair.packed;
+                dev->res_obs[0] = env->obs; dev->res_obs[1] = env->obs_alt; dev->res_hidden[0] = pol->hidden; dev->res_hidden[1] = pol->hidden_alt;
+            } else {
+                (void)hipGetLastError();         // no resident executor this time: the launches below do the step
+            }
+        }
+        if (dev->res_running) {
+            rc = resident_drain(dev);            // one command slot: the previous command must have been taken out of it
+            if (rc) { mailbox_abort(dev, pair.mb_spec); mailbox_abort(dev, mb); return rc; }
+        }
+        if (dev->res_running) {
+            uint32_t sum = 0;
+            const uint32_t* au = reinterpret_cast<const uint32_t*>(dev->mb_in);
+            for (uint32_t k = 0; k < env->n * RQ_ACTION_DIM; ++k) sum += au[k];
+            *dev->res_cmd = pair;
+            dev->res_pending = true;
+            const uint32_t bits = (env->obs_alt == dev->res_obs[1] ? rq::kRbObsSel : 0u) | (pol->hidden == dev->res_hidden[1] ? rq::kRbHiddenSel : 0u);
+            resident_write_packet(dev, bits, pair.state_in, pair.state_out, pair.mb_step.seq, pair.mb_spec.seq, sum);
+            dev->res_last_post_ns = host_now_ns();
+            ++dev->res_posts;
+            posted = true;
+        }
+    }
+    if (!posted) {
+        const hipError_t e = launch_step_pair(dev, pair);
+        if (e != hipSuccess) {
+            if (pair.spec) mailbox_abort(dev, pair.mb_spec);
+            mailbox_abort(dev, mb);
+            return fail(RQ_ERR_HIP, std::string("rq_step: launch -> ") + hipGetErrorString(e));
+        }
+    }
     if (cache_obs) {
         dev->oc_env = env; dev->oc_env_uid = env->uid; dev->oc_params = params; dev->oc_params_version = params->version;
         dev->oc_state[0] = next_state; dev->oc_version[0] = next_state->version;
         dev->oc_state[1] = nullptr;
         dev->oc_seq = mb.seq; dev->oc_n = env->n;
         dev->oc_in_alt = true;
-        // speculative policy step on the observation just cached (see rq_device::sp_*): never an error of this call
-        speculation_unused(dev);             // the previous step's, if nobody took it
-        rq_policy* pol = dev->speculate && !dev->sp_suspended && action ? dev->last_policy : nullptr;
         dev->sp_policy = nullptr;
-        if (pol && policy_registry(pol, 0) && pol->dev == dev && pol->batch == env->n && pol->ld == env->ld && pol->hidden &&
-            pol->hidden_alt && !pol->needs_reset && pol->sas_mode != RQ_SAS_SAMPLE) {
-            const rq::Mailbox smb = mailbox_for(dev, nullptr, 0, dev->mb_act);
-            const hipError_t e = rq::launch_actor_step(dev->stream, env->n, packed_of(pol), env->obs_alt, env->ld, pol->hidden_alt,
-                                                       pol->ld, pol->act, pol->ld, nullptr, pol->precision,
-                                                       sas_of(pol, 0, nullptr, 0), smb, pol->hidden);
-            if (e == hipSuccess) {
-                dev->sp_policy = pol; dev->sp_policy_version = pol->version; dev->sp_batch = env->n;
-                dev->sp_seq = smb.seq; dev->sp_oc_seq = dev->oc_seq;
-                dev->sp_outstanding = true;
-            } else {
-                mailbox_abort(dev, smb);
-            }
+        if (pol) {
+            dev->sp_policy = pol; dev->sp_policy_version = pol->version; dev->sp_batch = env->n;
+            dev->sp_seq = pair.mb_spec.seq; dev->sp_oc_seq = dev->oc_seq;
+            dev->sp_outstanding = true;
         }
     }
     if (dts) for (uint32_t i = 0; i < env->n; ++i) dts[i] = env->cfg.dt;
@@ -1267,6 +1507,7 @@ RQ_API int rq_policy_create(rq_device* dev, const float* weights, size_t n_weigh
 RQ_API int rq_policy_destroy(rq_policy* pol) {
     if (!pol) return RQ_OK;
     DeviceScope on_device(pol->ordinal);
+    if (device_registry(pol->dev, 0) && pol->dev->res_running) (void)resident_retire(pol->dev);
     policy_registry(pol, -1);      // rq_device::last_policy may still name this object: it is checked against the registry
     policy_free_buffers(pol);
     if (pol->w_dev) (void)hipFree(pol->w_dev);
@@ -1365,7 +1606,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     }
     RQ_REQUIRE(batch > 0, RQ_ERR_INVALID_ARGUMENT, "batch must be positive");
     if (observation) RQ_REQUIRE(obs_stride >= RQ_POLICY_INPUT_DIM, RQ_ERR_INVALID_ARGUMENT, "obs_stride < 22");
-    DeviceScope on_device(pol->dev); int rc = on_device.rc; if (rc) return rc;
+    DeviceScope on_device(pol->dev, rq::KeepResident{}); int rc = on_device.rc; if (rc) return rc;
     rq_device* dev = pol->dev;
     if (observation && action && !env && batch < kGpuLayoutMinEnvs) {
         // Did rq_step already evaluate this policy on exactly these rows (speculative step)?  Same policy, hidden state
@@ -1403,6 +1644,7 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
         }
         dev->last_policy = pol;         // the policy rq_step will speculate with
     }
+    rc = rq::resident_scope_hook(dev); if (rc) return rc;     // a launch on the stream: the resident executor, if any, goes first
     rc = policy_size(pol, batch); if (rc) return rc;
     const bool mailbox = batch < kGpuLayoutMinEnvs && (observation || action);
     const float* d_obs; uint32_t ld_obs;

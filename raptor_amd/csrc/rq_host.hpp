@@ -32,6 +32,7 @@ struct DeviceScope {
         tl_scope_depth = 1; tl_scope_device = target;
     }
     explicit DeviceScope(const rq_device* dev);
+    DeviceScope(const rq_device* dev, struct KeepResident);
     ~DeviceScope() {
         if (nested) { --tl_scope_depth; return; }
         tl_scope_depth = outer_depth; tl_scope_device = outer_device;
@@ -49,7 +50,16 @@ rq_device* env_device(const rq_env* env);
 uint32_t env_num_envs(const rq_env* env);
 const float* env_finished_returns(const rq_env* env);      // device [ld]
 
-inline DeviceScope::DeviceScope(const rq_device* dev) : DeviceScope(device_ordinal(dev)) {}
+// The resident executor of the small-batch loop (rq_capi.cpp resident_*) works outside the device's stream; any entry point that may touch
+// that stream first retires it (a few microseconds, and only when one is running): that is this hook, run by every DeviceScope made
+// from an rq_device.  The three calls of the loop itself construct their scope with KeepResident and retire explicitly on their slow paths.
+int resident_scope_hook(const rq_device* dev);
+struct KeepResident {};
+
+inline DeviceScope::DeviceScope(const rq_device* dev) : DeviceScope(device_ordinal(dev)) {
+    if (rc == RQ_OK) rc = resident_scope_hook(dev);
+}
+inline DeviceScope::DeviceScope(const rq_device* dev, KeepResident) : DeviceScope(device_ordinal(dev)) {}
 
 }  // namespace rq
 

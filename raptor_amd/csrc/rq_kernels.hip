@@ -413,7 +413,10 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
                                          const float* state, float* __restrict__ action, float* next_state,
                                          const StatsPtrs& st, uint32_t flags, const SampleCfg& sc, uint64_t seed,
                                          float* __restrict__ hidden, const float* __restrict__ weights,
-                                         const Mailbox& mb, const ObsNext& on) {
+                                         const Mailbox& mb, const ObsNext& on,
+                                         const float* act_regs = nullptr, float* obs_regs = nullptr) {
+    // act_regs / obs_regs (the resident executor, k_resident_loop): the env's four actions handed over in registers (they are also
+    // filed in `action`), and the 22 policy inputs of the observation this step assembles handed back - nullptr everywhere else
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
@@ -423,7 +426,10 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     y.load([&](int j) { return field(state, j, ld)[i]; });
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
-    if (mb.rows_in != nullptr) {             // actions handed over in the host mailbox (kernel argument)
+    if (act_regs != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = act_regs[j]; field(action, j, ld)[i] = a[j]; }
+    } else if (mb.rows_in != nullptr) {      // actions handed over in the host mailbox (kernel argument)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[j] = mb.rows_in[(size_t)i * mb.in_stride + j]; field(action, j, ld)[i] = a[j]; }
     } else {
@@ -471,6 +477,10 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
         }
 #pragma unroll
         for (int j = 0; j < 22; ++j) o[j] = head[j];
+        if (obs_regs != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 22; ++j) obs_regs[j] = head[j];
+        }
         const float inv = 2.0f / (k.rmax - k.rmin);
         o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
         o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
@@ -499,6 +509,125 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
         step_env<ROLLOUT>(i, b, c, params, state, action, next_state, st, flags, sc, seed, hidden, weights, mb, on);
     mailbox_signal(mb);
 }
+// ------------------------------------------------------------------ resident executor ---
+// The reference's loop at its own batch (README.md:96-99, `vector8`): observe -> evaluate_step -> step -> assign on a handful of envs
+// with NumPy arrays at every call.  Rounds 3-5 served an iteration with ONE kernel round trip (k_step assembles the next observation,
+// a speculative k_actor_step evaluates the policy on it) - two launches, 19.4 us per iteration against 6.9 us for a native CPU loop.
+// What is left of that is launch + completion.  This kernel removes it: ONE workgroup stays on the device for as long as the host
+// keeps calling step() on the same objects, polls a 64-byte command line in pinned host memory, and for every command does exactly what
+// the two launches did - step_env<false> (actions in from pinned rows, next state, statistics, the next observation to the env's
+// buffer and to pinned rows), then ACTOR::step on that observation (new hidden state to the policy's spare buffer, actions to pinned
+// rows) - publishing the same two sequence numbers in the same pinned flag.  The policy's operand image is loaded once for the
+// kernel's lifetime.  The kernel leaves on a QUIT command, or by itself after `idle_ticks` without one (a host that died or went
+// away must not leave a wave spinning), and says so in `exited`; a command it never consumed is replayed by the host as launches
+// (rq_capi.cpp resident_*).  It is never the device stream's business: the host retires it before anything else is enqueued.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loop(ResidentArgs ra) {
+    typedef ActorF32Lean ACTOR;                 // the build launch_actor_step takes for fp32 policies: the same bits
+    __shared__ uint32_t sh_pkt[16];
+    __shared__ uint32_t sh_sum[WAVES];
+    ACTOR actor;
+    actor.template load<WAVES>(ra.packed);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t wave_base = wave * 64u;
+    const uint32_t n = ra.b.n;
+    const uint32_t i0 = wave_base + lane;
+    const bool valid = i0 < n;
+    const uint32_t i = valid ? i0 : n - 1;
+    uint32_t expect = ra.first_packet;
+    unsigned long long idle_since = (unsigned long long)wall_clock64();
+    for (;;) {
+        if (wave == 0) {
+            uint32_t w = 0;
+            for (;;) {
+                if (lane < 16) w = __hip_atomic_load(const_cast<uint32_t*>(ra.packet) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const uint32_t head = __builtin_amdgcn_readlane(w, kRpHead), tail = __builtin_amdgcn_readlane(w, kRpTail);
+                if (head == expect && tail == expect) break;
+                if ((unsigned long long)wall_clock64() - idle_since > ra.idle_ticks) { w = lane == kRpBits ? kRbQuit : w; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane < 16) sh_pkt[lane] = w;
+        }
+        __syncthreads();
+        const uint32_t bits = __builtin_amdgcn_readfirstlane(sh_pkt[kRpBits]);
+        if (bits & kRbQuit) break;                                       // workgroup-uniform
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    // what the host wrote before the packet (the action rows)
+        const float* state_in = reinterpret_cast<const float*>(((uint64_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInHi]) << 32) |
+                                                               __builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInLo]));
+        float* state_out = reinterpret_cast<float*>(((uint64_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateOutHi]) << 32) |
+                                                    __builtin_amdgcn_readfirstlane(sh_pkt[kRpStateOutLo]));
+        const uint32_t seq_step = __builtin_amdgcn_readfirstlane(sh_pkt[kRpSeqStep]);
+        const uint32_t seq_spec = __builtin_amdgcn_readfirstlane(sh_pkt[kRpSeqSpec]);
+        const uint32_t want_sum = __builtin_amdgcn_readfirstlane(sh_pkt[kRpChecksum]);
+        float* obs_out = ra.obs_buf[bits & kRbObsSel ? 1 : 0];
+        const float* hidden_in = ra.hidden[bits & kRbHiddenSel ? 1 : 0];
+        float* hidden_out = ra.hidden[bits & kRbHiddenSel ? 0 : 1];
+        // the action rows travel beside the packet, not inside it: their sum must be the packet's (a line of rows read before the
+        // host wrote it would otherwise go unnoticed); re-read until it is - the host wrote them before the packet
+        float a_in[4];
+        for (uint32_t tries = 0;; ++tries) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = valid ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(ra.rows_action) + (size_t)i * 4 + k,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                a_in[k] = __builtin_bit_cast(float, u);
+                sum += u;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+            if (WAVES > 1) {
+                if (lane == 0) sh_sum[wave] = sum;
+                __syncthreads();
+                sum = 0;
+#pragma unroll
+                for (int v = 0; v < WAVES; ++v) sum += sh_sum[v];
+                __syncthreads();
+            }
+            if (sum == want_sum || tries > 100000u) break;
+        }
+        float x[22];
+#pragma unroll
+        for (int k = 0; k < 22; ++k) x[k] = 0.0f;                        // lanes past the batch feed the matrix cores zeros
+        if (valid) {
+            const Mailbox mb{nullptr, 0u, ra.rows_obs, nullptr, nullptr, 0u};
+            const ObsNext on{obs_out, NoiseCfg{}, 0u, 0u, nullptr};
+            step_env<false>(i, ra.b, ra.c, ra.params, state_in, ra.act, state_out, ra.st, 0u, ra.sc, ra.seed, nullptr, nullptr, mb, on,
+                            a_in, x);
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ra.flag, seq_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the policy on the observation just assembled: what the speculative k_actor_step launch computed
+        float hQ[4][4], a[4];
+        load_hidden_q(hidden_in, ra.ld_h, wave_base, n, hQ);
+        actor.step(x, hQ, a);
+        store_hidden_q(hidden_out, ra.ld_h, wave_base, __builtin_amdgcn_ballot_w64(valid), hQ);
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { field(ra.pol_act, k, ra.ld_h)[i] = a[k]; ra.rows_act[(size_t)i * 4 + k] = a[k]; }
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ra.flag, seq_spec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        expect += 1;
+        idle_since = (unsigned long long)wall_clock64();
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra) {
+    const uint32_t waves = (ra.b.n + 63u) / 64u;
+    if (ra.b.n == 0 || waves > 8) return hipErrorInvalidValue;
+    if (waves <= 1)      k_resident_loop<1><<<1, 64, 0, s>>>(ra);
+    else if (waves <= 2) k_resident_loop<2><<<1, 128, 0, s>>>(ra);
+    else if (waves <= 4) k_resident_loop<4><<<1, 256, 0, s>>>(ra);
+    else                 k_resident_loop<8><<<1, 512, 0, s>>>(ra);
+    return hipGetLastError();
+}
+
 // Chained-mode counterpart of the fused kernel's prologue under auto-reset: envs left frozen by an earlier
 // rollout start their next episode (sample_initial_state with the env's episode counter, policy state reset).
 __global__ __launch_bounds__(kBlock) void k_thaw_frozen(Batch b, SampleCfg c, uint64_t seed,

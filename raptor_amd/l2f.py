@@ -115,6 +115,18 @@ class Device:
         _lib.call("rq_device_get_speculation", self._h, C.byref(e), C.byref(s), C.byref(m))
         return {"enabled": bool(e.value), "suspended": bool(s.value), "consecutive_misses": int(m.value)}
 
+    def set_resident(self, enable):
+        """The small-batch loop's resident executor (rq_device_set_resident, include/raptor_quad.h): off / on for this device."""
+        _lib.call("rq_device_set_resident", self._h, 1 if enable else 0)
+
+    def resident(self):
+        """-> {"enabled", "running", "starts", "commands", "replays"}: is a resident kernel on the device now; kernels started,
+        commands posted to them, commands replayed as launches since the device was created."""
+        e, r = C.c_int(), C.c_int()
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.call("rq_device_get_resident", self._h, C.byref(e), C.byref(r), C.byref(a), C.byref(b), C.byref(c))
+        return {"enabled": bool(e.value), "running": bool(r.value), "starts": int(a.value), "commands": int(b.value), "replays": int(c.value)}
+
     @property
     def stream(self):
         s = C.c_void_p()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_status_strings():
     from raptor_amd import _lib
     lib = _lib.load()
-    assert lib.rq_abi_version() == 4
+    assert lib.rq_abi_version() == 5
     assert lib.rq_status_string(0) == b"ok"
     assert b"device" in lib.rq_status_string(-2)
 
