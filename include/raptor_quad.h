@@ -522,6 +522,9 @@ RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
  * kernels started, commands posted, and commands replayed as launches since the device was created. */
 RQ_API int rq_device_set_resident(rq_device* dev, int enable);
 RQ_API int rq_device_get_resident(const rq_device* dev, int* enabled, int* running, uint64_t* starts, uint64_t* commands, uint64_t* replays);
+/* Six device timestamps (100 MHz ticks) of the last command the resident kernel finished: command seen, action rows read, env stepped
+ * (observation rows written), first sequence number published, policy evaluated (action rows written), second number published. */
+RQ_API int rq_device_get_resident_timing(const rq_device* dev, uint64_t* ticks6);
 RQ_API int rq_device_get_speculation(const rq_device* dev, int* enabled, int* suspended, uint32_t* consecutive_misses);
 
 #ifdef __cplusplus

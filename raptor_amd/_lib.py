@@ -98,6 +98,7 @@ _SIGNATURES = {
     "rq_device_set_speculation": [_vp, C.c_int],
     "rq_device_get_speculation": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p],
     "rq_device_set_resident": [_vp, C.c_int],
+    "rq_device_get_resident_timing": [_vp, C.POINTER(C.c_uint64)],
     "rq_device_get_resident": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "rq_device_stream": [_vp, C.POINTER(_vp)],
     "rq_rng_create": [_vp, C.POINTER(_vp)],

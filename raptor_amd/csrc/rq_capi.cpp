@@ -159,7 +159,7 @@ struct rq_device {
     struct StepPair* res_cmd = nullptr;  // the command most recently posted: what a replay as launches needs
 };
 constexpr uint32_t kSpeculationMissLimit = 4;
-constexpr uint32_t kResidentMaxEnvs = 512;            // one workgroup: eight waves of 64 envs
+constexpr uint32_t kResidentMaxEnvs = 256;            // one workgroup, a wave per SIMD of one CU (at 512 envs the launches, spread over the chip, are faster)
 constexpr uint32_t kResidentStreak = 3;               // eligible steps in a row before a kernel is started
 constexpr uint64_t kResidentIdleTicks = 400000;       // the kernel leaves after 4 ms without a command (100 MHz ticks) ...
 constexpr uint64_t kResidentHostIdleNs = 1000000;     // ... and the host stops posting to one it has not fed for 1 ms
@@ -541,8 +541,8 @@ int resident_retire(rq_device* dev) {
 int ensure_resident_memory(rq_device* dev) {
     if (dev->res_mem) return RQ_OK;
     void* mem = nullptr;
-    RQ_HIP(hipHostMalloc(&mem, 256, hipHostMallocDefault));
-    std::memset(mem, 0, 256);
+    RQ_HIP(hipHostMalloc(&mem, 1024, hipHostMallocDefault));        // [0..15] command line, [16] exited, [32..43] timing, [64..] small action rows
+    std::memset(mem, 0, 1024);
     const hipError_t e = hipStreamCreateWithFlags(&dev->res_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipHostFree(mem); RQ_HIP(e); }
     dev->res_mem = static_cast<uint32_t*>(mem);
@@ -770,6 +770,13 @@ RQ_API int rq_device_get_resident(const rq_device* dev, int* enabled, int* runni
     if (starts) *starts = dev->res_starts;
     if (commands) *commands = dev->res_posts;
     if (replays) *replays = dev->res_replays;
+    return RQ_OK;
+}
+
+RQ_API int rq_device_get_resident_timing(const rq_device* dev, uint64_t* ticks6) {
+    RQ_REQUIRE(dev && ticks6, RQ_ERR_INVALID_ARGUMENT, "null argument");
+    RQ_REQUIRE(dev->res_mem, RQ_ERR_NOT_INITIALIZED, "no resident executor has run on this device");
+    std::memcpy(ticks6, dev->res_mem + 32, 6 * sizeof(uint64_t));
     return RQ_OK;
 }
 
@@ -1339,6 +1346,8 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             ra.packed = pair.packed; ra.hidden[0] = pol->hidden; ra.hidden[1] = pol->hidden_alt; ra.ld_h = pol->ld; ra.pol_act = pol->act;
             ra.rows_action = dev->mb_in; ra.rows_obs = dev->mb_obs; ra.rows_act = dev->mb_act; ra.flag = dev->mb_flag;
             ra.packet = dev->res_mem; ra.exited = dev->res_mem + 16;
+            ra.timing = reinterpret_cast<unsigned long long*>(dev->res_mem + 32);
+            ra.small_rows = dev->res_mem + 64;
             ra.launch_id = ++dev->res_launch_id; if (ra.launch_id == 0) ra.launch_id = ++dev->res_launch_id;
             ra.first_packet = dev->res_packet + 1;
             ra.idle_ticks = kResidentIdleTicks;
@@ -1360,6 +1369,8 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             uint32_t sum = 0;
             const uint32_t* au = reinterpret_cast<const uint32_t*>(dev->mb_in);
             for (uint32_t k = 0; k < env->n * RQ_ACTION_DIM; ++k) sum += au[k];
+            if (env->n <= rq::kResidentSmallEnvs)          // the small kernel reads the rows in the same load as the command line
+                std::memcpy(dev->res_mem + 64, dev->mb_in, (size_t)env->n * RQ_ACTION_DIM * sizeof(float));
             *dev->res_cmd = pair;
             dev->res_pending = true;
             const uint32_t bits = (env->obs_alt == dev->res_obs[1] ? rq::kRbObsSel : 0u) | (pol->hidden == dev->res_hidden[1] ? rq::kRbHiddenSel : 0u);

@@ -820,6 +820,74 @@ struct ActorF32T {
         run<kPipelined, N_STORES>(o, hQ, a, c, early_stores);
     }
 
+    // One tile of sixteen envs (round 6: the resident executor at the reference's own batch, README.md:96-99 with `vector8`): what
+    // run() computes for tile 0 and nothing else - 30 MFMAs instead of 120.  A tile's columns never meet another tile's, and every
+    // accumulator chain below is run()'s (bias, W_h h for k = 0..15, then W_i y0 for k = 0..15; layer_2 as run() writes it), so envs
+    // 0..15 get the bits the four-tile step gives them.  hq = hQ[0]; lanes 16 j + ... of rows >= 16 of the tiles hold nothing read.
+    __device__ __forceinline__ void step_tile0(const float (&o)[22], float (&hq)[4], float (&a)[4]) const {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
+        float hQ[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hQ[0][r] = hq[r];
+        f32x4 gr, gz, gni, gnh;
+        float X[6];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 22; ++f) wr[f] = o[f];
+        recurrent_tile<0>(hQ, gr, gz, gnh);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) X[s] = rd[0][4 * s];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 y0 = mfma16(W[QW_L0], X[0], zero);
+#pragma unroll
+        for (int s = 1; s < 6; ++s) y0 = mfma16(W[QW_L0 + s], X[s], y0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y0[r] = relu(y0[r]);
+        __builtin_amdgcn_sched_barrier(0);
+        gni = mfma16(W[QW_GI + 8], y0[0], cbni);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            gr = mfma16(W[QW_GI + 0 + s], y0[s], gr);
+            gz = mfma16(W[QW_GI + 4 + s], y0[s], gz);
+            if (s > 0) gni = mfma16(W[QW_GI + 8 + s], y0[s], gni);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gru_gates_prescaled(gr, gz, gni, gnh, hQ[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2 H01 = {hQ[0][0], hQ[0][1]}, H23 = {hQ[0][2], hQ[0][3]};
+        const f32x2 wl[4] = {{W[QW_L2 + 0], W[QW_L2 + 1]}, {W[QW_L2 + 4], W[QW_L2 + 5]}, {W[QW_L2 + 8], W[QW_L2 + 9]}, {W[QW_L2 + 12], W[QW_L2 + 13]}};
+        const f32x2 wh[4] = {{W[QW_L2 + 2], W[QW_L2 + 3]}, {W[QW_L2 + 6], W[QW_L2 + 7]}, {W[QW_L2 + 10], W[QW_L2 + 11]}, {W[QW_L2 + 14], W[QW_L2 + 15]}};
+        const f32x2 bl = {W[QW_B2 + 0], W[QW_B2 + 1]}, bh = {W[QW_B2 + 2], W[QW_B2 + 3]};
+        f32x2 pl, ph;
+        RQ_PK_FMA(pl, wl[0], H01, bl, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+        RQ_PK_FMA(ph, wh[0], H01, bh, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+        RQ_PK_FMA(pl, wl[1], H01, pl, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+        RQ_PK_FMA(ph, wh[1], H01, ph, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+        RQ_PK_FMA(pl, wl[2], H23, pl, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+        RQ_PK_FMA(ph, wh[2], H23, ph, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+        RQ_PK_FMA(pl, wl[3], H23, pl, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+        RQ_PK_FMA(ph, wh[3], H23, ph, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+        asm volatile("" : : "v"(pl), "v"(ph));
+        __builtin_amdgcn_sched_barrier(0);
+        red_wr[0] = f32x4{pl[0], pl[1], ph[0], ph[1]};
+        f32x4 R[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = red_rd[q];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x2 A01 = {R[0][0], R[0][1]}, A23 = {R[0][2], R[0][3]}, T01 = {R[2][0], R[2][1]}, T23 = {R[2][2], R[2][3]};
+        RQ_PK_ACC(A01, (f32x2{R[1][0], R[1][1]}));
+        RQ_PK_ACC(A23, (f32x2{R[1][2], R[1][3]}));
+        RQ_PK_ACC(T01, (f32x2{R[3][0], R[3][1]}));
+        RQ_PK_ACC(T23, (f32x2{R[3][2], R[3][3]}));
+        RQ_PK_ACC(A01, T01);
+        RQ_PK_ACC(A23, T23);
+        a[0] = A01[0]; a[1] = A01[1]; a[2] = A23[0]; a[3] = A23[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hq[r] = hQ[0][r];
+    }
+
     // `early_stores`: N_STORES vector-memory stores that only need the observation (the trajectory recorder's).
     // They are emitted into the first GRU pass and interleaved with its MFMAs - a store issues while the matrix
     // pipe executes, whereas a burst of 26 stores after the actor holds the wave for ~0.4 us (measured).

@@ -551,6 +551,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
         __syncthreads();
         const uint32_t bits = __builtin_amdgcn_readfirstlane(sh_pkt[kRpBits]);
         if (bits & kRbQuit) break;                                       // workgroup-uniform
+        const unsigned long long t_seen = (unsigned long long)wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    // what the host wrote before the packet (the action rows)
         const float* state_in = reinterpret_cast<const float*>(((uint64_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInHi]) << 32) |
                                                                __builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInLo]));
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
             }
             if (sum == want_sum || tries > 100000u) break;
         }
+        const unsigned long long t_rows = (unsigned long long)wall_clock64();
         float x[22];
 #pragma unroll
         for (int k = 0; k < 22; ++k) x[k] = 0.0f;                        // lanes past the batch feed the matrix cores zeros
@@ -595,9 +597,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
             step_env<false>(i, ra.b, ra.c, ra.params, state_in, ra.act, state_out, ra.st, 0u, ra.sc, ra.seed, nullptr, nullptr, mb, on,
                             a_in, x);
         }
+        const unsigned long long t_stepped = (unsigned long long)wall_clock64();
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(ra.flag, seq_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t_flag1 = (unsigned long long)wall_clock64();
         // the policy on the observation just assembled: what the speculative k_actor_step launch computed
         float hQ[4][4], a[4];
         load_hidden_q(hidden_in, ra.ld_h, wave_base, n, hQ);
@@ -607,24 +611,167 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
 #pragma unroll
             for (int k = 0; k < 4; ++k) { field(ra.pol_act, k, ra.ld_h)[i] = a[k]; ra.rows_act[(size_t)i * 4 + k] = a[k]; }
         }
+        const unsigned long long t_acted = (unsigned long long)wall_clock64();
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(ra.flag, seq_spec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         expect += 1;
         idle_since = (unsigned long long)wall_clock64();
+        if (threadIdx.x == 0 && ra.timing != nullptr) {                  // a diagnostic (rq_device_get_resident_timing): 100 MHz ticks of this command
+            ra.timing[0] = t_seen; ra.timing[1] = t_rows; ra.timing[2] = t_stepped; ra.timing[3] = t_flag1; ra.timing[4] = t_acted;
+            ra.timing[5] = idle_since;
+        }
     }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The same executor for the reference's own batch (`vector8`: at most 12 envs, one wave), with everything that is latency taken out of
+// a command's path (device-side timeline of a command at 8 envs: 8.2 us with k_resident_loop<1>, of which 1.7 us fetching the action
+// rows, 2.5 us the step, 2.9 us the policy, 1 us the two publications):
+//  - the action rows ride in the same vector load as the command line (lanes 16..63 of the poll read 48 dwords beside the 16 of the
+//    packet): no second trip over PCIe;
+//  - the env's constants, its state, its statistics and the policy's hidden state STAY IN REGISTERS from command to command - a
+//    command whose input state / hidden buffer is the one the previous command wrote (the loop's own shape: assign, speculation hit)
+//    loads nothing; any other buffer is loaded as before.  Everything is still stored every step: the buffers are what the API shows;
+//  - the policy runs on ONE 16-env tile (ActorF32T::step_tile0: 30 MFMAs instead of 120; same bits for the envs that exist).
+// Nothing else of the protocol differs: same packet, same flags, same rows out.
+__global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
+    typedef ActorF32Lean ACTOR;
+    ACTOR actor;
+    actor.template load<1>(ra.packed);
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const uint32_t n = ra.b.n;                 // <= 12
+    const bool valid = lane < n;
+    const uint32_t i = valid ? lane : n - 1;
+    const size_t ld = ra.b.ld;
+    const EnvConsts k = make_consts([&](int f) { return field(ra.params, f, ld)[i]; });      // the parameters cannot change under a running kernel
+    QuadState y{};
+    float f6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Stats st = load_stats(ra.st, i);
+    const float* have_state = nullptr;         // the buffer whose contents y / f6 hold
+    float hq[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* have_hidden = nullptr;
+    const uint32_t hj = j < n ? j : n - 1;     // tile 0 of the Q layout: lane (q, j) = env j, hidden features 4 q .. 4 q + 3
+    const uint32_t* poll_at = lane < 16 ? const_cast<const uint32_t*>(ra.packet) + lane : ra.small_rows + (lane - 16);
+    uint32_t expect = ra.first_packet;
+    unsigned long long idle_since = (unsigned long long)wall_clock64();
+    for (;;) {
+        uint32_t w, bits;
+        for (;;) {
+            w = __hip_atomic_load(poll_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t head = __builtin_amdgcn_readlane(w, kRpHead), tail = __builtin_amdgcn_readlane(w, kRpTail);
+            bits = __builtin_amdgcn_readlane(w, kRpBits);
+            if (head == expect && tail == expect) {
+                if (bits & kRbQuit) break;
+                uint32_t sum = (lane >= 16 && lane < 16 + 4 * n) ? w : 0u;       // the rows travelled beside the packet: their sum is in it
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+                if (sum == (uint32_t)__builtin_amdgcn_readlane(w, kRpChecksum)) break;
+            }
+            if ((unsigned long long)wall_clock64() - idle_since > ra.idle_ticks) { bits = kRbQuit; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (bits & kRbQuit) break;
+        const unsigned long long t_seen = (unsigned long long)wall_clock64();
+        const float* state_in = reinterpret_cast<const float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(w, kRpStateInHi) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane(w, kRpStateInLo));
+        float* state_out = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(w, kRpStateOutHi) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane(w, kRpStateOutLo));
+        const uint32_t seq_step = __builtin_amdgcn_readlane(w, kRpSeqStep), seq_spec = __builtin_amdgcn_readlane(w, kRpSeqSpec);
+        float* obs_out = ra.obs_buf[bits & kRbObsSel ? 1 : 0];
+        const float* hidden_in = ra.hidden[bits & kRbHiddenSel ? 1 : 0];
+        float* hidden_out = ra.hidden[bits & kRbHiddenSel ? 0 : 1];
+        float a_in[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a_in[c] = __builtin_bit_cast(float, (uint32_t)__shfl((int)w, (int)(16 + 4 * i + c)));
+        if (state_in != have_state) {            // wave-uniform: not the buffer the previous command wrote
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            y.load([&](int f) { return field(state_in, f, ld)[i]; });
+#pragma unroll
+            for (int f = 0; f < 6; ++f) f6[f] = field(state_in, (RQ_S_FORCE + f), ld)[i];
+        }
+        const unsigned long long t_rows = (unsigned long long)wall_clock64();
+        // ---- step_env<false>, its loads skipped: same functions in the same order ----
+        float x[22];
+#pragma unroll
+        for (int c = 0; c < 22; ++c) x[c] = 0.0f;
+        f32x2 AC01, AC23;
+        const Disturbance ds = make_disturbance(k, ra.c.gravity, f6);
+        bool term;
+        const float r = step_inplace<false>(ra.c, k, ds, y, a_in, AC01, AC23, term);
+        if (ra.c.action_history_raw) { AC01 = f32x2{a_in[0], a_in[1]}; AC23 = f32x2{a_in[2], a_in[3]}; }
+        const bool ended = stats_update(ra.c.episode_step_limit, r, term, st);
+        float o[RQ_OBSERVATION_DIM];
+        observe_head<false>(y, AC01, AC23, NoiseCfg{}, ra.seed, 0u, ra.b.env_offset + i, x);
+#pragma unroll
+        for (int c = 0; c < 22; ++c) o[c] = x[c];
+        const float inv = 2.0f / (k.rmax - k.rmin);
+        o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
+        o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < RQ_OBSERVATION_DIM; ++c) ra.rows_obs[(size_t)i * RQ_OBSERVATION_DIM + c] = o[c];       // what the host waits for first
+#pragma unroll
+            for (int c = 0; c < 4; ++c) field(ra.act, c, ld)[i] = a_in[c];
+            ra.st.last_reward[i] = r;
+            ra.st.last_terminated[i] = term ? 1 : 0;
+            ra.st.last_done[i] = term ? 1 : (ended ? 2 : 0);
+            store_stats(ra.st, i, st, ended);
+            y.store([&](int f, float v) { field(state_out, f, ld)[i] = v; });
+            field(state_out, (RQ_S_LAST_ACTION + 0), ld)[i] = AC01[0]; field(state_out, (RQ_S_LAST_ACTION + 1), ld)[i] = AC01[1];
+            field(state_out, (RQ_S_LAST_ACTION + 2), ld)[i] = AC23[0]; field(state_out, (RQ_S_LAST_ACTION + 3), ld)[i] = AC23[1];
+#pragma unroll
+            for (int c = 0; c < RQ_OBSERVATION_DIM; ++c) put<kNtObs>(&field(obs_out, c, ld)[i], o[c]);
+#pragma unroll
+            for (int f = 0; f < 6; ++f) field(state_out, (RQ_S_FORCE + f), ld)[i] = f6[f];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 22; ++c) x[c] = 0.0f;                 // lanes past the batch feed the matrix cores zeros
+        }
+        have_state = state_out;
+        const unsigned long long t_stepped = (unsigned long long)wall_clock64();
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(ra.flag, seq_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t_flag1 = (unsigned long long)wall_clock64();
+        // ---- the policy on that observation ----
+        if (hidden_in != have_hidden) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hq[c] = hidden_in[(size_t)(4 * q + c) * ra.ld_h + hj];
+        }
+        float a[4];
+        actor.step_tile0(x, hq, a);
+        if (j < n) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hidden_out[(size_t)(4 * q + c) * ra.ld_h + j] = hq[c];
+        }
+        have_hidden = hidden_out;
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ra.rows_act[(size_t)i * 4 + c] = a[c]; field(ra.pol_act, c, ra.ld_h)[i] = a[c]; }
+        }
+        const unsigned long long t_acted = (unsigned long long)wall_clock64();
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(ra.flag, seq_spec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        expect += 1;
+        idle_since = (unsigned long long)wall_clock64();
+        if (lane == 0 && ra.timing != nullptr) {
+            ra.timing[0] = t_seen; ra.timing[1] = t_rows; ra.timing[2] = t_stepped; ra.timing[3] = t_flag1; ra.timing[4] = t_acted;
+            ra.timing[5] = idle_since;
+        }
+    }
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra) {
     const uint32_t waves = (ra.b.n + 63u) / 64u;
-    if (ra.b.n == 0 || waves > 8) return hipErrorInvalidValue;
-    if (waves <= 1)      k_resident_loop<1><<<1, 64, 0, s>>>(ra);
+    if (ra.b.n == 0 || waves > 4) return hipErrorInvalidValue;
+    if (ra.b.n <= kResidentSmallEnvs && ra.small_rows != nullptr) k_resident_small<<<1, 64, 0, s>>>(ra);
+    else if (waves <= 1) k_resident_loop<1><<<1, 64, 0, s>>>(ra);
     else if (waves <= 2) k_resident_loop<2><<<1, 128, 0, s>>>(ra);
-    else if (waves <= 4) k_resident_loop<4><<<1, 256, 0, s>>>(ra);
-    else                 k_resident_loop<8><<<1, 512, 0, s>>>(ra);
+    else                 k_resident_loop<4><<<1, 256, 0, s>>>(ra);
     return hipGetLastError();
 }
 

@@ -103,20 +103,23 @@ struct ResidentArgs {
     float* hidden[2];             // the policy's two hidden-state buffers; bit 1 picks the one that is read (the other is written)
     uint32_t ld_h; float* pol_act;
     const float* rows_action;     // pinned: [n][4] actions of the command
+    const uint32_t* small_rows;   // pinned: the same rows once more, 48 dwords right where the poll of k_resident_small reads them (n <= 12)
     float* rows_obs;              // pinned: [n][RQ_OBSERVATION_DIM] observation of the state the step wrote
     float* rows_act;              // pinned: [n][4] the policy's actions on that observation
     uint32_t* flag;               // pinned: the device's mailbox flag (sequence numbers of finished work)
     volatile uint32_t* packet;    // pinned: 16 dwords, see ResidentPacket
     uint32_t* exited;             // pinned: receives launch_id when the kernel has left
+    unsigned long long* timing;   // pinned: six 100 MHz timestamps of the last command (seen, rows read, stepped, first flag, acted, done)
     uint32_t launch_id, first_packet;
     unsigned long long idle_ticks;       // 100 MHz ticks without a command after which the kernel leaves
 };
 // dwords of the command line (one 64-byte line of pinned host memory, written body first, then tail, then head)
 enum ResidentPacket { kRpHead = 0, kRpBits = 1, kRpStateInLo = 2, kRpStateInHi = 3, kRpStateOutLo = 4, kRpStateOutHi = 5,
                       kRpSeqStep = 6, kRpSeqSpec = 7, kRpChecksum = 8, kRpTail = 15 };
+constexpr uint32_t kResidentSmallEnvs = 12;      // 4 n action dwords fit the 48 lanes the command line leaves of one poll
 enum ResidentBits : uint32_t { kRbObsSel = 1u, kRbHiddenSel = 2u, kRbQuit = 4u };
 
-// one workgroup of ceil(n / 64) <= 8 waves on stream s; returns at once, the kernel stays until told to quit or idle for idle_ticks
+// one workgroup of ceil(n / 64) <= 4 waves on stream s; returns at once, the kernel stays until told to quit or idle for idle_ticks
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra);
 
 // vector.sample_initial_parameters (README.md:60)

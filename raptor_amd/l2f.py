@@ -127,6 +127,13 @@ class Device:
         _lib.call("rq_device_get_resident", self._h, C.byref(e), C.byref(r), C.byref(a), C.byref(b), C.byref(c))
         return {"enabled": bool(e.value), "running": bool(r.value), "starts": int(a.value), "commands": int(b.value), "replays": int(c.value)}
 
+    def resident_timing_us(self):
+        """Device-side timeline of the last command the resident kernel finished, in microseconds from the moment it saw the command:
+        {"rows_read", "stepped", "first_flag", "acted", "done"} (rq_device_get_resident_timing)."""
+        t = (C.c_uint64 * 6)()
+        _lib.call("rq_device_get_resident_timing", self._h, t)
+        return {k: (int(t[i + 1]) - int(t[0])) / 100.0 for i, k in enumerate(("rows_read", "stepped", "first_flag", "acted", "done"))}
+
     @property
     def stream(self):
         s = C.c_void_p()

@@ -48,6 +48,8 @@ def run(resident, iters, record):
             log.append((obs.copy(), action.copy()))
     us = (time.perf_counter() - t0) / iters * 1e6
     stats = device.resident()
+    if resident:
+        stats["last_command_us"] = device.resident_timing_us()
     final = state.numpy().copy()
     hidden = policy.hidden_state(args.envs).copy()
     rewards = env.rewards().copy()
