@@ -297,6 +297,34 @@ def call(name, *args):
     return status
 
 
+_from_buffer, _addressof = C.c_char.from_buffer, C.addressof
+
+
 def fptr(a):
-    """C-contiguous numpy array -> its address (an int; the argtypes of array arguments are void*)"""
-    return a.ctypes.data
+    """C-contiguous numpy array -> its address (an int; the argtypes of array arguments are void*).  `a.ctypes.data` builds a helper
+    object per call (0.9 us: with four arrays per iteration that was a fifth of the README loop at 8 envs); the buffer protocol
+    gives the same address in 0.4 us.  Read-only and empty arrays take the old way."""
+    try:
+        return _addressof(_from_buffer(a))
+    except (TypeError, ValueError):
+        return a.ctypes.data
+
+
+_ptr_cache = {}
+
+
+def fptr_cached(a):
+    """The same for an array that comes back call after call (the observation buffer of the README loop): address remembered per
+    object (a weak reference guards against an id being reused) - 0.2 us."""
+    e = _ptr_cache.get(id(a))
+    if e is not None and e[0]() is a:
+        return e[1]
+    import weakref
+    p = fptr(a)
+    if len(_ptr_cache) > 64:
+        _ptr_cache.clear()
+    try:
+        _ptr_cache[id(a)] = (weakref.ref(a), p)
+    except TypeError:
+        pass
+    return p

@@ -155,6 +155,7 @@ struct rq_device {
     rq_policy* res_policy = nullptr;
     rq_env_config res_cfg{}; uint64_t res_seed = 0;
     float* res_obs[2] = {nullptr, nullptr}; float* res_hidden[2] = {nullptr, nullptr}; const float* res_packed = nullptr;
+    bool res_timing = false;             // RQ_RESIDENT_TIMING in the environment: the kernel records its timestamps (rq_device_get_resident_timing)
     bool res_pending = false;            // res_cmd was posted and is not known to have been consumed
     struct StepPair* res_cmd = nullptr;  // the command most recently posted: what a replay as launches needs
 };
@@ -743,6 +744,7 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     d->speculate = std::getenv("RQ_NO_SPECULATION") == nullptr;
     d->graphs_enabled = std::getenv("RQ_NO_GRAPHS") == nullptr;
     d->res_enabled = std::getenv("RQ_NO_RESIDENT") == nullptr;
+    d->res_timing = std::getenv("RQ_RESIDENT_TIMING") != nullptr;
     device_registry(d, +1);
     *out = d;
     return RQ_OK;
@@ -1346,7 +1348,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             ra.packed = pair.packed; ra.hidden[0] = pol->hidden; ra.hidden[1] = pol->hidden_alt; ra.ld_h = pol->ld; ra.pol_act = pol->act;
             ra.rows_action = dev->mb_in; ra.rows_obs = dev->mb_obs; ra.rows_act = dev->mb_act; ra.flag = dev->mb_flag;
             ra.packet = dev->res_mem; ra.exited = dev->res_mem + 16;
-            ra.timing = reinterpret_cast<unsigned long long*>(dev->res_mem + 32);
+            ra.timing = dev->res_timing ? reinterpret_cast<unsigned long long*>(dev->res_mem + 32) : nullptr;
             ra.small_rows = dev->res_mem + 64;
             ra.launch_id = ++dev->res_launch_id; if (ra.launch_id == 0) ra.launch_id = ++dev->res_launch_id;
             ra.first_packet = dev->res_packet + 1;

@@ -276,6 +276,14 @@ class VectorModule:
             @config.setter
             def config(self, cfg):
                 _lib.call("rq_env_set_config", self._require("environment"), C.byref(cfg))
+                self._dt = None
+
+            def _step_dt(self):
+                """dt of the configuration in force (what ``step`` returns per env), asked of the library once per configuration."""
+                dt = getattr(self, "_dt", None)
+                if dt is None:
+                    dt = self._dt = float(self.config.dt)
+                return dt
 
             # --- device-resident observation / action buffers ---
             def observation(self):
@@ -506,6 +514,7 @@ class VectorModule:
     def initialize_environment(self, device, env):
         """README.md:59 — default MDP configuration."""
         _lib.call("rq_initialize_environment", device._h, env._ensure(device))
+        env._dt = None
 
     def sample_initial_parameters(self, device, env, params, rng):
         """README.md:60 — per-env dynamics parameters (domain randomisation)."""
@@ -525,7 +534,7 @@ class VectorModule:
             if (observation.dtype != np.float32 or not observation.flags.c_contiguous or
                     observation.shape != (self.N_ENVIRONMENTS, OBSERVATION_DIM)):
                 raise ValueError("observation must be C-contiguous float32 [N_ENVIRONMENTS, OBSERVATION_DIM]")
-            ptr = _lib.fptr(observation)
+            ptr = _lib.fptr_cached(observation)
         _lib.call("rq_observe", device._h, env._require("environment"), params._require("VectorParameters"),
                   state._require("VectorState"), ptr, rng._require("rng"))
 
@@ -543,7 +552,8 @@ class VectorModule:
                   state._require("VectorState"), aptr, next_state._ensure(env), rng._require("rng"), None)
         # every env advances by the configured dt (rq_step's dts output is that constant N times); turning 65 536
         # float32 into Python floats one by one took longer than the step itself (numpy tolist: ~1 ms)
-        return [float(env.config.dt)] * self.N_ENVIRONMENTS
+        # (the dt itself is remembered per env: asking the library for the whole configuration cost the README loop 2 us per step)
+        return [env._step_dt()] * self.N_ENVIRONMENTS
 
     def step_device(self, device, env, params, state, next_state, rng):
         """``step`` without host traffic: action from the env's device buffer, no dt list."""
