@@ -300,27 +300,42 @@ def call(name, *args):
 _from_buffer, _addressof = C.c_char.from_buffer, C.addressof
 
 
-def fptr(a):
-    """C-contiguous numpy array -> its address (an int; the argtypes of array arguments are void*).  `a.ctypes.data` builds a helper
-    object per call (0.9 us: with four arrays per iteration that was a fifth of the README loop at 8 envs); the buffer protocol
-    gives the same address in 0.4 us.  Read-only and empty arrays take the old way."""
+def _fptr_portable(a):
     try:
         return _addressof(_from_buffer(a))
     except (TypeError, ValueError):
         return a.ctypes.data
 
 
+try:                                  # the optional CPython helper (csrc/rq_pyfast.c, built by raptor_amd.build): 0.06 us, any array
+    from ._rq_fast import address as _fast_address
+except ImportError:                   # not built (no gcc / Python.h): the portable ways below
+    _fast_address = None
+
+
+def fptr(a):
+    """numpy array -> the address of its first element (an int; the argtypes of array arguments are void*).  `a.ctypes.data` builds a
+    helper object per call (0.9 us: with four arrays per iteration that was a fifth of the README loop at 8 envs).  With the
+    _rq_fast helper `fptr` IS its `address` (one PyObject_GetBuffer, 0.07 us, strided views included); without it: the buffer
+    protocol through ctypes (0.4 us; read-only, strided and empty arrays fall back to `.ctypes.data`)."""
+    return _fptr_portable(a)
+
+
+if _fast_address is not None:
+    fptr = _fast_address              # noqa: F811  (no Python frame in between)
+
+
 _ptr_cache = {}
 
 
 def fptr_cached(a):
-    """The same for an array that comes back call after call (the observation buffer of the README loop): address remembered per
-    object (a weak reference guards against an id being reused) - 0.2 us."""
+    """The same for an array that comes back call after call (the observation buffer of the README loop) when the helper is missing:
+    address remembered per object (a weak reference guards against an id being reused) - 0.2 us."""
     e = _ptr_cache.get(id(a))
     if e is not None and e[0]() is a:
         return e[1]
     import weakref
-    p = fptr(a)
+    p = _fptr_portable(a)
     if len(_ptr_cache) > 64:
         _ptr_cache.clear()
     try:
@@ -328,3 +343,7 @@ def fptr_cached(a):
     except TypeError:
         pass
     return p
+
+
+if _fast_address is not None:
+    fptr_cached = _fast_address       # noqa: F811

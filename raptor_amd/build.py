@@ -174,6 +174,8 @@ def build(force=False, verbose=False, variant=None, extra_flags=(), patches=()):
         if ignored and verbose:
             print("ignored for the product build (experiment builds only, --variant):", ", ".join(ignored))
     os.makedirs(obj_dir, exist_ok=True)
+    if not variant:
+        build_pyfast(force, verbose)
     _bundle_targets()
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         results = list(ex.map(lambda s: _compile(s, force, src_dir, obj_dir, flags, rewrite), SOURCES))
@@ -192,6 +194,28 @@ def build(force=False, verbose=False, variant=None, extra_flags=(), patches=()):
     elif verbose:
         print("up to date:", lib)
     return lib
+
+
+def build_pyfast(force=False, verbose=False):
+    """raptor_amd/_rq_fast<EXT_SUFFIX>: the veneer's optional CPython helper (csrc/rq_pyfast.c: array address in 60 ns).  gcc only; a
+    missing compiler or Python.h is not an error - raptor_amd/_lib.py then takes addresses the slower way.  -> path or None"""
+    import sysconfig
+    src = os.path.join(CSRC, "rq_pyfast.c")
+    out = os.path.join(PKG, "_rq_fast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if not force and not _stale(out, [src]):
+        return out
+    cc = shutil.which("gcc") or shutil.which("cc")
+    inc = sysconfig.get_paths().get("include")
+    if not cc or not inc or not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    r = subprocess.run([cc, "-O2", "-shared", "-fPIC", "-Wall", "-I", inc, src, "-o", out], capture_output=True, text=True)
+    if r.returncode != 0:
+        if verbose:
+            print("_rq_fast not built:", r.stderr[-500:])
+        return None
+    if verbose:
+        print("built", out)
+    return out
 
 
 def library_sha256(path=LIB):

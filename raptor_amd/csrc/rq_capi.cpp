@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstring>
 #include <ctime>
+#include <emmintrin.h>
 #include <new>
 #include <mutex>
 #include <string>
@@ -75,6 +76,18 @@ static uint64_t fresh_version() {
     static std::atomic<uint64_t> counter{1};
     return counter.fetch_add(1, std::memory_order_relaxed) + 1;
 }
+
+constexpr uint32_t kResidentMaxEnvs = 256;            // one workgroup, a wave per SIMD of one CU (at 512 envs the launches, spread over the chip, are faster)
+constexpr uint32_t kResidentStreak = 3;               // eligible steps in a row before a kernel is started
+constexpr uint64_t kResidentIdleTicks = 400000;       // the kernel leaves after 4 ms without a command (100 MHz ticks) ...
+constexpr uint64_t kResidentHostIdleNs = 1000000;     // ... and the host stops posting to one it has not fed for 1 ms
+// A kernel that never ends would make hipDeviceSynchronize - a learner's torch.cuda.synchronize() on another thread - wait for as long
+// as the loop runs: the kernel leaves between two commands once it is 2 ms old, and the host, which knows its age, retires it at
+// 1.5 ms and starts the next one (one launch per ~190 iterations at 8 envs).
+constexpr uint64_t kResidentLifeTicks = 200000;
+constexpr uint64_t kResidentHostLifeNs = 1500000;
+constexpr size_t kResCmdBytes = 8192;                 // command memory: [0..15] the command line, [64 .. 64 + 4 x 256) the action rows
+
 
 struct rq_device {
     int ordinal = 0;
@@ -144,11 +157,17 @@ struct rq_device {
     // same two sequence numbers in mb_flag.  Anything else the device is asked to do retires it first (resident_scope_hook).
     hipStream_t res_stream = nullptr;
     uint32_t* res_mem = nullptr;         // pinned: [0..15] the command line, [16] launch id of the kernel that has left
+    uint32_t* res_cmd_mem = nullptr;     // where commands are written: res_mem, or - on a large-BAR platform - fine-grained DEVICE memory the
+                                         // host writes straight into ([0..15] command line, [64..] action rows): the wave polls local memory
+    bool res_cmd_on_device = false;
     bool res_enabled = true;             // RQ_NO_RESIDENT in the environment: off
     bool res_running = false;
     uint32_t res_launch_id = 0, res_packet = 0;     // id of the kernel that is running; commands posted to it
     uint32_t res_streak = 0;             // eligible rq_step calls in a row with nothing else asked of the device in between
     uint64_t res_last_post_ns = 0;       // host clock of the last command: a kernel idle for too long may be leaving, it is not posted to
+    uint64_t res_born_ns = 0;            // host clock at the kernel's launch
+    uint64_t res_idle_ticks = kResidentIdleTicks, res_life_ticks = kResidentLifeTicks;       // RQ_RESIDENT_IDLE_TICKS / _LIFE_TICKS (tests)
+    uint64_t res_host_idle_ns = kResidentHostIdleNs, res_host_life_ns = kResidentHostLifeNs; // RQ_RESIDENT_HOST_IDLE_NS / _HOST_LIFE_NS (tests)
     uint64_t res_starts = 0, res_posts = 0, res_replays = 0;     // diagnostics
     const rq_env* res_env = nullptr; uint64_t res_env_uid = 0;   // what the running kernel was started for
     const rq_params* res_params = nullptr; uint64_t res_params_version = 0;
@@ -160,11 +179,6 @@ struct rq_device {
     struct StepPair* res_cmd = nullptr;  // the command most recently posted: what a replay as launches needs
 };
 constexpr uint32_t kSpeculationMissLimit = 4;
-constexpr uint32_t kResidentMaxEnvs = 256;            // one workgroup, a wave per SIMD of one CU (at 512 envs the launches, spread over the chip, are faster)
-constexpr uint32_t kResidentStreak = 3;               // eligible steps in a row before a kernel is started
-constexpr uint64_t kResidentIdleTicks = 400000;       // the kernel leaves after 4 ms without a command (100 MHz ticks) ...
-constexpr uint64_t kResidentHostIdleNs = 1000000;     // ... and the host stops posting to one it has not fed for 1 ms
-
 // the two launches of a small-batch step: k_step (+ the next observation) and the speculative policy step on it
 struct StepPair {
     rq::Batch b; rq::StepCfg c; rq::SampleCfg sc; uint64_t seed;
@@ -512,17 +526,28 @@ int resident_drain(rq_device* dev) {
     return rc;
 }
 
+// The command line is written as four 16-byte stores, the quarter that holds `head` last: device memory behind the BAR is mapped
+// uncached or write-combining, where every store is a transaction of its own (forty 4-byte stores cost rq_step 0.5 us) and, write-
+// combining, may leave in any order until a store fence.  A reader that finds head == tail == id has the whole line - and the action
+// rows, which were written (one 16-byte store per env) before it.
 void resident_write_packet(rq_device* dev, uint32_t bits, const float* state_in, float* state_out, uint32_t seq_step, uint32_t seq_spec,
                            uint32_t checksum) {
-    volatile uint32_t* pk = dev->res_mem;
     const uint32_t id = ++dev->res_packet;
     const uint64_t a = reinterpret_cast<uint64_t>(state_in), b = reinterpret_cast<uint64_t>(state_out);
-    pk[rq::kRpBits] = bits;
-    pk[rq::kRpStateInLo] = (uint32_t)a; pk[rq::kRpStateInHi] = (uint32_t)(a >> 32);
-    pk[rq::kRpStateOutLo] = (uint32_t)b; pk[rq::kRpStateOutHi] = (uint32_t)(b >> 32);
-    pk[rq::kRpSeqStep] = seq_step; pk[rq::kRpSeqSpec] = seq_spec; pk[rq::kRpChecksum] = checksum;
-    __atomic_store_n(const_cast<uint32_t*>(&pk[rq::kRpTail]), id, __ATOMIC_RELEASE);       // body, then tail, then head: a reader that
-    __atomic_store_n(const_cast<uint32_t*>(&pk[rq::kRpHead]), id, __ATOMIC_RELEASE);       // finds head == tail == id has the body
+    alignas(16) uint32_t line[16] = {};
+    line[rq::kRpHead] = id; line[rq::kRpBits] = bits;
+    line[rq::kRpStateInLo] = (uint32_t)a; line[rq::kRpStateInHi] = (uint32_t)(a >> 32);
+    line[rq::kRpStateOutLo] = (uint32_t)b; line[rq::kRpStateOutHi] = (uint32_t)(b >> 32);
+    line[rq::kRpSeqStep] = seq_step; line[rq::kRpSeqSpec] = seq_spec; line[rq::kRpChecksum] = checksum;
+    line[rq::kRpTail] = id;
+    __m128i* dst = reinterpret_cast<__m128i*>(dev->res_cmd_mem);
+    const __m128i* src = reinterpret_cast<const __m128i*>(line);
+    _mm_store_si128(dst + 1, _mm_load_si128(src + 1));
+    _mm_store_si128(dst + 2, _mm_load_si128(src + 2));
+    _mm_store_si128(dst + 3, _mm_load_si128(src + 3));
+    _mm_sfence();
+    _mm_store_si128(dst + 0, _mm_load_si128(src + 0));
+    _mm_sfence();
 }
 
 // tell the kernel to leave and wait until it has
@@ -547,6 +572,25 @@ int ensure_resident_memory(rq_device* dev) {
     const hipError_t e = hipStreamCreateWithFlags(&dev->res_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipHostFree(mem); RQ_HIP(e); }
     dev->res_mem = static_cast<uint32_t*>(mem);
+    dev->res_cmd_mem = dev->res_mem;
+    // Where the wave looks for its commands.  Pinned host memory works everywhere: every poll is a read across PCIe, and a command is
+    // seen ~1.7 us after it was written.  Where the platform maps VRAM for the CPU (large BAR) the command line lives in fine-grained
+    // device memory instead: the host's stores cross PCIe once, as posted writes, the wave polls its own memory - a host -> wave ->
+    // host round trip of 1.8 us instead of 2.5 (tools/bar_probe.hip).  The host never reads that memory.
+    int large_bar = 0;
+    if (std::getenv("RQ_RESIDENT_HOST_COMMANDS") == nullptr &&
+        hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev->ordinal) == hipSuccess && large_bar) {
+        void* fine = nullptr;
+        if (hipExtMallocWithFlags(&fine, kResCmdBytes, hipDeviceMallocFinegrained) == hipSuccess) {
+            if (hipMemset(fine, 0, kResCmdBytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+                dev->res_cmd_mem = static_cast<uint32_t*>(fine);
+                dev->res_cmd_on_device = true;
+            } else {
+                (void)hipFree(fine);
+            }
+        }
+        (void)hipGetLastError();
+    }
     if (!dev->res_cmd) dev->res_cmd = new (std::nothrow) StepPair();
     RQ_REQUIRE(dev->res_cmd, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     return RQ_OK;
@@ -745,6 +789,10 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     d->graphs_enabled = std::getenv("RQ_NO_GRAPHS") == nullptr;
     d->res_enabled = std::getenv("RQ_NO_RESIDENT") == nullptr;
     d->res_timing = std::getenv("RQ_RESIDENT_TIMING") != nullptr;
+    if (const char* v = std::getenv("RQ_RESIDENT_IDLE_TICKS")) d->res_idle_ticks = std::strtoull(v, nullptr, 10);
+    if (const char* v = std::getenv("RQ_RESIDENT_LIFE_TICKS")) d->res_life_ticks = std::strtoull(v, nullptr, 10);
+    if (const char* v = std::getenv("RQ_RESIDENT_HOST_IDLE_NS")) d->res_host_idle_ns = std::strtoull(v, nullptr, 10);
+    if (const char* v = std::getenv("RQ_RESIDENT_HOST_LIFE_NS")) d->res_host_life_ns = std::strtoull(v, nullptr, 10);
     device_registry(d, +1);
     *out = d;
     return RQ_OK;
@@ -796,6 +844,7 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     (void)resident_retire(dev);
     device_registry(dev, -1);
     if (dev->res_stream) (void)hipStreamDestroy(dev->res_stream);
+    if (dev->res_cmd_on_device && dev->res_cmd_mem) (void)hipFree(dev->res_cmd_mem);
     if (dev->res_mem) (void)hipHostFree(dev->res_mem);
     delete dev->res_cmd;
     if (dev->stream) { (void)hipStreamSynchronize(dev->stream); (void)hipStreamDestroy(dev->stream); }
@@ -1288,12 +1337,13 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     const bool eligible = dev->res_enabled && pol && env->obs_alt && env->n <= kResidentMaxEnvs && next_state != state && !state->exposed &&
                           pol->precision == RQ_POLICY_FP32 && pol->sas_mode == RQ_SAS_OFF;
     dev->res_streak = eligible ? dev->res_streak + 1 : 0;
+    const uint64_t now_ns = dev->res_running ? host_now_ns() : 0;
     const bool bound = dev->res_running && dev->res_env == env && dev->res_env_uid == env->uid && dev->res_params == params &&
                        dev->res_params_version == params->version && dev->res_policy == pol && dev->res_seed == rng->seed &&
                        dev->res_packed == packed_of(pol) && std::memcmp(&dev->res_cfg, &env->cfg, sizeof(rq_env_config)) == 0 &&
                        (env->obs_alt == dev->res_obs[0] || env->obs_alt == dev->res_obs[1]) &&
                        (pol->hidden == dev->res_hidden[0] || pol->hidden == dev->res_hidden[1]) &&
-                       host_now_ns() - dev->res_last_post_ns < kResidentHostIdleNs;
+                       now_ns - dev->res_last_post_ns < dev->res_host_idle_ns && now_ns - dev->res_born_ns < dev->res_host_life_ns;
     const bool resident = eligible && (bound || dev->res_streak >= kResidentStreak);
     if (dev->res_running && !(eligible && bound)) { rc = resident_retire(dev); if (rc) return rc; }
     // next_state is written in full: if it shares its buffer (state.assign(next_state) of the previous iteration) it
@@ -1347,15 +1397,21 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             ra.obs_buf[0] = env->obs; ra.obs_buf[1] = env->obs_alt;
             ra.packed = pair.packed; ra.hidden[0] = pol->hidden; ra.hidden[1] = pol->hidden_alt; ra.ld_h = pol->ld; ra.pol_act = pol->act;
             ra.rows_action = dev->mb_in; ra.rows_obs = dev->mb_obs; ra.rows_act = dev->mb_act; ra.flag = dev->mb_flag;
-            ra.packet = dev->res_mem; ra.exited = dev->res_mem + 16;
+            ra.packet = dev->res_cmd_mem; ra.exited = dev->res_mem + 16;
+            if (dev->res_cmd_on_device) ra.rows_action = reinterpret_cast<const float*>(dev->res_cmd_mem + 64);     // the rows beside the line
             ra.timing = dev->res_timing ? reinterpret_cast<unsigned long long*>(dev->res_mem + 32) : nullptr;
-            ra.small_rows = dev->res_mem + 64;
+            ra.small_rows = dev->res_cmd_mem + 64;
             ra.launch_id = ++dev->res_launch_id; if (ra.launch_id == 0) ra.launch_id = ++dev->res_launch_id;
             ra.first_packet = dev->res_packet + 1;
-            ra.idle_ticks = kResidentIdleTicks;
+            ra.idle_ticks = dev->res_idle_ticks; ra.life_ticks = dev->res_life_ticks;
+            if (std::getenv("RQ_RESIDENT_DEBUG"))
+                std::fprintf(stderr, "resident start: n %u ld %u params %p act %p st.returns %p obs %p %p packed %p hidden %p %p ld_h %u pol_act %p rows_action %p rows_obs %p rows_act %p flag %p packet %p exited %p small_rows %p state_in %p state_out %p\n",
+                             ra.b.n, ra.b.ld, (const void*)ra.params, (void*)ra.act, (void*)ra.st.returns, (void*)ra.obs_buf[0], (void*)ra.obs_buf[1], (const void*)ra.packed,
+                             (void*)ra.hidden[0], (void*)ra.hidden[1], ra.ld_h, (void*)ra.pol_act, (const void*)ra.rows_action, (void*)ra.rows_obs, (void*)ra.rows_act,
+                             (void*)ra.flag, (const void*)ra.packet, (void*)ra.exited, (const void*)ra.small_rows, (const void*)pair.state_in, (void*)pair.state_out);
             const hipError_t e = rq::launch_resident(dev->res_stream, ra);
             if (e == hipSuccess) {
-                dev->res_running = true; ++dev->res_starts;
+                dev->res_running = true; ++dev->res_starts; dev->res_born_ns = host_now_ns();
                 dev->res_env = env; dev->res_env_uid = env->uid; dev->res_params = params; dev->res_params_version = params->version;
                 dev->res_policy = pol; dev->res_cfg = env->cfg; dev->res_seed = rng->seed; dev->res_packed = pair.packed;
                 dev->res_obs[0] = env->obs; dev->res_obs[1] = env->obs_alt; dev->res_hidden[0] = pol->hidden; dev->res_hidden[1] = pol->hidden_alt;
@@ -1371,8 +1427,10 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             uint32_t sum = 0;
             const uint32_t* au = reinterpret_cast<const uint32_t*>(dev->mb_in);
             for (uint32_t k = 0; k < env->n * RQ_ACTION_DIM; ++k) sum += au[k];
-            if (env->n <= rq::kResidentSmallEnvs)          // the small kernel reads the rows in the same load as the command line
-                std::memcpy(dev->res_mem + 64, dev->mb_in, (size_t)env->n * RQ_ACTION_DIM * sizeof(float));
+            if (env->n <= rq::kResidentSmallEnvs || dev->res_cmd_on_device) {  // the small kernel reads the rows in the same load as the
+                __m128i* rows = reinterpret_cast<__m128i*>(dev->res_cmd_mem + 64);     // command line; in device memory every kernel reads them there
+                for (uint32_t k = 0; k < env->n; ++k) _mm_store_si128(rows + k, _mm_loadu_si128(reinterpret_cast<const __m128i*>(au) + k));
+            }
             *dev->res_cmd = pair;
             dev->res_pending = true;
             const uint32_t bits = (env->obs_alt == dev->res_obs[1] ? rq::kRbObsSel : 0u) | (pol->hidden == dev->res_hidden[1] ? rq::kRbHiddenSel : 0u);

@@ -536,6 +536,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
     const uint32_t i = valid ? i0 : n - 1;
     uint32_t expect = ra.first_packet;
     unsigned long long idle_since = (unsigned long long)wall_clock64();
+    const unsigned long long born = idle_since;
     for (;;) {
         if (wave == 0) {
             uint32_t w = 0;
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
                 if (lane < 16) w = __hip_atomic_load(const_cast<uint32_t*>(ra.packet) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const uint32_t head = __builtin_amdgcn_readlane(w, kRpHead), tail = __builtin_amdgcn_readlane(w, kRpTail);
                 if (head == expect && tail == expect) break;
-                if ((unsigned long long)wall_clock64() - idle_since > ra.idle_ticks) { w = lane == kRpBits ? kRbQuit : w; break; }
+                const unsigned long long now = (unsigned long long)wall_clock64();       // idle for too long, or old enough (a device-wide
+                if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) { w = lane == kRpBits ? kRbQuit : w; break; }     // synchronize waits for this kernel)
                 __builtin_amdgcn_s_sleep(2);
             }
             if (lane < 16) sh_pkt[lane] = w;
@@ -553,10 +555,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
         if (bits & kRbQuit) break;                                       // workgroup-uniform
         const unsigned long long t_seen = (unsigned long long)wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    // what the host wrote before the packet (the action rows)
-        const float* state_in = reinterpret_cast<const float*>(((uint64_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInHi]) << 32) |
-                                                               __builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInLo]));
-        float* state_out = reinterpret_cast<float*>(((uint64_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateOutHi]) << 32) |
-                                                    __builtin_amdgcn_readfirstlane(sh_pkt[kRpStateOutLo]));
+        // (the builtin returns int: without the casts a low half with its top bit set sign-extends over the high half)
+        const float* state_in = reinterpret_cast<const float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInHi]) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateInLo]));
+        float* state_out = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateOutHi]) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readfirstlane(sh_pkt[kRpStateOutLo]));
         const uint32_t seq_step = __builtin_amdgcn_readfirstlane(sh_pkt[kRpSeqStep]);
         const uint32_t seq_spec = __builtin_amdgcn_readfirstlane(sh_pkt[kRpSeqSpec]);
         const uint32_t want_sum = __builtin_amdgcn_readfirstlane(sh_pkt[kRpChecksum]);
@@ -657,6 +660,7 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
     const uint32_t* poll_at = lane < 16 ? const_cast<const uint32_t*>(ra.packet) + lane : ra.small_rows + (lane - 16);
     uint32_t expect = ra.first_packet;
     unsigned long long idle_since = (unsigned long long)wall_clock64();
+    const unsigned long long born = idle_since;
     for (;;) {
         uint32_t w, bits;
         for (;;) {
@@ -670,7 +674,8 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
                 for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
                 if (sum == (uint32_t)__builtin_amdgcn_readlane(w, kRpChecksum)) break;
             }
-            if ((unsigned long long)wall_clock64() - idle_since > ra.idle_ticks) { bits = kRbQuit; break; }
+            const unsigned long long now = (unsigned long long)wall_clock64();           // idle for too long, or old enough (a device-wide
+            if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) { bits = kRbQuit; break; }         // synchronize waits for this kernel)
             __builtin_amdgcn_s_sleep(1);
         }
         if (bits & kRbQuit) break;

@@ -112,6 +112,7 @@ struct ResidentArgs {
     unsigned long long* timing;   // pinned: six 100 MHz timestamps of the last command (seen, rows read, stepped, first flag, acted, done)
     uint32_t launch_id, first_packet;
     unsigned long long idle_ticks;       // 100 MHz ticks without a command after which the kernel leaves
+    unsigned long long life_ticks;       // ... and its age at which it leaves between two commands whatever the traffic (the host starts another)
 };
 // dwords of the command line (one 64-byte line of pinned host memory, written body first, then tail, then head)
 enum ResidentPacket { kRpHead = 0, kRpBits = 1, kRpStateInLo = 2, kRpStateInHi = 3, kRpStateOutLo = 4, kRpStateOutHi = 5,

@@ -169,7 +169,7 @@ class Raptor:
             stride = obs.shape[1]
         batch = obs.shape[0]
         act = np.empty((batch, POLICY_OUTPUT_DIM), np.float32)
-        _lib.call("rq_policy_evaluate_step", self._handle(), None, _lib.fptr(obs) if obs.flags.c_contiguous else obs.ctypes.data,
+        _lib.call("rq_policy_evaluate_step", self._handle(), None, _lib.fptr(obs),
                   batch, stride, _lib.fptr(act))
         return act
 
