@@ -634,15 +634,20 @@ def api_loop_probe(device, n=8, iters=500):
     out = {}
     import gc
     gc.collect()      # free the previous probes' device buffers now, not inside the timed loop
-    for name in ("numpy_arrays", "device_resident"):
+    # numpy_arrays: the loop as the README writes it; below 257 envs its step + speculated policy step are commands to the resident
+    # executor (round 6: one workgroup stays on the device, include/raptor_quad.h rq_device_set_resident) - `numpy_arrays_launches`
+    # is the same loop with the executor switched off (two launches per iteration, what rounds 3-5 measured)
+    for name in ("numpy_arrays", "numpy_arrays_launches", "device_resident"):
         policy.reset()
+        device.set_resident(name != "numpy_arrays_launches")
         t0 = None
-        warm = max(2, iters // 10)
+        warm = max(5, iters // 10)
+        before = None
         for it in range(iters + warm):
             if it == warm:
-                device.synchronize()
+                before = device.resident()
                 t0 = time.perf_counter()
-            if name == "numpy_arrays":
+            if name != "device_resident":
                 vector.observe(device, env, params, state, observation, rng)
                 action = policy.evaluate_step(observation[:, :22])
                 vector.step(device, env, params, state, action, next_state, rng)
@@ -651,8 +656,16 @@ def api_loop_probe(device, n=8, iters=500):
                 vector.observe(device, env, params, state, None, rng)
                 policy.evaluate_step_device(env)
                 vector.step_device(device, env, params, state, state, rng)
+        if name == "device_resident":
+            device.synchronize()
+        elapsed = time.perf_counter() - t0
+        out[name + "_us_per_iteration"] = round(elapsed / iters * 1e6, 2)
+        if name == "numpy_arrays":
+            after = device.resident()
+            out["resident_executor"] = {k: after[k] - before[k] for k in ("starts", "commands", "replays")}
+            out["resident_executor"]["iterations"] = iters
         device.synchronize()
-        out[name + "_us_per_iteration"] = round((time.perf_counter() - t0) / iters * 1e6, 2)
+    device.set_resident(True)
     out["env_steps_per_s_numpy_arrays"] = round(n / (out["numpy_arrays_us_per_iteration"] * 1e-6), 1)
     return out
 

@@ -32,8 +32,9 @@ ARCH = "gfx950"
 # -ffp-contract=off: only explicit fmaf() calls fuse (DESIGN.md "Arithmetic contract")
 DEVICE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"--offload-arch={ARCH}",
                 "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
-SOURCES = ["rq_kernels.hip", "rq_kernels_16bit.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_comm.cpp", "rq_pack.cpp"]
-HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_rollout.hpp", "rq_host.hpp"]
+SOURCES = ["rq_kernels.hip", "rq_kernels_16bit.hip", "rq_teacher.hip", "rq_capi.cpp", "rq_capi_vector.cpp", "rq_capi_policy.cpp",
+           "rq_capi_rollout.cpp", "rq_capi_teacher.cpp", "rq_comm.cpp", "rq_pack.cpp"]
+HEADERS = ["rq_kernels.hpp", "rq_device_math.hpp", "rq_rollout.hpp", "rq_host.hpp", "rq_objects.hpp"]
 # per-source flags (none today).  Round 4 built rq_kernels_16bit.hip with -mllvm -amdgpu-sched-strategy=max-ilp; the gain on the bf16 build
 # that ships was inside the box-to-box spread, and the two-waves-per-SIMD bf16 build gave run-to-run different results with it - the
 # gfx950 fault round 5 found (gfx950_errata.py), which _compile() now rewrites out of every listing whatever the scheduler.

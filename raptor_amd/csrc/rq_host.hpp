@@ -1,4 +1,4 @@
-// rq_host.hpp — what the host-side translation units of libraptor_quad.so share (rq_capi.cpp, rq_comm.cpp):
+// rq_host.hpp — what the host-side translation units of libraptor_quad.so share (rq_capi*.cpp, rq_comm.cpp):
 // error reporting, the status-returning check macros and the current-device scope.
 #pragma once
 #include <hip/hip_runtime_api.h>
@@ -50,7 +50,7 @@ rq_device* env_device(const rq_env* env);
 uint32_t env_num_envs(const rq_env* env);
 const float* env_finished_returns(const rq_env* env);      // device [ld]
 
-// The resident executor of the small-batch loop (rq_capi.cpp resident_*) works outside the device's stream; any entry point that may touch
+// The resident executor of the small-batch loop (rq_capi_vector.cpp resident_*) works outside the device's stream; any entry point that may touch
 // that stream first retires it (a few microseconds, and only when one is running): that is this hook, run by every DeviceScope made
 // from an rq_device.  The three calls of the loop itself construct their scope with KeepResident and retire explicitly on their slow paths.
 int resident_scope_hook(const rq_device* dev);

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // rows) - publishing the same two sequence numbers in the same pinned flag.  The policy's operand image is loaded once for the
 // kernel's lifetime.  The kernel leaves on a QUIT command, or by itself after `idle_ticks` without one (a host that died or went
 // away must not leave a wave spinning), and says so in `exited`; a command it never consumed is replayed by the host as launches
-// (rq_capi.cpp resident_*).  It is never the device stream's business: the host retires it before anything else is enqueued.
+// (rq_capi_vector.cpp resident_*).  It is never the device stream's business: the host retires it before anything else is enqueued.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loop(ResidentArgs ra) {
     typedef ActorF32Lean ACTOR;                 // the build launch_actor_step takes for fp32 policies: the same bits

@@ -94,7 +94,7 @@ struct Mailbox {
     uint32_t seq;
 };
 
-// ---- resident executor of the small-batch loop (rq_kernels.hip k_resident_loop; host side: rq_capi.cpp resident_*) ----
+// ---- resident executor of the small-batch loop (rq_kernels.hip k_resident_loop; host side: rq_capi_vector.cpp resident_*) ----
 struct ResidentArgs {
     Batch b; StepCfg c; SampleCfg sc; uint64_t seed;
     const float* params; float* act; StatsPtrs st;

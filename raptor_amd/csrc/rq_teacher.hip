@@ -7,7 +7,7 @@
 // activation for the hidden layers and one for the output - with H1, H2 in {16, 32, 64}.
 //
 // Mapping.  Every env has its own teacher, so the contraction is not one GEMM: envs are grouped by teacher on
-// the host into TILES of 16 envs of ONE teacher (rq_capi.cpp), and one wave owns one tile for all T recorded
+// the host into TILES of 16 envs of ONE teacher (rq_capi_teacher.cpp), and one wave owns one tile for all T recorded
 // steps.  That makes every layer a true dense contraction W[out x in] X[in x 16] on the matrix cores with the
 // teacher's operands register-stationary (loaded once per wave, 124 VGPRs for 22-64-64-4, amortised over T
 // steps):

@@ -118,7 +118,7 @@ if args.direction in ("both", "torch_aggressor"):
                   "torch.matmul f16 1024^3": many(lambda: torch.matmul(ha, hb), 50),
                   # no MFMA at all: a thread that allocates, frees and synchronises the device the whole time - what invalidates another
                   # thread's open hipGraph capture (the chained rollout captures one per new env): the rollout must fall back to plain
-                  # launches, not fail (rq_capi.cpp rollout_impl)
+                  # launches, not fail (rq_capi_rollout.cpp rollout_impl)
                   "hipMalloc / hipFree / hipDeviceSynchronize churn": many(churn, 5)}
     for what, fn in aggressors.items():
         bg = Background(fn, what)
