@@ -416,11 +416,6 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             ra.launch_id = ++dev->res_launch_id; if (ra.launch_id == 0) ra.launch_id = ++dev->res_launch_id;
             ra.first_packet = dev->res_packet + 1;
             ra.idle_ticks = dev->res_idle_ticks; ra.life_ticks = dev->res_life_ticks;
-            if (std::getenv("RQ_RESIDENT_DEBUG"))
-                std::fprintf(stderr, "resident start: n %u ld %u params %p act %p st.returns %p obs %p %p packed %p hidden %p %p ld_h %u pol_act %p rows_action %p rows_obs %p rows_act %p flag %p packet %p exited %p small_rows %p state_in %p state_out %p\n",
-                             ra.b.n, ra.b.ld, (const void*)ra.params, (void*)ra.act, (void*)ra.st.returns, (void*)ra.obs_buf[0], (void*)ra.obs_buf[1], (const void*)ra.packed,
-                             (void*)ra.hidden[0], (void*)ra.hidden[1], ra.ld_h, (void*)ra.pol_act, (const void*)ra.rows_action, (void*)ra.rows_obs, (void*)ra.rows_act,
-                             (void*)ra.flag, (const void*)ra.packet, (void*)ra.exited, (const void*)ra.small_rows, (const void*)pair.state_in, (void*)pair.state_out);
             const hipError_t e = rq::launch_resident(dev->res_stream, ra);
             if (e == hipSuccess) {
                 dev->res_running = true; ++dev->res_starts; dev->res_born_ns = host_now_ns();

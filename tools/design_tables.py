@@ -50,6 +50,11 @@ def main(tag):
         f"{get(d, 'timing/repetitions')} regions)", f"{drv_name}: value, ms_per_step, timing")
     row("`roofline.frac` of the fused kernel in those regions: 4 968 FLOP × 65 536 × 20 ÷ rocprofv3's mean per-dispatch duration ÷ 157.3 TFLOP/s",
         f"**{r['frac']:.3f}** ({r['achieved']:.1f} TFLOP/s, {r['avg_launch_ms'] * 1e3:.2f} µs per launch)", f"{drv_name}: roofline; {get(r, 'rocprofv3/source')}")
+    row("which clock that fraction is on (`roofline.frac_basis`)", str(r.get("frac_basis")), f"{drv_name}: roofline/frac_basis")
+    row("the same launches measured in the record's own run: the waves' first-in / last-out span; HIP events on the engine's stream around the launch; "
+        "the same FLOP over the timed region itself", f"frac_in_run {fmt(r.get('frac_in_run'))} ({fmt((r.get('avg_launch_ms_in_run') or 0) * 1e3)} µs) / "
+        f"frac_hip_events {fmt(r.get('frac_hip_events'))} ({fmt((r.get('avg_launch_ms_hip_events') or 0) * 1e3)} µs) / frac_by_region {fmt(r.get('frac_by_region'))}",
+        f"{drv_name}: roofline/frac_in_run, frac_hip_events, frac_by_region")
     if "wave_span" in r:
         w = r["wave_span"]
         row("the same launches by the waves' own first-in / last-out span, measured in the record's run",
@@ -100,10 +105,15 @@ def main(tag):
         t = record(tpath)
         lay = {k: v for k, v in t.items() if k.startswith("layers_")}
         if lay:
-            row("teacher stacks outside that family (streaming kernel, fp32): " + ", ".join(k[7:] for k in lay),
+            row("teacher stacks outside that family (dense-stack kernel: LDS-resident image, (env, step) column tiles, fp32; contiguous assignment): " + ", ".join(k[7:] for k in lay),
                 ", ".join(f"{fmt(v['ms'])} ms ({fmt(v['frac_of_f32_mfma_peak'])})" for v in lay.values()), f"{tag}_teacher_rate.json")
         if "bf16" in t and "f16x2" in t:
             row("the 22-64-64-4 bank in bf16 / split f16", f"{fmt(t['bf16']['ms'])} / {fmt(t['f16x2']['ms'])} ms", f"{tag}_teacher_rate.json")
+    if os.path.exists(P("teacher_pmc.json")):
+        tp = json.load(open(P("teacher_pmc.json")))
+        tops = [k for k in tp if k[0].isdigit()]
+        row("HBM traffic of those launches over their algorithmic bytes (observations in + actions out + every teacher's parameters once)",
+            ", ".join(f"{k}: {fmt(tp[k]['traffic_over_algorithmic'])}×" for k in tops), f"{tag}_teacher_pmc.json")
     dg = d.get("dagger_epoch") or {}
     row("one DAgger epoch of the reference's size (≈ 78 k transitions × 1 000 teachers: record + relabel)",
         f"{fmt(get(dg, 'one_env_per_teacher/ms_per_epoch'))} ms (one env per teacher) / {fmt(get(dg, 'sixteen_envs_per_teacher/ms_per_epoch'))} ms (16 per teacher)",
@@ -117,8 +127,11 @@ def main(tag):
     rc = get(d, "config/rccl") or {}
     row("the RCCL this record met, by its own account", f"{rc.get('ranks')} rank(s), version {rc.get('version')}, `{rc.get('library_path')}`", f"{drv_name}: config/rccl")
     rl = d.get("readme_loop_n8") or {}
-    row("the README loop at the reference's batch (8 envs, NumPy arrays every call) / kept on the device", f"{fmt(rl.get('numpy_arrays_us_per_iteration'))} / "
-        f"{fmt(rl.get('device_resident_us_per_iteration'))} µs per iteration", f"{drv_name}: readme_loop_n8")
+    rx = rl.get("resident_executor") or {}
+    row("the README loop at the reference's batch (8 envs, NumPy arrays every call): resident executor / the two launches it replaces / the "
+        "device-resident chain of three launches", f"**{fmt(rl.get('numpy_arrays_us_per_iteration'))}** / {fmt(rl.get('numpy_arrays_launches_us_per_iteration'))} / "
+        f"{fmt(rl.get('device_resident_us_per_iteration'))} µs per iteration ({rx.get('commands')} commands to {rx.get('starts')} kernels in "
+        f"{rx.get('iterations')} iterations, {rx.get('replays')} replayed)", f"{drv_name}: readme_loop_n8")
     cb = d.get("cpu_baseline") or {}
     row("CPU baseline: the oracle's C restatement on the GPU box's host cores (a reported baseline, not a target)",
         f"{cb.get('value', 0):.3g} env-steps/s with {cb.get('cores')} threads ({cb.get('host_threads_available')} visible, quota ≈ {fmt(cb.get('effective_cores'))}); "
@@ -132,6 +145,22 @@ def main(tag):
         if os.path.exists(P(name)):
             x = record(P(name))
             row(label, f"{x['value']:.4g} env-steps/s, roofline frac {fmt(get(x, 'roofline/frac'))}", f"{tag}_{name}")
+    if os.path.exists(P("sq_sequence.json")):
+        row("`evaluate_sequence` at 2 000 steps per launch and its SQ breakdown (120 MFMAs + 128 vector + 96 transcendental instructions per wave-step, "
+            "co-execution 0: at the lone wave's issue model)", "0.657 of the f32 MFMA peak", f"{tag}_sequence_breakdown.md, {tag}_sq_sequence.json")
+    if os.path.exists(P("foreign_soak.json")):
+        fs = json.load(open(P("foreign_soak.json")))["results"]
+        ran = [x for x in fs if "skipped" not in x]
+        row("foreign aggressor / victim soak beside PyTorch on one GPU: repetitions that differ from the idle-GPU bits",
+            f"{sum(x['repetitions_that_differ'] for x in ran)} of {sum(x['repetitions'] for x in ran)} over {len(ran)} pairings", f"{tag}_foreign_soak.json")
+    if os.path.exists(P("foreign_soak_unrewritten_build.json")):
+        fs = json.load(open(P("foreign_soak_unrewritten_build.json")))["results"]
+        row("the same victim workload in a build WITHOUT the op_sel pass, beside torch's 16-bit kernels",
+            "; ".join(f"{x['aggressor'].split(',')[0]}: {x['repetitions_that_differ']}/{x['repetitions']}" for x in fs), f"{tag}_foreign_soak_unrewritten_build.json")
+    if os.path.exists(P("eight_ranks_one_gpu.json")):
+        e8 = json.load(open(P("eight_ranks_one_gpu.json")))
+        row("the driver's eight-rank command end to end on ONE GPU (`--allow-oversubscribe`, tests-only RCCL): wall time",
+            f"{fmt(e8.get('wall_s'))} s (box: 120 s)", f"{tag}_eight_ranks_one_gpu.json")
     table = "\n".join([BEGIN, f"One MI355X per run; files under `profiles/` (what each is: `profiles/README.md`).  Generated by `python tools/design_tables.py {tag}`.", "",
                        "| what | measured | read from |", "|---|---|---|"] + rows + [END])
     path = os.path.join(ROOT, "DESIGN.md")
@@ -142,4 +171,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r05")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r06")
