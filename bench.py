@@ -785,6 +785,14 @@ def parity_block(device):
         j = json.load(open(joint[0]))
         out["reference_log"]["joint_scan"] = {"source": os.path.basename(joint[0]), "verdict": j["verdict"],
                                               "settings_reproducing_both_tags": len(j["joint_matches"])}
+    # round 6: the one non-fitting experiment that closed the topic (tools/policy_competence.py, oracle): the shipped policy's competence
+    # boundary brackets this specification's randomisation ranges; the log is not reproduced with them either
+    comp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_policy_competence.json")), reverse=True)
+    if comp and "reference_log" in out:
+        c = json.load(open(comp[0]))
+        out["reference_log"]["policy_competence"] = {
+            "source": os.path.basename(comp[0]), "verdict": c["verdict"],
+            "competence_ranges": {k: (v or {}).get("range") for k, v in c["competence_ranges"].items()}}
     out["summary"] = "actor pinned; env unpinned (under-determined by the reference tree): parity is partial"
     return out
 
