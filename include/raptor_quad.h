@@ -511,13 +511,16 @@ RQ_API int rq_device_launch_floor(rq_device* dev, uint32_t n, uint32_t reps, flo
  * switches it off for this device (RQ_NO_SPECULATION in the environment: off at rq_device_create), 1 on again.
  * rq_device_get_speculation: any out pointer may be NULL. */
 RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
-/* The resident executor of that loop (round 6, ABI 5): once rq_step has been called three times in a row in the loop's own shape (host
- * actions, an env of at most 512 envs, the observation cached, an fp32 policy to speculate with, next_state != state) and nothing else
- * was asked of the device in between, the step and the speculated policy step are no longer LAUNCHED: one workgroup stays on the device,
- * on a stream of its own, polls a 64-byte command line in pinned host memory and does for every command what the two launches did
- * (same device functions, same bits, same sequence numbers in the same flag).  Any other call on the device retires it first (a few
- * microseconds); it leaves by itself after 4 ms without a command, and a command it never took is replayed as launches.  Results
- * never depend on it.  enable = 0 switches it off for this device (RQ_NO_RESIDENT in the environment: off at rq_device_create).
+/* The resident executor of that loop (round 6, ABI 5): once rq_step has been called three times in a row, each within 200 us of the one
+ * before, in the loop's own shape (host actions, an env of at most 256 envs, the observation cached, an fp32 policy to speculate with,
+ * next_state != state) and nothing else was asked of the device in between, the step and the speculated policy step are no longer
+ * LAUNCHED: one workgroup stays on the device, on a stream of its own, polls a 64-byte command line (pinned host memory, or device memory
+ * behind a large BAR) and does for every command what the two launches did (same device functions, same bits, same sequence numbers in
+ * the same flag).  Any other call on the device retires it first (a few microseconds); it leaves by itself after 300 us without a
+ * command and, between two commands, once it is 1 ms old (a device-wide synchronize waits for a running kernel); a command it never
+ * took is replayed as launches; kernels that idle out having served fewer than 8 commands are started 8, 16, ... 1 024 steps apart.
+ * A loop paced like README.md:94-101 (10 ms of sleep per step) keeps its launches.  Results never depend on any of this.  enable = 0
+ * switches it off for this device (RQ_NO_RESIDENT in the environment: off at rq_device_create); either value clears the back-off.
  * rq_device_get_resident: any out pointer may be NULL; `running` = a kernel is on the device now; starts / commands / replays count
  * kernels started, commands posted, and commands replayed as launches since the device was created. */
 RQ_API int rq_device_set_resident(rq_device* dev, int enable);

@@ -133,6 +133,15 @@ int resident_gone(rq_device* dev) {
     if (!dev->res_running) return RQ_OK;
     dev->res_running = false;
     RQ_HIP(hipStreamSynchronize(dev->res_stream));
+    // was it worth its launch?  A kernel that idled out after a handful of commands was not (see kResidentMinCommands): back off.
+    const uint64_t served = dev->res_posts - dev->res_posts_at_start;
+    const uint32_t why = __atomic_load_n(&dev->res_mem[17], __ATOMIC_ACQUIRE);
+    if (served >= kResidentGoodCommands) {
+        dev->res_backoff = 0;
+    } else if ((why & rq::kRbLeftIdle) && served < kResidentMinCommands) {
+        dev->res_backoff = dev->res_backoff ? std::min(2 * dev->res_backoff, kResidentMaxBackoff) : kResidentMinCommands;
+        dev->res_backoff_left = dev->res_backoff;
+    }
     if (dev->res_pending) {
         dev->res_pending = false;
         const uint32_t f = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
@@ -242,6 +251,7 @@ RQ_API int rq_device_set_resident(rq_device* dev, int enable) {
     RQ_REQUIRE(dev, RQ_ERR_INVALID_ARGUMENT, "null argument");
     DeviceScope on_device(dev); int rc = on_device.rc; if (rc) return rc;      // retires a running one
     dev->res_enabled = enable != 0;
+    dev->res_backoff = dev->res_backoff_left = 0;
     return RQ_OK;
 }
 
@@ -348,16 +358,18 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     // fp32 policy step behind it, out of place, on buffers the library alone writes - and the same objects as the kernel in flight.
     const bool eligible = dev->res_enabled && pol && env->obs_alt && env->n <= kResidentMaxEnvs && next_state != state && !state->exposed &&
                           pol->precision == RQ_POLICY_FP32 && pol->sas_mode == RQ_SAS_OFF;
-    dev->res_streak = eligible ? dev->res_streak + 1 : 0;
-    const uint64_t now_ns = dev->res_running ? host_now_ns() : 0;
+    const uint64_t now_ns = eligible ? host_now_ns() : 0;
+    dev->res_streak = !eligible ? 0 : now_ns - dev->res_last_step_ns < kResidentMaxGapNs ? dev->res_streak + 1 : 1;
+    if (eligible) dev->res_last_step_ns = now_ns;
     const bool bound = dev->res_running && dev->res_env == env && dev->res_env_uid == env->uid && dev->res_params == params &&
                        dev->res_params_version == params->version && dev->res_policy == pol && dev->res_seed == rng->seed &&
                        dev->res_packed == packed_of(pol) && std::memcmp(&dev->res_cfg, &env->cfg, sizeof(rq_env_config)) == 0 &&
                        (env->obs_alt == dev->res_obs[0] || env->obs_alt == dev->res_obs[1]) &&
                        (pol->hidden == dev->res_hidden[0] || pol->hidden == dev->res_hidden[1]) &&
                        now_ns - dev->res_last_post_ns < dev->res_host_idle_ns && now_ns - dev->res_born_ns < dev->res_host_life_ns;
-    const bool resident = eligible && (bound || dev->res_streak >= kResidentStreak);
     if (dev->res_running && !(eligible && bound)) { rc = resident_retire(dev); if (rc) return rc; }
+    bool resident = eligible && (bound || dev->res_streak >= kResidentStreak);
+    if (resident && !dev->res_running && dev->res_backoff_left) { --dev->res_backoff_left; resident = false; }     // see kResidentMinCommands
     // next_state is written in full: if it shares its buffer (state.assign(next_state) of the previous iteration) it
     // gets another one; stepping a state in place (next_state == state) keeps the contents it is about to read
     rc = state_make_private(next_state, next_state == state); if (rc) return rc;
@@ -418,7 +430,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             ra.idle_ticks = dev->res_idle_ticks; ra.life_ticks = dev->res_life_ticks;
             const hipError_t e = rq::launch_resident(dev->res_stream, ra);
             if (e == hipSuccess) {
-                dev->res_running = true; ++dev->res_starts; dev->res_born_ns = host_now_ns();
+                dev->res_running = true; ++dev->res_starts; dev->res_born_ns = host_now_ns(); dev->res_posts_at_start = dev->res_posts;
                 dev->res_env = env; dev->res_env_uid = env->uid; dev->res_params = params; dev->res_params_version = params->version;
                 dev->res_policy = pol; dev->res_cfg = env->cfg; dev->res_seed = rng->seed; dev->res_packed = pair.packed;
                 dev->res_obs[0] = env->obs; dev->res_obs[1] = env->obs_alt; dev->res_hidden[0] = pol->hidden; dev->res_hidden[1] = pol->hidden_alt;

@@ -545,7 +545,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
                 const uint32_t head = __builtin_amdgcn_readlane(w, kRpHead), tail = __builtin_amdgcn_readlane(w, kRpTail);
                 if (head == expect && tail == expect) break;
                 const unsigned long long now = (unsigned long long)wall_clock64();       // idle for too long, or old enough (a device-wide
-                if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) { w = lane == kRpBits ? kRbQuit : w; break; }     // synchronize waits for this kernel)
+                if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) {                                                 // synchronize waits for this kernel)
+                    w = lane == kRpBits ? (kRbQuit | (now - born > ra.life_ticks ? kRbLeftOld : kRbLeftIdle)) : w;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
             if (lane < 16) sh_pkt[lane] = w;
@@ -627,7 +630,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
     }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        ra.exited[1] = __builtin_amdgcn_readfirstlane(sh_pkt[kRpBits]) & (kRbLeftIdle | kRbLeftOld);      // why: 0 = told to
+        __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // The same executor for the reference's own batch (`vector8`: at most 12 envs, one wave), with everything that is latency taken out of
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
     float hq[4] = {0.f, 0.f, 0.f, 0.f};
     const float* have_hidden = nullptr;
     const uint32_t hj = j < n ? j : n - 1;     // tile 0 of the Q layout: lane (q, j) = env j, hidden features 4 q .. 4 q + 3
+    uint32_t bits_at_exit = 0;
     const uint32_t* poll_at = lane < 16 ? const_cast<const uint32_t*>(ra.packet) + lane : ra.small_rows + (lane - 16);
     uint32_t expect = ra.first_packet;
     unsigned long long idle_since = (unsigned long long)wall_clock64();
@@ -675,10 +682,13 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
                 if (sum == (uint32_t)__builtin_amdgcn_readlane(w, kRpChecksum)) break;
             }
             const unsigned long long now = (unsigned long long)wall_clock64();           // idle for too long, or old enough (a device-wide
-            if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) { bits = kRbQuit; break; }         // synchronize waits for this kernel)
+            if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) {                                  // synchronize waits for this kernel)
+                bits = kRbQuit | (now - born > ra.life_ticks ? kRbLeftOld : kRbLeftIdle);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (bits & kRbQuit) break;
+        if (bits & kRbQuit) { bits_at_exit = bits; break; }
         const bool timed = ra.timing != nullptr;       // a diagnostic (RQ_RESIDENT_TIMING): reading the clock five times costs a command ~0.5 us
         const unsigned long long t_seen = timed ? (unsigned long long)wall_clock64() : 0ull;
         const float* state_in = reinterpret_cast<const float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(w, kRpStateInHi) << 32) |
@@ -768,7 +778,10 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
         }
     }
     __threadfence_system();
-    if (lane == 0) __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) {
+        ra.exited[1] = bits_at_exit & (kRbLeftIdle | kRbLeftOld);      // why: 0 = told to
+        __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra) {

@@ -108,7 +108,7 @@ struct ResidentArgs {
     float* rows_act;              // pinned: [n][4] the policy's actions on that observation
     uint32_t* flag;               // pinned: the device's mailbox flag (sequence numbers of finished work)
     volatile uint32_t* packet;    // pinned: 16 dwords, see ResidentPacket
-    uint32_t* exited;             // pinned: receives launch_id when the kernel has left
+    uint32_t* exited;             // pinned: [0] receives launch_id when the kernel has left, [1] why (0 told to, kRbLeftIdle, kRbLeftOld)
     unsigned long long* timing;   // pinned: six 100 MHz timestamps of the last command (seen, rows read, stepped, first flag, acted, done)
     uint32_t launch_id, first_packet;
     unsigned long long idle_ticks;       // 100 MHz ticks without a command after which the kernel leaves
@@ -118,7 +118,8 @@ struct ResidentArgs {
 enum ResidentPacket { kRpHead = 0, kRpBits = 1, kRpStateInLo = 2, kRpStateInHi = 3, kRpStateOutLo = 4, kRpStateOutHi = 5,
                       kRpSeqStep = 6, kRpSeqSpec = 7, kRpChecksum = 8, kRpTail = 15 };
 constexpr uint32_t kResidentSmallEnvs = 12;      // 4 n action dwords fit the 48 lanes the command line leaves of one poll
-enum ResidentBits : uint32_t { kRbObsSel = 1u, kRbHiddenSel = 2u, kRbQuit = 4u };
+enum ResidentBits : uint32_t { kRbObsSel = 1u, kRbHiddenSel = 2u, kRbQuit = 4u,
+                               kRbLeftIdle = 8u, kRbLeftOld = 16u };      // set by the kernel itself: why it left (exited[1])
 
 // one workgroup of ceil(n / 64) <= 4 waves on stream s; returns at once, the kernel stays until told to quit or idle for idle_ticks
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra);

@@ -46,13 +46,20 @@ inline uint64_t fresh_version() {
 
 constexpr uint32_t kResidentMaxEnvs = 256;            // one workgroup, a wave per SIMD of one CU (at 512 envs the launches, spread over the chip, are faster)
 constexpr uint32_t kResidentStreak = 3;               // eligible steps in a row before a kernel is started
-constexpr uint64_t kResidentIdleTicks = 400000;       // the kernel leaves after 4 ms without a command (100 MHz ticks) ...
-constexpr uint64_t kResidentHostIdleNs = 1000000;     // ... and the host stops posting to one it has not fed for 1 ms
-// A kernel that never ends would make hipDeviceSynchronize - a learner's torch.cuda.synchronize() on another thread - wait for as long
-// as the loop runs: the kernel leaves between two commands once it is 2 ms old, and the host, which knows its age, retires it at
-// 1.5 ms and starts the next one (one launch per ~190 iterations at 8 envs).
-constexpr uint64_t kResidentLifeTicks = 200000;
-constexpr uint64_t kResidentHostLifeNs = 1500000;
+// The loop must really be running: an eligible step counts towards the streak only when it follows the previous one within 200 us (the
+// README loop as the reference writes it sleeps 10 ms per step: it keeps its launches, nothing spins for it).
+constexpr uint64_t kResidentMaxGapNs = 200000;
+constexpr uint64_t kResidentIdleTicks = 30000;        // the kernel leaves after 300 us without a command (100 MHz ticks) ...
+constexpr uint64_t kResidentHostIdleNs = 150000;      // ... and the host stops posting to one it has not fed for 150 us
+// A kernel that never ends would make hipDeviceSynchronize - a learner's torch.cuda.synchronize() on another thread, any hipFree - wait
+// for as long as the loop runs: the kernel leaves between two commands once it is 1 ms old, and the host, which knows its age, retires it
+// at 0.75 ms and starts the next one (one launch per ~100 iterations at 8 envs).
+constexpr uint64_t kResidentLifeTicks = 100000;
+constexpr uint64_t kResidentHostLifeNs = 750000;
+// A kernel that left by itself (idle) after fewer than 8 commands was not worth its launch - something stalls the loop that the host
+// cannot see (a device-wide synchronize of the caller's own, a slow consumer): the next kernel is started only after 8, 16, ... 1 024
+// further eligible steps; a kernel that served 64 commands resets that.
+constexpr uint32_t kResidentMinCommands = 8, kResidentGoodCommands = 64, kResidentMaxBackoff = 1024;
 constexpr size_t kResCmdBytes = 8192;                 // command memory: [0..15] the command line, [64 .. 64 + 4 x 256) the action rows
 
 
@@ -133,6 +140,9 @@ struct rq_device {
     uint32_t res_streak = 0;             // eligible rq_step calls in a row with nothing else asked of the device in between
     uint64_t res_last_post_ns = 0;       // host clock of the last command: a kernel idle for too long may be leaving, it is not posted to
     uint64_t res_born_ns = 0;            // host clock at the kernel's launch
+    uint64_t res_last_step_ns = 0;       // host clock of the last eligible rq_step (the streak counts steps that follow one another closely)
+    uint64_t res_posts_at_start = 0;     // res_posts when the running kernel was started: what it has served = res_posts - this
+    uint32_t res_backoff = 0, res_backoff_left = 0;    // eligible steps still to let pass before another kernel is started
     uint64_t res_idle_ticks = kResidentIdleTicks, res_life_ticks = kResidentLifeTicks;       // RQ_RESIDENT_IDLE_TICKS / _LIFE_TICKS (tests)
     uint64_t res_host_idle_ns = kResidentHostIdleNs, res_host_life_ns = kResidentHostLifeNs; // RQ_RESIDENT_HOST_IDLE_NS / _HOST_LIFE_NS (tests)
     uint64_t res_starts = 0, res_posts = 0, res_replays = 0;     // diagnostics
