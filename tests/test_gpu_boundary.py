@@ -56,14 +56,17 @@ def test_host_transfers_small_and_large_batch_paths(device, oracle, weights, n):
         assert np.array_equal(w.state.numpy(), w.S)
 
 
-@pytest.mark.parametrize("n", [8, 1000, 1100])
+@pytest.mark.parametrize("n", [8, 13, 200, 1000, 1100])
 def test_random_api_sequences_against_a_shadow_model(device, oracle, weights, n):
     """Model-based fuzz of the API-granular calls: 250 random operations mixing host arrays and the
     device-resident buffers (both sides of the 1 024-env switch between the pinned mailbox and the GPU layout
     kernels), back-to-back asynchronous steps, in-place steps and getters in between.  A shadow model driven
     by the oracle holds what every buffer must contain; env data is compared bit for bit, actions to ACTOR_TOL."""
+    met = 0
     for round_ in range(int(os.environ.get("RQ_FUZZ_ROUNDS", "3"))):       # more rounds: a soak of the host logic
-        _one_random_api_sequence(device, oracle, weights, n, n + 7919 * round_)
+        met += _one_random_api_sequence(device, oracle, weights, n, n + 7919 * round_)
+    if n <= 256 and device.resident()["enabled"]:
+        assert met > 0                                # the fuzz did meet the resident executor (commands taken inside its bursts)
 
 
 def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
@@ -81,11 +84,12 @@ def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
     w.policy.reset()
     obs_host = np.zeros((n, 26), np.float32)
     held = None                                       # (a copy of the state taken earlier, what it held then)
+    bursts_resident = 0                               # commands the resident executor took inside "readme_burst" ops
     for it in range(250):
         op = rng.choice(["observe_host", "observe_dev", "eval_host_host", "eval_dev_dev", "step_host", "step_dev",
                          "step_inplace", "assign", "get_obs", "get_act", "set_act", "get_state", "stats",
                          "readme_iteration", "readme_iteration", "eval_observed", "state_set", "state_copy",
-                         "assign_back", "policy_reset", "view_write", "speculation_toggle"])
+                         "assign_back", "policy_reset", "view_write", "speculation_toggle", "readme_burst", "readme_burst"])
         if op == "speculation_toggle":                 # round 4: rq_device_set_speculation, in every state of the mechanism
             device.set_speculation(bool(rng.integers(0, 2)))
             assert device.speculation()["consecutive_misses"] == 0
@@ -160,6 +164,29 @@ def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
                 w.state.assign(w.next_state)
                 S = NS.copy()
                 act_dev = a
+        elif op == "readme_burst":
+            # the same loop at the pace of a real one (nothing of the checker in between: steps closer than 200 us are what
+            # starts the resident executor, round 6), checked afterwards; whatever op comes next meets a resident kernel
+            k = int(rng.integers(3, 14))
+            Os, As = [], []
+            posts = device.resident()["commands"]
+            for _ in range(k):
+                w.vector.observe(device, w.env, w.params, w.state, obs_host, w.rng)
+                a = w.policy.evaluate_step(obs_host[:, :22])
+                w.vector.step(device, w.env, w.params, w.state, a, w.next_state, w.rng)
+                w.state.assign(w.next_state)
+                Os.append(obs_host.copy()); As.append(a.copy())
+            bursts_resident += device.resident()["commands"] - posts
+            for o, a in zip(Os, As):
+                obs_dev = oracle.observe(w.cfg, w.seed, epoch, w.offset, w.P, S); epoch += 1
+                assert np.array_equal(o, obs_dev), (it, op)
+                ref = oracle.actor_batch_step(weights, np.ascontiguousarray(o[:, :22]), H)
+                assert np.max(np.abs(a - ref)) < 10 * ACTOR_TOL, (it, op)
+                NS, r, term = oracle.step(w.cfg, w.P, S, a)
+                oracle.stats_update(w.cfg, r, term, w.st)
+                S = NS.copy()
+                act_dev = a
+            assert np.array_equal(w.env.rewards(), r) and np.array_equal(w.env.terminated(), term), (it, op)
         elif op == "eval_observed":
             a = w.policy.evaluate_step(obs_host[:, :22])
             ref = oracle.actor_batch_step(weights, np.ascontiguousarray(obs_host[:, :22]), H)
@@ -187,6 +214,7 @@ def _one_random_api_sequence(device, oracle, weights, n, fuzz_seed):
     if held is not None:
         assert np.array_equal(held[0].numpy(), held[1])
     device.set_speculation(True)
+    return bursts_resident
 
 
 # ------------------------------------------------------------------------------ loops ------
