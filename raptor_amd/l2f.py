@@ -633,3 +633,11 @@ def vector(n_environments, global_env_offset=0):
 
 
 vector8 = vector(8)   # README.md:45
+
+
+def __getattr__(name):
+    """``from l2f import vectorN`` for any N (the reference ships a fixed set of pre-compiled ``vectorN`` modules, README.md:45
+    imports ``vector8``; here N is a run-time value, so every positive N resolves)."""
+    if name.startswith("vector") and name[6:].isdigit() and int(name[6:]) > 0 and not name[6:].startswith("0"):
+        return vector(int(name[6:]))
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

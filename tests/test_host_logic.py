@@ -401,3 +401,15 @@ def test_a_committed_trace_counts_only_for_the_build_it_was_taken_from(tmp_path)
     assert bench.traffic_of(None) is None and bench.traffic_of({"same_library": False, "bytes_per_launch": 1.0}) is None
     assert bench.traffic_of({"same_library": True, "bytes_per_launch": 3.0}) == 3.0
     assert bench.traffic_of({"same_library": None, "bytes_per_launch": 2.0}) == 2.0
+
+
+def test_every_vectorN_module_name_resolves():
+    """README.md:45 `from l2f import vector8 as vector`: the reference pre-compiles a set of vectorN modules; here the batch is a
+    run-time value and any `vectorN` is `l2f.vector(N)` (no GPU is touched by naming one)."""
+    import raptor_amd.l2f as l2f
+    from raptor_amd.l2f import vector8, vector1, vector64, vector65536      # noqa: F401
+    assert vector8 is l2f.vector(8) and vector65536 is l2f.vector(65536) and vector1.N_ENVIRONMENTS == 1
+    assert l2f.vector256.N_ENVIRONMENTS == 256
+    for bad in ("vector0", "vector08", "vectorx", "vector-1", "vectors"):
+        with pytest.raises(AttributeError):
+            getattr(l2f, bad)
