@@ -535,6 +535,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
     const bool valid = i0 < n;
     const uint32_t i = valid ? i0 : n - 1;
     uint32_t expect = ra.first_packet;
+    uint32_t left_bits = 0;                     // why the kernel left (workgroup-uniform)
     unsigned long long idle_since = (unsigned long long)wall_clock64();
     const unsigned long long born = idle_since;
     for (;;) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
         }
         __syncthreads();
         const uint32_t bits = __builtin_amdgcn_readfirstlane(sh_pkt[kRpBits]);
-        if (bits & kRbQuit) break;                                       // workgroup-uniform
+        if (bits & kRbQuit) { left_bits = bits; break; }                 // workgroup-uniform
         const unsigned long long t_seen = (unsigned long long)wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    // what the host wrote before the packet (the action rows)
         // (the builtin returns int: without the casts a low half with its top bit set sign-extends over the high half)
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
         // the action rows travel beside the packet, not inside it: their sum must be the packet's (a line of rows read before the
         // host wrote it would otherwise go unnoticed); re-read until it is - the host wrote them before the packet
         float a_in[4];
+        bool rows_bad = false;
         for (uint32_t tries = 0;; ++tries) {
             uint32_t sum = 0;
 #pragma unroll
@@ -591,8 +593,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
                 for (int v = 0; v < WAVES; ++v) sum += sh_sum[v];
                 __syncthreads();
             }
-            if (sum == want_sum || tries > 100000u) break;
+            if (sum == want_sum) break;
+            // rows that never add up (the host writes them before the line: this does not happen) are not stepped with: the kernel
+            // leaves, the command counts as never taken and the host replays it as launches (workgroup-uniform: sum and tries are)
+            if (tries > 4096u) { rows_bad = true; break; }
         }
+        if (rows_bad) { left_bits = kRbLeftIdle; break; }
         const unsigned long long t_rows = (unsigned long long)wall_clock64();
         float x[22];
 #pragma unroll
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        ra.exited[1] = __builtin_amdgcn_readfirstlane(sh_pkt[kRpBits]) & (kRbLeftIdle | kRbLeftOld);      // why: 0 = told to
+        ra.exited[1] = left_bits & (kRbLeftIdle | kRbLeftOld);      // why: 0 = told to
         __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
