@@ -308,9 +308,23 @@ def _fptr_portable(a):
 
 
 try:                                  # the optional CPython helper (csrc/rq_pyfast.c, built by raptor_amd.build): 0.06 us, any array
-    from ._rq_fast import address as _fast_address
+    from . import _rq_fast as fast
+    _fast_address = fast.address
+    if not hasattr(fast, "observe") or os.environ.get("RQ_NO_PYFAST"):      # an older build of the helper: addresses only
+        fast = None
 except ImportError:                   # not built (no gcc / Python.h): the portable ways below
+    fast = None
     _fast_address = None
+
+_fn_addrs = {}
+
+
+def fn_addr(name):
+    """Address of a C entry point of the loaded library, for the helper's direct calls (`fast.observe` ...): an int."""
+    a = _fn_addrs.get(name)
+    if a is None:
+        a = _fn_addrs[name] = C.cast(getattr(load(), name), C.c_void_p).value
+    return a
 
 
 def fptr(a):

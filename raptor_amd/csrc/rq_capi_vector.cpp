@@ -132,7 +132,11 @@ hipError_t launch_step_pair(rq_device* dev, const StepPair& p) {
 int resident_gone(rq_device* dev) {
     if (!dev->res_running) return RQ_OK;
     dev->res_running = false;
-    RQ_HIP(hipStreamSynchronize(dev->res_stream));
+    // A kernel that has published `exited` has nothing left to do but end (its stores were fenced before that word): whatever follows
+    // may go ahead - the next resident kernel queues behind it on res_stream by itself - and a restart does not pay for a stream
+    // synchronize (~10 us of completion signalling, once per ~100 iterations of the loop).  Otherwise (the stream was found drained,
+    // or failed) the synchronize returns at once or reports the error.
+    if (__atomic_load_n(&dev->res_mem[16], __ATOMIC_ACQUIRE) != dev->res_launch_id) RQ_HIP(hipStreamSynchronize(dev->res_stream));
     // was it worth its launch?  A kernel that idled out after a handful of commands was not (see kResidentMinCommands): back off.
     const uint64_t served = dev->res_posts - dev->res_posts_at_start;
     const uint32_t why = __atomic_load_n(&dev->res_mem[17], __ATOMIC_ACQUIRE);

@@ -415,6 +415,13 @@ class VectorModule:
                 if self._h is None:
                     self._ensure(other._env)
                 self._mirror = None                       # overwritten anyway
+                fast = _lib.fast
+                if fast is not None and other._mirror is None:
+                    status = fast.assign(_lib.fn_addr("rq_state_assign"), self._h, other._h)
+                    if status == 0:
+                        return
+                    if status != 1:
+                        _lib.check(status)
                 _lib.call("rq_state_assign", self._h, other._require("VectorState"))
 
             @property
@@ -529,6 +536,15 @@ class VectorModule:
     def observe(self, device, env, params, state, observation, rng):
         """README.md:96 — fills ``observation`` [N, OBSERVATION_DIM] float32 in place
         (``None``: keep it in the env's device buffer)."""
+        fast = _lib.fast
+        if fast is not None and observation is not None and state._mirror is None:      # the README loop's call: no ctypes in between
+            # (csrc/rq_pyfast.c; a state with views handed out goes the ordinary way, which writes them back first)
+            status = fast.observe(_lib.fn_addr("rq_observe"), device._h, env._h, params._h, state._h, observation, rng._h,
+                                  self.N_ENVIRONMENTS, OBSERVATION_DIM)
+            if status == 0:
+                return
+            if status != 1:
+                _lib.check(status)
         ptr = None
         if observation is not None:
             if (observation.dtype != np.float32 or not observation.flags.c_contiguous or
@@ -542,6 +558,14 @@ class VectorModule:
         """README.md:98 — returns the list of per-env dt in seconds.
         ``action`` [N,4] (``None``: the env's device action buffer, e.g. written by
         ``Raptor.evaluate_step_device``)."""
+        fast = _lib.fast
+        if fast is not None and action is not None and next_state._h is not None and state._mirror is None and next_state._mirror is None:
+            status = fast.step(_lib.fn_addr("rq_step"), device._h, env._h, params._h, state._h, action, next_state._h, rng._h,
+                               self.N_ENVIRONMENTS)
+            if status == 0:
+                return [env._step_dt()] * self.N_ENVIRONMENTS
+            if status != 1:
+                _lib.check(status)
         aptr = None
         if action is not None:
             a = np.ascontiguousarray(action, np.float32)

@@ -385,3 +385,58 @@ def test_the_hazard_lint_sees_a_move_behind_a_taken_branch():
                         os.path.join(ROOT, "tests", "golden", "mfma_hazard_bad.s")], capture_output=True, text=True)
     assert r.returncode == 1
     assert "2 hazard(s)" in r.stdout and "bad_prime" in r.stdout and "good_prime" not in r.stdout
+
+
+def test_the_python_helpers_direct_calls_match_the_header_and_decline_what_they_do_not_take(tmp_path):
+    """raptor_amd/csrc/rq_pyfast.c calls four entry points of the library by ADDRESS, with the signatures written out in that file
+    (it does not link against the library).  Held to include/raptor_quad.h here: a C file that assigns the header's functions to the
+    helper's function-pointer types must compile without a diagnostic.  And the helper declines - status 1, nothing called - whatever
+    the fast path does not take: missing handles, another dtype, a strided observation buffer, a wrong shape."""
+    import re
+    import subprocess
+    src = open(os.path.join(ROOT, "raptor_amd", "csrc", "rq_pyfast.c")).read()
+    typedefs = re.findall(r"^typedef int \(\*\w+_fn\)\([^;]*\);", src, re.M)
+    assert len(typedefs) == 4
+    c = tmp_path / "sig.c"
+    c.write_text('#include <stdint.h>\n#include "raptor_quad.h"\n' + "\n".join(typedefs).replace("void*", "void *") + """
+/* the helper's types hold the handles as void pointers: the header's functions converted to them must differ in pointee types only */
+int main(void) {
+    observe_fn a = (observe_fn)rq_observe; evaluate_step_fn b = (evaluate_step_fn)rq_policy_evaluate_step;
+    step_fn c = (step_fn)rq_step; assign_fn d = (assign_fn)rq_state_assign;
+    _Static_assert(sizeof(int (*)(rq_device*, rq_env*, const rq_params*, const rq_state*, float*, rq_rng*)) == sizeof(observe_fn), "");
+    int (*pa)(rq_device*, rq_env*, const rq_params*, const rq_state*, float*, rq_rng*) = rq_observe;
+    int (*pb)(rq_policy*, rq_env*, const float*, uint32_t, uint32_t, float*) = rq_policy_evaluate_step;
+    int (*pc)(rq_device*, rq_env*, const rq_params*, const rq_state*, const float*, rq_state*, rq_rng*, float*) = rq_step;
+    int (*pd)(rq_state*, const rq_state*) = rq_state_assign;
+    return (a && b && c && d && pa && pb && pc && pd) ? 0 : 1;
+}
+""")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-c", str(c), "-I", os.path.join(ROOT, "include"), "-o", str(tmp_path / "sig.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the argument lists the helper's typedefs declare, against the header's, position by position (pointer-ness and integer width)
+    hdr = open(os.path.join(ROOT, "include", "raptor_quad.h")).read()
+    for name, td in zip(("rq_observe", "rq_policy_evaluate_step", "rq_step", "rq_state_assign"), typedefs):
+        decl = re.search(r"RQ_API int %s\(([^;]*)\);" % name, hdr, re.S).group(1)
+        want = ["*" in a or "uint32_t" not in a for a in decl.split(",")]
+        got = ["*" in a for a in td[td.index(")(") + 2:-2].split(",")]
+        assert len(want) == len(got) and all(w == g for w, g in zip(want, got)), (name, decl, td)
+    from raptor_amd import _lib
+    if _lib.fast is None:
+        pytest.skip("the helper is not built here")
+    import ctypes as C
+    f, obs, act = _lib.fast, np.zeros((8, 26), np.float32), np.zeros((8, 4), np.float32)
+    h, none = C.c_void_p(4096), C.c_void_p(0)
+    assert f.NOT_HANDLED == 1
+    assert f.observe(1, none, h, h, h, obs, h, 8, 26) == 1 and f.observe(1, h, h, None, h, obs, h, 8, 26) == 1
+    assert f.observe(1, h, h, h, h, obs[:, :22], h, 8, 26) == 1 and f.observe(1, h, h, h, h, obs.astype(np.float64), h, 8, 26) == 1
+    assert f.observe(1, h, h, h, h, obs, h, 9, 26) == 1 and f.observe(1, h, h, h, h, [[0.0] * 26] * 8, h, 8, 26) == 1
+    ro = obs.copy(); ro.setflags(write=False)
+    assert f.observe(1, h, h, h, h, ro, h, 8, 26) == 1
+    assert f.step(1, h, h, h, h, act[:, :3], h, h, 8) == 1 and f.step(1, h, h, h, h, act, None, h, 8) == 1
+    assert f.step(1, h, h, h, h, np.zeros((8, 8), np.float32)[:, :4], h, h, 8) == 1
+    assert f.evaluate_step(1, None, obs[:, :22], act, 22) == 1 and f.evaluate_step(1, h, obs[:, :21], act, 22) == 1
+    assert f.evaluate_step(1, h, obs[:, :22], act[:4], 22) == 1 and f.evaluate_step(1, h, obs[:, ::2], act, 13) == 1
+    assert f.assign(1, h, None) == 1 and f.assign(1, none, h) == 1
+    with pytest.raises(TypeError):
+        f.observe(1, h)
