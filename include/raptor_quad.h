@@ -521,8 +521,12 @@ RQ_API int rq_device_set_speculation(rq_device* dev, int enable);
  * took is replayed as launches; kernels that idle out having served fewer than 8 commands are started 8, 16, ... 1 024 steps apart.
  * A loop paced like README.md:94-101 (10 ms of sleep per step) keeps its launches.  Results never depend on any of this.  enable = 0
  * switches it off for this device (RQ_NO_RESIDENT in the environment: off at rq_device_create); either value clears the back-off.
+ * The same executor serves a policy ALONE: rq_policy_evaluate_step with host rows (env = NULL), at most 16 of them, an fp32 policy
+ * without a sampling stage, called three times in a row within 200 us of one another (README.md:17-25, a caller with a simulator of
+ * its own) - from then on the rows are commands to a resident wave that keeps the hidden state in registers (and in the policy's buffer,
+ * every step); same lifecycle, same bits as the launch.  One resident kernel per device at a time, of either kind.
  * rq_device_get_resident: any out pointer may be NULL; `running` = a kernel is on the device now; starts / commands / replays count
- * kernels started, commands posted, and commands replayed as launches since the device was created. */
+ * kernels started, commands posted, and commands replayed as launches since the device was created (both kinds). */
 RQ_API int rq_device_set_resident(rq_device* dev, int enable);
 RQ_API int rq_device_get_resident(const rq_device* dev, int* enabled, int* running, uint64_t* starts, uint64_t* commands, uint64_t* replays);
 /* Six device timestamps (100 MHz ticks) of the last command the resident kernel finished: command seen, action rows read, env stepped

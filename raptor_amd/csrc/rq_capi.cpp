@@ -180,7 +180,7 @@ using namespace rqh;
 namespace rq {
 int resident_scope_hook(const rq_device* dev_) {
     rq_device* dev = const_cast<rq_device*>(dev_);
-    dev->res_streak = 0;
+    dev->res_streak = 0; dev->res_pol_streak = 0;
     return dev->res_running ? resident_retire(dev) : RQ_OK;
 }
 int device_ordinal(const rq_device* dev) { return dev->ordinal; }
@@ -263,6 +263,7 @@ RQ_API int rq_device_destroy(rq_device* dev) {
     if (dev->res_cmd_on_device && dev->res_cmd_mem) (void)hipFree(dev->res_cmd_mem);
     if (dev->res_mem) (void)hipHostFree(dev->res_mem);
     delete dev->res_cmd;
+    delete dev->res_pol_cmd;
     if (dev->stream) { (void)hipStreamSynchronize(dev->stream); (void)hipStreamDestroy(dev->stream); }
     if (dev->ev_start) (void)hipEventDestroy(dev->ev_start);
     if (dev->ev_stop) (void)hipEventDestroy(dev->ev_stop);

@@ -1,5 +1,7 @@
 // rq_capi_policy.cpp - foundation_policy.Raptor behind the C ABI (README.md:19-24,48,94,97; checkpoint.h:34-194): create, the optional
 // Standardize / SampleAndSquash stages, reset, evaluate_step (with the small-batch loop's speculation hit), evaluate_sequence, selftest.
+#include <emmintrin.h>
+
 #include "rq_objects.hpp"
 
 namespace rqh {
@@ -264,8 +266,79 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
         }
         dev->last_policy = pol;         // the policy rq_step will speculate with
     }
+    // ---- the policy alone, at most 16 rows, called again and again (README.md:17-25: a caller with a simulator of its own): from the
+    // third call in a row on - each within 200 us of the one before, nothing else asked of the device in between - the rows go to a
+    // wave that stays on the device (k_resident_policy) instead of into a launch.  Same lifecycle as the loop's executor
+    // (rq_capi_vector.cpp resident_*): retired before anything else touches the device, replayed as a launch if it had left.
+    const bool pol_eligible = dev->res_enabled && observation && action && !env && batch <= rq::kResidentPolicyBatch &&
+                              pol->precision == RQ_POLICY_FP32 && pol->sas_mode == RQ_SAS_OFF;
+    uint64_t now_ns = 0;
+    uint32_t streak = 0;
+    if (pol_eligible) {
+        now_ns = host_now_ns();
+        streak = now_ns - dev->res_pol_last_ns < kResidentMaxGapNs ? dev->res_pol_streak + 1 : 1;
+        dev->res_pol_last_ns = now_ns;
+    }
+    const bool ready = pol_eligible && pol->batch == batch && pol->hidden && !pol->needs_reset;      // nothing to size or fill
+    const bool bound = ready && dev->res_running && dev->res_policy_mode && dev->res_policy == pol && dev->res_pol_batch == batch &&
+                       dev->res_packed == packed_of(pol) && dev->res_pol_hidden == pol->hidden &&
+                       now_ns - dev->res_last_post_ns < dev->res_host_idle_ns && now_ns - dev->res_born_ns < dev->res_host_life_ns;
+    if (dev->res_running && !bound) { rc = resident_retire(dev); if (rc) return rc; }
+    bool resident = ready && (bound || streak >= kResidentStreak);
+    if (resident && !dev->res_running && dev->res_backoff_left) { --dev->res_backoff_left; resident = false; }     // rq_objects.hpp kResidentMinCommands
+    if (resident) {
+        rc = ensure_mailbox(dev); if (rc) return rc;
+        rc = ensure_resident_memory(dev); if (rc) return rc;
+        if (!dev->res_running) {
+            RQ_HIP(hipStreamSynchronize(dev->stream));      // the kernel reads the hidden state on a stream of its own
+            rq::ResidentArgs ra{};
+            ra.b = rq::Batch{batch, pol->ld, 0};
+            ra.packed = packed_of(pol); ra.hidden[0] = ra.hidden[1] = pol->hidden; ra.ld_h = pol->ld; ra.pol_act = pol->act;
+            ra.rows_act = dev->mb_out; ra.flag = dev->mb_flag;
+            ra.packet = dev->res_cmd_mem; ra.exited = dev->res_mem + 16; ra.small_rows = dev->res_cmd_mem + 64;
+            ra.launch_id = ++dev->res_launch_id; if (ra.launch_id == 0) ra.launch_id = ++dev->res_launch_id;
+            ra.first_packet = dev->res_packet + 1;
+            ra.idle_ticks = dev->res_idle_ticks; ra.life_ticks = dev->res_life_ticks;
+            if (rq::launch_resident_policy(dev->res_stream, ra) == hipSuccess) {
+                dev->res_running = true; ++dev->res_starts; dev->res_born_ns = host_now_ns(); dev->res_posts_at_start = dev->res_posts;
+                dev->res_policy_mode = true; dev->res_policy = pol; dev->res_env = nullptr; dev->res_pol_batch = batch;
+                dev->res_packed = ra.packed; dev->res_pol_hidden = pol->hidden;
+            } else {
+                (void)hipGetLastError();                    // no resident executor this time: the launch below does the step
+            }
+        }
+        if (dev->res_running) {
+            rc = mailbox_in_free(dev); if (rc) return rc;
+            // the rows twice: compact in the mailbox (what a replay as a launch reads), and - padded to whole 16-byte words, one store
+            // each - in command memory, before the line that announces them
+            uint32_t sum = 0;
+            __m128i* rows = reinterpret_cast<__m128i*>(dev->res_cmd_mem + 64);
+            for (uint32_t i = 0; i < batch; ++i) {
+                alignas(16) float row[rq::kResidentPolicyRow] = {};
+                std::memcpy(row, observation + (size_t)i * obs_stride, RQ_POLICY_INPUT_DIM * sizeof(float));
+                std::memcpy(dev->mb_in + (size_t)i * RQ_POLICY_INPUT_DIM, row, RQ_POLICY_INPUT_DIM * sizeof(float));
+                for (int k = 0; k < RQ_POLICY_INPUT_DIM; ++k) { uint32_t u; std::memcpy(&u, &row[k], 4); sum += u; }
+                for (uint32_t k = 0; k < rq::kResidentPolicyRow / 4; ++k)
+                    _mm_store_si128(rows + (size_t)i * (rq::kResidentPolicyRow / 4) + k, _mm_load_si128(reinterpret_cast<const __m128i*>(row) + k));
+            }
+            const rq::Mailbox mb = mailbox_for(dev, dev->mb_in, RQ_POLICY_INPUT_DIM, dev->mb_out);
+            *dev->res_pol_cmd = PolicyCmd{batch, packed_of(pol), pol->obs, pol->hidden, pol->ld, pol->act, pol->precision,
+                                          sas_of(pol, pol->sas_counter, nullptr, 0), mb};
+            dev->res_pending = true; dev->res_pending_first = dev->res_pending_last = mb.seq;
+            resident_write_packet(dev, 0u, nullptr, nullptr, 0u, mb.seq, sum);
+            dev->res_last_post_ns = host_now_ns();
+            ++dev->res_posts;
+            pol->version = fresh_version();                 // as policy_size does for the launch: the hidden state moves on
+            dev->res_pol_streak = streak;
+            rc = mailbox_wait(dev, mb.seq); if (rc) return rc;      // (a kernel that had left: noticed in there, replayed as the launch)
+            dev->res_pending = false;
+            std::memcpy(action, dev->mb_out, (size_t)batch * RQ_ACTION_DIM * sizeof(float));
+            return RQ_OK;
+        }
+    }
     rc = rq::resident_scope_hook(dev); if (rc) return rc;     // a launch on the stream: the resident executor, if any, goes first
     rc = policy_size(pol, batch); if (rc) return rc;
+    dev->res_pol_streak = streak;                             // (the two calls above are "something else asked of the device": not this one)
     const bool mailbox = batch < kGpuLayoutMinEnvs && (observation || action);
     const float* d_obs; uint32_t ld_obs;
     const float* rows_in = nullptr;

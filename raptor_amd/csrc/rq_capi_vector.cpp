@@ -149,10 +149,16 @@ int resident_gone(rq_device* dev) {
     if (dev->res_pending) {
         dev->res_pending = false;
         const uint32_t f = __atomic_load_n(dev->mb_flag, __ATOMIC_ACQUIRE);
-        if ((int32_t)(f - dev->res_cmd->mb_spec.seq) < 0) {
-            RQ_REQUIRE((int32_t)(f - dev->res_cmd->mb_step.seq) < 0, RQ_ERR_HIP, "the resident executor left in the middle of a command");
+        if ((int32_t)(f - dev->res_pending_last) < 0) {
+            RQ_REQUIRE((int32_t)(f - dev->res_pending_first) < 0, RQ_ERR_HIP, "the resident executor left in the middle of a command");
             ++dev->res_replays;
-            RQ_HIP(launch_step_pair(dev, *dev->res_cmd));
+            if (dev->res_policy_mode) {
+                const PolicyCmd& p = *dev->res_pol_cmd;
+                RQ_HIP(rq::launch_actor_step(dev->stream, p.batch, p.packed, p.obs, p.ld, p.hidden, p.ld, p.act, p.ld, nullptr, p.precision,
+                                             p.sas, p.mb));
+            } else {
+                RQ_HIP(launch_step_pair(dev, *dev->res_cmd));
+            }
         }
     }
     return RQ_OK;
@@ -161,7 +167,7 @@ int resident_gone(rq_device* dev) {
 // wait until the command posted last has been consumed (its first sequence number published) or the kernel has left
 int resident_drain(rq_device* dev) {
     if (!dev->res_running || !dev->res_pending) return RQ_OK;
-    const int rc = mailbox_wait(dev, dev->res_cmd->mb_step.seq);
+    const int rc = mailbox_wait(dev, dev->res_pending_first);
     if (rc == RQ_OK && dev->res_running) dev->res_pending = false;
     return rc;
 }
@@ -207,8 +213,8 @@ int resident_retire(rq_device* dev) {
 int ensure_resident_memory(rq_device* dev) {
     if (dev->res_mem) return RQ_OK;
     void* mem = nullptr;
-    RQ_HIP(hipHostMalloc(&mem, 1024, hipHostMallocDefault));        // [0..15] command line, [16] exited, [32..43] timing, [64..] small action rows
-    std::memset(mem, 0, 1024);
+    RQ_HIP(hipHostMalloc(&mem, 4096, hipHostMallocDefault));        // [0..15] command line, [16] exited, [17] why, [32..43] timing, [64..] the rows that
+    std::memset(mem, 0, 4096);                                       // travel beside a command (12 x 4 action dwords; 16 x 24 observation dwords)
     const hipError_t e = hipStreamCreateWithFlags(&dev->res_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipHostFree(mem); RQ_HIP(e); }
     dev->res_mem = static_cast<uint32_t*>(mem);
@@ -232,7 +238,8 @@ int ensure_resident_memory(rq_device* dev) {
         (void)hipGetLastError();
     }
     if (!dev->res_cmd) dev->res_cmd = new (std::nothrow) StepPair();
-    RQ_REQUIRE(dev->res_cmd, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
+    if (!dev->res_pol_cmd) dev->res_pol_cmd = new (std::nothrow) PolicyCmd();
+    RQ_REQUIRE(dev->res_cmd && dev->res_pol_cmd, RQ_ERR_OUT_OF_MEMORY, "host allocation failed");
     return RQ_OK;
 }
 
@@ -365,7 +372,8 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     const uint64_t now_ns = eligible ? host_now_ns() : 0;
     dev->res_streak = !eligible ? 0 : now_ns - dev->res_last_step_ns < kResidentMaxGapNs ? dev->res_streak + 1 : 1;
     if (eligible) dev->res_last_step_ns = now_ns;
-    const bool bound = dev->res_running && dev->res_env == env && dev->res_env_uid == env->uid && dev->res_params == params &&
+    dev->res_pol_streak = 0;
+    const bool bound = dev->res_running && !dev->res_policy_mode && dev->res_env == env && dev->res_env_uid == env->uid && dev->res_params == params &&
                        dev->res_params_version == params->version && dev->res_policy == pol && dev->res_seed == rng->seed &&
                        dev->res_packed == packed_of(pol) && std::memcmp(&dev->res_cfg, &env->cfg, sizeof(rq_env_config)) == 0 &&
                        (env->obs_alt == dev->res_obs[0] || env->obs_alt == dev->res_obs[1]) &&
@@ -435,6 +443,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
             const hipError_t e = rq::launch_resident(dev->res_stream, ra);
             if (e == hipSuccess) {
                 dev->res_running = true; ++dev->res_starts; dev->res_born_ns = host_now_ns(); dev->res_posts_at_start = dev->res_posts;
+                dev->res_policy_mode = false;
                 dev->res_env = env; dev->res_env_uid = env->uid; dev->res_params = params; dev->res_params_version = params->version;
                 dev->res_policy = pol; dev->res_cfg = env->cfg; dev->res_seed = rng->seed; dev->res_packed = pair.packed;
                 dev->res_obs[0] = env->obs; dev->res_obs[1] = env->obs_alt; dev->res_hidden[0] = pol->hidden; dev->res_hidden[1] = pol->hidden_alt;
@@ -455,7 +464,7 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
                 for (uint32_t k = 0; k < env->n; ++k) _mm_store_si128(rows + k, _mm_loadu_si128(reinterpret_cast<const __m128i*>(au) + k));
             }
             *dev->res_cmd = pair;
-            dev->res_pending = true;
+            dev->res_pending = true; dev->res_pending_first = pair.mb_step.seq; dev->res_pending_last = pair.mb_spec.seq;
             const uint32_t bits = (env->obs_alt == dev->res_obs[1] ? rq::kRbObsSel : 0u) | (pol->hidden == dev->res_hidden[1] ? rq::kRbHiddenSel : 0u);
             resident_write_packet(dev, bits, pair.state_in, pair.state_out, pair.mb_step.seq, pair.mb_spec.seq, sum);
             dev->res_last_post_ns = host_now_ns();

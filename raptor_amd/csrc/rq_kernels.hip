@@ -790,6 +790,101 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
     }
 }
 
+// The policy alone, for a caller with a simulator of its own (README.md:17-25: `policy.evaluate_step(observation)[0]` a thousand times
+// at batch 1): one wave stays on the device, takes the observation rows of at most 16 envs as commands and answers with the action rows -
+// a PCIe round trip around ~1.5 us of work instead of a launch and its completion (13.9 us per call at batch 1 -> see DESIGN.md section 5).
+// Same protocol as above (command line, checksum over the rows, `exited`), same arithmetic as the launch it replaces
+// (ActorF32T::step_tile0: the bits k_actor_step gives envs 0..15), hidden state resident in registers and stored every step to the
+// policy's buffer (that buffer is what the API shows).  Rows in command memory: [batch][24] floats (22 + 2 of padding: the host writes
+// whole 16-byte words); up to two rows ride in the poll itself (lanes 16..63), more are fetched once the line has been seen.
+__global__ __launch_bounds__(64, 1) void k_resident_policy(ResidentArgs ra) {
+    typedef ActorF32Lean ACTOR;
+    ACTOR actor;
+    actor.template load<1>(ra.packed);
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const uint32_t n = ra.b.n;                 // <= kResidentPolicyBatch
+    const bool valid = lane < n;
+    const uint32_t i = valid ? lane : n - 1;
+    const uint32_t hj = j < n ? j : n - 1;     // tile 0 of the Q layout: lane (q, j) = env j, hidden features 4 q .. 4 q + 3
+    float* hidden = ra.hidden[0];
+    float hq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hq[c] = hidden[(size_t)(4 * q + c) * ra.ld_h + hj];
+    const bool in_poll = n <= 2;               // wave-uniform
+    const uint32_t* poll_at = lane < 16 ? const_cast<const uint32_t*>(ra.packet) + lane : ra.small_rows + (lane - 16);
+    uint32_t expect = ra.first_packet, left_bits = 0;
+    unsigned long long idle_since = (unsigned long long)wall_clock64();
+    const unsigned long long born = idle_since;
+    for (;;) {
+        uint32_t w, bits;
+        float x[22];
+        for (;;) {
+            w = __hip_atomic_load(poll_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t head = __builtin_amdgcn_readlane(w, kRpHead), tail = __builtin_amdgcn_readlane(w, kRpTail);
+            bits = __builtin_amdgcn_readlane(w, kRpBits);
+            if (head == expect && tail == expect) {
+                if (bits & kRbQuit) break;
+                uint32_t sum = 0;
+                if (in_poll) {
+#pragma unroll
+                    for (int c = 0; c < 22; ++c) {
+                        const uint32_t u = (uint32_t)__shfl((int)w, (int)(16 + 24 * i + c));
+                        x[c] = __builtin_bit_cast(float, u);
+                        sum += valid ? u : 0u;
+                    }
+                } else {
+                    uint32_t u[22];
+#pragma unroll
+                    for (int c = 0; c < 22; ++c)
+                        u[c] = __hip_atomic_load(ra.small_rows + 24 * i + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+                    for (int c = 0; c < 22; ++c) { x[c] = __builtin_bit_cast(float, u[c]); sum += valid ? u[c] : 0u; }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+                if (sum == (uint32_t)__builtin_amdgcn_readlane(w, kRpChecksum)) break;      // else: rows not all there yet - look again
+            }
+            const unsigned long long now = (unsigned long long)wall_clock64();
+            if (now - idle_since > ra.idle_ticks || now - born > ra.life_ticks) {
+                bits = kRbQuit | (now - born > ra.life_ticks ? kRbLeftOld : kRbLeftIdle);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (bits & kRbQuit) { left_bits = bits; break; }
+        const uint32_t seq = __builtin_amdgcn_readlane(w, kRpSeqSpec);
+        if (!valid) {
+#pragma unroll
+            for (int c = 0; c < 22; ++c) x[c] = 0.0f;                 // lanes past the batch feed the matrix cores zeros
+        }
+        float a[4];
+        actor.step_tile0(x, hq, a);
+        if (j < n) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hidden[(size_t)(4 * q + c) * ra.ld_h + j] = hq[c];
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ra.rows_act[(size_t)i * 4 + c] = a[c]; field(ra.pol_act, c, ra.ld_h)[i] = a[c]; }
+        }
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(ra.flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        expect += 1;
+        idle_since = (unsigned long long)wall_clock64();
+    }
+    __threadfence_system();
+    if (lane == 0) {
+        ra.exited[1] = left_bits & (kRbLeftIdle | kRbLeftOld);      // why: 0 = told to
+        __hip_atomic_store(ra.exited, ra.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_resident_policy(hipStream_t s, const ResidentArgs& ra) {
+    if (ra.b.n == 0 || ra.b.n > kResidentPolicyBatch || ra.small_rows == nullptr) return hipErrorInvalidValue;
+    k_resident_policy<<<1, 64, 0, s>>>(ra);
+    return hipGetLastError();
+}
+
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra) {
     const uint32_t waves = (ra.b.n + 63u) / 64u;
     if (ra.b.n == 0 || waves > 4) return hipErrorInvalidValue;

@@ -121,8 +121,14 @@ constexpr uint32_t kResidentSmallEnvs = 12;      // 4 n action dwords fit the 48
 enum ResidentBits : uint32_t { kRbObsSel = 1u, kRbHiddenSel = 2u, kRbQuit = 4u,
                                kRbLeftIdle = 8u, kRbLeftOld = 16u };      // set by the kernel itself: why it left (exited[1])
 
+constexpr uint32_t kResidentPolicyBatch = 16;    // the policy-only executor: one 16-env tile
+constexpr uint32_t kResidentPolicyRow = 24;      // floats per observation row in command memory (22 + padding to whole 16-byte words)
+
 // one workgroup of ceil(n / 64) <= 4 waves on stream s; returns at once, the kernel stays until told to quit or idle for idle_ticks
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& ra);
+// the policy alone (rq_policy_evaluate_step with host rows, batch <= kResidentPolicyBatch): uses packed, hidden[0] (in place), ld_h,
+// pol_act, small_rows (observation rows [n][kResidentPolicyRow] behind the command line), rows_act, flag, packet, exited; b.n = batch
+hipError_t launch_resident_policy(hipStream_t s, const ResidentArgs& ra);
 
 // vector.sample_initial_parameters (README.md:60)
 hipError_t launch_sample_params(hipStream_t s, Batch b, SampleCfg c, uint64_t seed, uint32_t epoch, float* params);

@@ -154,6 +154,15 @@ struct rq_device {
     bool res_timing = false;             // RQ_RESIDENT_TIMING in the environment: the kernel records its timestamps (rq_device_get_resident_timing)
     bool res_pending = false;            // res_cmd was posted and is not known to have been consumed
     struct StepPair* res_cmd = nullptr;  // the command most recently posted: what a replay as launches needs
+    // The same executor serving a policy ALONE (rq_policy_evaluate_step with host rows, at most 16 of them: README.md:17-25, a caller
+    // with a simulator of its own; kernel: k_resident_policy).  One kernel per device at a time, of either kind.
+    bool res_policy_mode = false;        // the running kernel is k_resident_policy
+    uint32_t res_pol_streak = 0;         // eligible rq_policy_evaluate_step calls in a row (each within kResidentMaxGapNs of the one before)
+    uint64_t res_pol_last_ns = 0;        // host clock of the last of them
+    uint32_t res_pol_batch = 0;          // the batch the running kernel was started for
+    float* res_pol_hidden = nullptr;     // the hidden-state buffer it keeps up to date
+    uint32_t res_pending_first = 0, res_pending_last = 0;   // the posted command's sequence numbers: the first one published = consumed
+    struct PolicyCmd* res_pol_cmd = nullptr;                // the policy command most recently posted (replay)
 };
 constexpr uint32_t kSpeculationMissLimit = 4;
 // the two launches of a small-batch step: k_step (+ the next observation) and the speculative policy step on it
@@ -164,6 +173,11 @@ struct StepPair {
     bool spec;
     const float* packed; float* hidden_out; uint32_t ld_h; float* pol_act; int precision; rq::SasArgs sas;
     rq::Mailbox mb_spec; const float* hidden_in;
+};
+
+// the launch of a small-batch policy step on host rows (dev->mb_in -> dev->mb_out): what a policy command replays as
+struct PolicyCmd {
+    uint32_t batch; const float* packed; float* obs; float* hidden; uint32_t ld; float* act; int precision; rq::SasArgs sas; rq::Mailbox mb;
 };
 
 struct rq_rng {
@@ -297,6 +311,10 @@ rq::Mailbox mailbox_for(rq_device* dev, const float* rows_in, uint32_t in_stride
 void mailbox_abort(rq_device* dev, const rq::Mailbox& mb);
 int resident_gone(rq_device* dev);
 int resident_retire(rq_device* dev);
+int ensure_resident_memory(rq_device* dev);
+uint64_t host_now_ns();
+void resident_write_packet(rq_device* dev, uint32_t bits, const float* state_in, float* state_out, uint32_t seq_step, uint32_t seq_spec,
+                           uint32_t checksum);
 
 // ---- rq_capi_policy.cpp ----
 void policy_free_buffers(rq_policy* pol);

@@ -268,3 +268,144 @@ def test_the_loop_at_the_references_batch_beats_its_launches(device):
     off, on = timed(False), timed(True)
     print(f"[README loop, 8 envs, NumPy arrays] launches {off:.2f} us, resident executor {on:.2f} us per iteration")
     assert on < 0.67 * off, (on, off)
+
+
+# ------------------------------------------------------------------ the policy alone (README.md:17-25) ------
+def _policy_loop(device, batch, steps, resident, between=None, seed=0, wide=False, policy=None):
+    """`policy.evaluate_step(observation)` again and again, as a caller with a simulator of its own does (README.md:20-24)
+    -> (actions [steps, batch, 4], final hidden state, resident statistics)."""
+    from raptor_amd.foundation_policy import Raptor
+    device.set_resident(resident)
+    if policy is None:
+        policy = Raptor(device)
+    policy.reset()
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((steps, batch, 26 if wide else 22)).astype(np.float32)
+    before = device.resident()
+    A = []
+    for t in range(steps):
+        A.append(policy.evaluate_step(X[t][:, :22]).copy())       # (wide: rows of 26 floats, the README's observation[:, :22])
+        if between is not None:
+            between(t, policy)
+    after = device.resident()
+    out = (np.array(A), policy.hidden_state(batch).copy(), {k: after[k] - before[k] for k in ("starts", "commands", "replays")})
+    device.set_resident(True)
+    return out
+
+
+@pytest.mark.parametrize("batch,wide", [(1, False), (1, True), (2, True), (3, False), (8, True), (16, False)])
+def test_the_policy_alone_is_bit_identical_with_and_without_the_resident_executor(device, batch, wide):
+    """400 recurrent steps on random rows: every action and the hidden state at the end, with the rows riding in the poll (batch <= 2)
+    and fetched behind the line (up to 16), compact rows and rows of a wider array."""
+    off = _policy_loop(device, batch, 400, False, wide=wide)
+    on = _policy_loop(device, batch, 400, True, wide=wide)
+    assert np.array_equal(off[0].view(np.uint32), on[0].view(np.uint32)) and np.array_equal(off[1].view(np.uint32), on[1].view(np.uint32))
+    assert off[2]["commands"] == 0 and on[2]["commands"] >= 390 and on[2]["replays"] == 0, (off[2], on[2])
+
+
+def test_more_than_sixteen_rows_keep_their_launch(device):
+    on = _policy_loop(device, 17, 30, True)
+    assert on[2]["commands"] == 0 and on[2]["starts"] == 0
+
+
+def test_the_references_known_answers_through_the_resident_policy_executor(device):
+    """checkpoint.h:197-215 and h5:/example: 500 recurrent steps at batch 2, the C selftest's tight loop - which the executor takes over
+    from its third step on - against the reference's own outputs, 1e-5."""
+    from raptor_amd.foundation_policy import Raptor
+    gold = os.path.join(ROOT, "tests", "golden")
+    policy = Raptor(device)
+    for tag in ("h", "h5"):
+        x = np.fromfile(os.path.join(gold, f"kat_{tag}_input.bin"), "<f4").reshape(500, 2, 22)
+        y = np.fromfile(os.path.join(gold, f"kat_{tag}_output.bin"), "<f4").reshape(500, 2, 4)
+        before = device.resident()["commands"]
+        err = policy.selftest(x, y, tolerance=1e-5)
+        assert err < 1e-5 and device.resident()["commands"] - before >= 490, (err, device.resident())
+        assert not device.resident()["running"]          # the selftest's private policy is gone, and its kernel with it
+
+
+def test_whatever_else_touches_the_policy_or_the_device_retires_the_policy_executor_first(device, oracle):
+    """reset(), set_hidden_state(), reading the hidden state, another policy on the same device, a README-loop iteration, a large
+    rollout in between: same results as with launches, and no kernel left on the device afterwards."""
+    from raptor_amd.foundation_policy import Raptor
+    other = Raptor(device)
+    big = World(device, oracle, 4096, seed=3)
+
+    def between(t, policy):
+        if t == 30:
+            assert device.resident()["running"] == device.resident()["enabled"]
+            policy.hidden_state(4)
+            assert not device.resident()["running"]
+        if t == 60:
+            policy.reset()
+        if t == 90:
+            h = policy.hidden_state(4)
+            policy.set_hidden_state(h * np.float32(0.5))
+        if t == 120:
+            other.reset()
+            other.evaluate_step(np.ones((4, 22), np.float32))
+        if t == 150:
+            big.vector.rollout(device, big.env, big.params, big.state, big.policy, big.rng, 5, "fused", True)
+        if 180 <= t < 200:
+            time.sleep(0.0005)                           # a caller that has something else to do between its steps
+    off = _policy_loop(device, 4, 260, False, between)
+    big = World(device, oracle, 4096, seed=3)
+    other = Raptor(device)
+    on = _policy_loop(device, 4, 260, True, between)
+    assert np.array_equal(off[0].view(np.uint32), on[0].view(np.uint32)) and np.array_equal(off[1].view(np.uint32), on[1].view(np.uint32))
+    assert on[2]["starts"] >= 4 and on[2]["replays"] == 0, on[2]
+    device.synchronize()
+    assert not device.resident()["running"]
+
+
+def test_the_policy_alone_and_the_readme_loop_take_turns(device):
+    """One device, one resident kernel at a time, of either kind: a README loop, then the same policy object evaluated alone, then the
+    loop again - each phase bit-identical to itself without the executor."""
+    from raptor_amd.foundation_policy import Raptor
+
+    def phases(resident):
+        out = []
+        out.append(_loop(device, 8, 60, resident)[:6])
+        pol = Raptor(device)
+        out.append(_policy_loop(device, 8, 60, resident, policy=pol)[:2])
+        out.append(_loop(device, 8, 60, resident, seed=1)[:6])
+        out.append(_policy_loop(device, 8, 60, resident, policy=pol, seed=1)[:2])
+        return out
+    off, on = phases(False), phases(True)
+    for a, b in zip(off, on):
+        assert all(np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)) for x, y in zip(a, b))
+
+
+@pytest.mark.timeout(300)
+def test_a_policy_command_the_kernel_never_took_is_replayed_as_a_launch():
+    """Kernels that leave after 20 us of idling and a host that keeps posting to them regardless, with pauses: the rows posted into
+    the void are evaluated by a launch, and nothing differs."""
+    code = r'''
+import sys, time, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import raptor_amd.l2f as l2f
+from test_gpu_resident import _policy_loop
+dev = l2f.Device(0)
+pause = lambda t, p: time.sleep(0.001) if t %% 23 == 3 else None
+on = _policy_loop(dev, 2, 400, True, pause)
+off = _policy_loop(dev, 2, 400, False, pause)
+print("STATS", on[2])
+assert np.array_equal(off[0].view(np.uint32), on[0].view(np.uint32)) and np.array_equal(off[1].view(np.uint32), on[1].view(np.uint32)), "results differ"
+assert on[2]["replays"] >= 5, on[2]
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, RQ_RESIDENT_IDLE_TICKS="2000", RQ_RESIDENT_HOST_IDLE_NS="100000000000", RQ_RESIDENT_HOST_LIFE_NS="100000000000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_the_policy_alone_at_batch_one_beats_its_launch(device):
+    """Wall time per `policy.evaluate_step(observation)` at batch 1 through the Python binding (measured: 5 against 14 us)."""
+    def timed(resident):
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            _policy_loop(device, 1, 2000, resident)
+            t.append((time.perf_counter() - t0) / 2000 * 1e6)
+        return min(t)
+    off, on = timed(False), timed(True)
+    print(f"[policy alone, batch 1, NumPy arrays] launch {off:.2f} us, resident executor {on:.2f} us per call")
+    assert on < 0.67 * off, (on, off)
