@@ -670,6 +670,32 @@ def api_loop_probe(device, n=8, iters=500):
     return out
 
 
+def policy_alone_probe(device, batch=1, calls=2000):
+    """README.md:17-25: `policy.evaluate_step(observation)[0]` inside a caller's own simulator - the policy alone, batch 1, NumPy
+    arrays at every call.  Microseconds per call with the resident policy executor (round 6: k_resident_policy) and as the launch
+    it replaces."""
+    from raptor_amd.foundation_policy import Raptor
+    policy = Raptor(device)
+    X = np.random.default_rng(0).standard_normal((calls + 200, batch, 22)).astype(np.float32)
+    out = {"batch": batch, "calls": calls}
+    for name in ("resident_executor", "launches"):
+        policy.reset()
+        device.set_resident(name == "resident_executor")
+        before = None
+        for t in range(calls + 200):
+            if t == 200:
+                before = device.resident()
+                t0 = time.perf_counter()
+            policy.evaluate_step(X[t])
+        out[name + "_us_per_call"] = round((time.perf_counter() - t0) / calls * 1e6, 2)
+        if name == "resident_executor":
+            after = device.resident()
+            out["commands"] = {k: after[k] - before[k] for k in ("starts", "commands", "replays")}
+        device.synchronize()
+    device.set_resident(True)
+    return out
+
+
 def cpu_baseline(seconds):
     """Oracle (C restatement of the reference semantics; the reference binary is unavailable) on
     this box's host cores: same workload, bounded sample, all OpenMP threads."""
@@ -1479,6 +1505,7 @@ def run_benchmark(args, engine, rank, local_rank, world, dist):
         except Exception as exc:      # noqa: BLE001
             result["native_exchange_1rank"] = {"unavailable": str(exc)}
         result["readme_loop_n8"] = api_loop_probe(device)
+        result["policy_alone_n1"] = policy_alone_probe(device)
         result["readme_loop_n65536_pcie_inclusive"] = api_loop_probe(device, ENVS_PER_GPU, 20)
     if world == 1 and engine.name == "hip":
         result["parity"] = parity_block(engine.device)

@@ -132,6 +132,12 @@ def main(tag):
         "device-resident chain of three launches", f"**{fmt(rl.get('numpy_arrays_us_per_iteration'))}** / {fmt(rl.get('numpy_arrays_launches_us_per_iteration'))} / "
         f"{fmt(rl.get('device_resident_us_per_iteration'))} µs per iteration ({rx.get('commands')} commands to {rx.get('starts')} kernels in "
         f"{rx.get('iterations')} iterations, {rx.get('replays')} replayed)", f"{drv_name}: readme_loop_n8")
+    pl = d.get("policy_alone_n1") or {}
+    if pl:
+        pc = pl.get("commands") or {}
+        row("the policy alone at batch 1 (`policy.evaluate_step(observation)[0]`, README.md:17-25, NumPy arrays every call): resident policy executor / "
+            "the launch it replaces", f"**{fmt(pl.get('resident_executor_us_per_call'))}** / {fmt(pl.get('launches_us_per_call'))} µs per call "
+            f"({pc.get('commands')} commands to {pc.get('starts')} kernels in {pl.get('calls')} calls, {pc.get('replays')} replayed)", f"{drv_name}: policy_alone_n1")
     cb = d.get("cpu_baseline") or {}
     row("CPU baseline: the oracle's C restatement on the GPU box's host cores (a reported baseline, not a target)",
         f"{cb.get('value', 0):.3g} env-steps/s with {cb.get('cores')} threads ({cb.get('host_threads_available')} visible, quota ≈ {fmt(cb.get('effective_cores'))}); "
