@@ -229,7 +229,7 @@ def test_a_caller_that_synchronizes_the_device_every_iteration_is_not_made_to_wa
     print(f"[README loop + hipDeviceSynchronize per iteration] launches {t_off:.1f} us, with the executor enabled {t_on:.1f} us; {on[6]}")
     assert _same(off, on)
     assert 1 <= on[6]["starts"] <= 8 and on[6]["replays"] == 0, on[6]
-    assert t_on < t_off + 10.0, (t_on, t_off)
+    assert t_on < t_off + 25.0, (t_on, t_off)          # (measured: + 4.5 .. 6 us; without the back-off: + 300)
 
 
 @pytest.mark.timeout(300)
