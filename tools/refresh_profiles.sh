@@ -33,5 +33,6 @@ bash tools/teacher_traffic.sh $TAG > $DST/teacher_traffic.log 2>&1; echo "teache
 echo "side rates rc=$?"
 python tools/determinism_soak.py --steps 1500 > $DST/${TAG}_determinism_soak.txt 2>&1; echo "soak rc=$?"
 python tools/foreign_soak.py --reps 30 --json $DST/${TAG}_foreign_soak.json > $DST/${TAG}_foreign_soak.txt 2>&1; echo "foreign soak rc=$?"
+python tools/resident_soak.py --iters 100000 --json $DST/${TAG}_resident_soak.json > $DST/resident_soak.log 2>&1; echo "resident soak rc=$?"
 python tools/cross_stream_soak.py --aggressor f16x2 --reps 30 > $DST/${TAG}_cross_stream_soak.txt 2>&1; echo "cross-stream soak rc=$?"
 ls -la $DST
