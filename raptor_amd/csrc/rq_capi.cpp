@@ -249,6 +249,9 @@ RQ_API int rq_device_create(int ordinal, rq_device** out) {
     if (const char* v = std::getenv("RQ_RESIDENT_LIFE_TICKS")) d->res_life_ticks = std::strtoull(v, nullptr, 10);
     if (const char* v = std::getenv("RQ_RESIDENT_HOST_IDLE_NS")) d->res_host_idle_ns = std::strtoull(v, nullptr, 10);
     if (const char* v = std::getenv("RQ_RESIDENT_HOST_LIFE_NS")) d->res_host_life_ns = std::strtoull(v, nullptr, 10);
+    // the resident executor's stream and command memory now, not inside somebody's loop: creating a second stream costs ~8 ms (a
+    // hardware queue of its own); a failure here is not the device's - the loop tries again when it first wants them
+    if (d->res_enabled && ensure_resident_memory(d) != RQ_OK) (void)hipGetLastError();
     device_registry(d, +1);
     *out = d;
     return RQ_OK;
