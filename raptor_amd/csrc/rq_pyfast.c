@@ -4,7 +4,7 @@
  *                      protocol through ctypes takes 0.4 us and refuses strided or read-only arrays (the README loop hands
  *                      `observation[:, :22]`, a strided view, to evaluate_step: README.md:97); here it is one PyObject_GetBuffer -
  *                      0.06 us for any array.
- *  observe / evaluate_step / step / assign
+ *  observe / evaluate_step / step / assign / rollout
  *                      the four calls of the reference's loop (README.md:96-99) without the ctypes foreign-call machinery: an
  *                      eight-argument call through ctypes costs 0.7 us before the library sees it, and at the reference's own batch
  *                      (8 envs) the library's own work per call is of that order (DESIGN.md section 5 "Resident executor").  Each takes the
@@ -16,7 +16,7 @@
  *
  * Optional: without this module the veneer falls back to ctypes for everything.  Nothing of the rollout path lives here -
  * libraptor_quad.so does not know Python, and this file does not link against it (signatures: include/raptor_quad.h rq_observe,
- * rq_policy_evaluate_step, rq_step, rq_state_assign; tests/test_capi_cpu.py holds them to the header). */
+ * rq_policy_evaluate_step, rq_step, rq_state_assign, rq_rollout; tests/test_capi_cpu.py holds them to the header). */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
@@ -27,6 +27,7 @@ typedef int (*observe_fn)(void*, void*, const void*, const void*, float*, void*)
 typedef int (*evaluate_step_fn)(void*, void*, const float*, uint32_t, uint32_t, float*);
 typedef int (*step_fn)(void*, void*, const void*, const void*, const float*, void*, void*, float*);
 typedef int (*assign_fn)(void*, const void*);
+typedef int (*rollout_fn)(void*, void*, const void*, void*, void*, void*, uint32_t, int, uint32_t);
 
 static PyObject* rq_address(PyObject* self, PyObject* obj) {
     Py_buffer view;
@@ -146,6 +147,27 @@ static PyObject* rq_fast_assign(PyObject* self, PyObject* const* a, Py_ssize_t n
     return PyLong_FromLong(((assign_fn)fn)(dst, src));     /* host-side bookkeeping only: the GIL stays */
 }
 
+/* rollout(fn, device, env, params, state, policy, rng, n_steps, mode, flags) -> status: rq_rollout, the call inside bench.py's timed
+ * region (one launch per region of 20 steps: the call itself is 5 % of it) */
+static PyObject* rq_fast_rollout(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+    (void)self;
+    if (nargs != 10) { PyErr_SetString(PyExc_TypeError, "rollout takes 10 arguments"); return NULL; }
+    void *fn, *dev, *env, *params, *state, *policy, *rng;
+    if (!handle_of(a[0], &fn) || !handle_of(a[1], &dev) || !handle_of(a[2], &env) || !handle_of(a[3], &params) ||
+        !handle_of(a[4], &state) || !handle_of(a[5], &policy) || !handle_of(a[6], &rng))
+        return not_handled();
+    const unsigned long n_steps = PyLong_AsUnsignedLong(a[7]);
+    const long mode = PyLong_AsLong(a[8]);
+    const unsigned long flags = PyLong_AsUnsignedLong(a[9]);
+    if (PyErr_Occurred()) return NULL;
+    if (n_steps > 0xFFFFFFFFul || flags > 0xFFFFFFFFul || mode < -0x7FFFFFFFl || mode > 0x7FFFFFFFl) return not_handled();
+    int status;
+    Py_BEGIN_ALLOW_THREADS
+    status = ((rollout_fn)fn)(dev, env, params, state, policy, rng, (uint32_t)n_steps, (int)mode, (uint32_t)flags);
+    Py_END_ALLOW_THREADS
+    return PyLong_FromLong(status);
+}
+
 static PyMethodDef methods[] = {
     {"address", rq_address, METH_O, "address(array) -> int: where the array's first element lives (any buffer, strided or read-only)"},
     {"observe", (PyCFunction)(void (*)(void))rq_fast_observe, METH_FASTCALL, "rq_observe with a host array; -> status, 1 = not handled"},
@@ -153,6 +175,7 @@ static PyMethodDef methods[] = {
      "rq_policy_evaluate_step with host arrays; -> status, 1 = not handled"},
     {"step", (PyCFunction)(void (*)(void))rq_fast_step, METH_FASTCALL, "rq_step with a host action array; -> status, 1 = not handled"},
     {"assign", (PyCFunction)(void (*)(void))rq_fast_assign, METH_FASTCALL, "rq_state_assign; -> status, 1 = not handled"},
+    {"rollout", (PyCFunction)(void (*)(void))rq_fast_rollout, METH_FASTCALL, "rq_rollout; -> status, 1 = not handled"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_rq_fast", "fast helpers of the raptor_amd ctypes veneer", -1, methods,

@@ -589,6 +589,14 @@ class VectorModule:
         """The loop body README.md:95-99, ``n_steps`` times, entirely on the device; with
         ``trajectory`` every transition is also appended to that buffer."""
         m = {"fused": ROLLOUT_FUSED, "chained": ROLLOUT_CHAINED}[mode]
+        fast = _lib.fast
+        if fast is not None and trajectory is None and state._mirror is None and hasattr(fast, "rollout"):
+            status = fast.rollout(_lib.fn_addr("rq_rollout"), device._h, env._h, params._h, state._h, policy._handle(device), rng._h,
+                                  int(n_steps), m, ROLLOUT_AUTORESET if autoreset else 0)
+            if status == 0:
+                return
+            if status != 1:
+                _lib.check(status)
         args = (device._h, env._require("environment"), params._require("VectorParameters"),
                 state._require("VectorState"), policy._handle(device), rng._require("rng"), int(n_steps), m,
                 ROLLOUT_AUTORESET if autoreset else 0)

@@ -396,19 +396,20 @@ def test_the_python_helpers_direct_calls_match_the_header_and_decline_what_they_
     import subprocess
     src = open(os.path.join(ROOT, "raptor_amd", "csrc", "rq_pyfast.c")).read()
     typedefs = re.findall(r"^typedef int \(\*\w+_fn\)\([^;]*\);", src, re.M)
-    assert len(typedefs) == 4
+    assert len(typedefs) == 5
     c = tmp_path / "sig.c"
     c.write_text('#include <stdint.h>\n#include "raptor_quad.h"\n' + "\n".join(typedefs).replace("void*", "void *") + """
 /* the helper's types hold the handles as void pointers: the header's functions converted to them must differ in pointee types only */
 int main(void) {
     observe_fn a = (observe_fn)rq_observe; evaluate_step_fn b = (evaluate_step_fn)rq_policy_evaluate_step;
-    step_fn c = (step_fn)rq_step; assign_fn d = (assign_fn)rq_state_assign;
+    step_fn c = (step_fn)rq_step; assign_fn d = (assign_fn)rq_state_assign; rollout_fn e = (rollout_fn)rq_rollout;
     _Static_assert(sizeof(int (*)(rq_device*, rq_env*, const rq_params*, const rq_state*, float*, rq_rng*)) == sizeof(observe_fn), "");
     int (*pa)(rq_device*, rq_env*, const rq_params*, const rq_state*, float*, rq_rng*) = rq_observe;
     int (*pb)(rq_policy*, rq_env*, const float*, uint32_t, uint32_t, float*) = rq_policy_evaluate_step;
     int (*pc)(rq_device*, rq_env*, const rq_params*, const rq_state*, const float*, rq_state*, rq_rng*, float*) = rq_step;
     int (*pd)(rq_state*, const rq_state*) = rq_state_assign;
-    return (a && b && c && d && pa && pb && pc && pd) ? 0 : 1;
+    int (*pe)(rq_device*, rq_env*, const rq_params*, rq_state*, rq_policy*, rq_rng*, uint32_t, int, uint32_t) = rq_rollout;
+    return (a && b && c && d && e && pa && pb && pc && pd && pe) ? 0 : 1;
 }
 """)
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-c", str(c), "-I", os.path.join(ROOT, "include"), "-o", str(tmp_path / "sig.o")],
@@ -416,9 +417,9 @@ int main(void) {
     assert r.returncode == 0, r.stderr
     # the argument lists the helper's typedefs declare, against the header's, position by position (pointer-ness and integer width)
     hdr = open(os.path.join(ROOT, "include", "raptor_quad.h")).read()
-    for name, td in zip(("rq_observe", "rq_policy_evaluate_step", "rq_step", "rq_state_assign"), typedefs):
+    for name, td in zip(("rq_observe", "rq_policy_evaluate_step", "rq_step", "rq_state_assign", "rq_rollout"), typedefs):
         decl = re.search(r"RQ_API int %s\(([^;]*)\);" % name, hdr, re.S).group(1)
-        want = ["*" in a or "uint32_t" not in a for a in decl.split(",")]
+        want = ["*" in a for a in decl.split(",")]
         got = ["*" in a for a in td[td.index(")(") + 2:-2].split(",")]
         assert len(want) == len(got) and all(w == g for w, g in zip(want, got)), (name, decl, td)
     from raptor_amd import _lib
@@ -438,5 +439,6 @@ int main(void) {
     assert f.evaluate_step(1, None, obs[:, :22], act, 22) == 1 and f.evaluate_step(1, h, obs[:, :21], act, 22) == 1
     assert f.evaluate_step(1, h, obs[:, :22], act[:4], 22) == 1 and f.evaluate_step(1, h, obs[:, ::2], act, 13) == 1
     assert f.assign(1, h, None) == 1 and f.assign(1, none, h) == 1
+    assert f.rollout(1, h, h, h, h, None, h, 20, 0, 1) == 1 and f.rollout(1, h, h, h, h, h, h, 1 << 40, 0, 1) == 1
     with pytest.raises(TypeError):
         f.observe(1, h)
