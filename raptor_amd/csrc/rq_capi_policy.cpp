@@ -276,8 +276,11 @@ RQ_API int rq_policy_evaluate_step(rq_policy* pol, rq_env* env, const float* obs
     uint32_t streak = 0;
     if (pol_eligible) {
         now_ns = host_now_ns();
-        streak = now_ns - dev->res_pol_last_ns < kResidentMaxGapNs ? dev->res_pol_streak + 1 : 1;
-        dev->res_pol_last_ns = now_ns;
+        // in a row = the same policy at the same batch: two policies evaluated in turns (a student and a teacher on the same rows)
+        // would otherwise retire each other's kernel call after call
+        streak = now_ns - dev->res_pol_last_ns < kResidentMaxGapNs && dev->res_pol_last == pol && dev->res_pol_last_batch == batch
+                     ? dev->res_pol_streak + 1 : 1;
+        dev->res_pol_last_ns = now_ns; dev->res_pol_last = pol; dev->res_pol_last_batch = batch;
     }
     const bool ready = pol_eligible && pol->batch == batch && pol->hidden && !pol->needs_reset;      // nothing to size or fill
     const bool bound = ready && dev->res_running && dev->res_policy_mode && dev->res_policy == pol && dev->res_pol_batch == batch &&

@@ -370,8 +370,8 @@ RQ_API int rq_step(rq_device* dev, rq_env* env, const rq_params* params, const r
     const bool eligible = dev->res_enabled && pol && env->obs_alt && env->n <= kResidentMaxEnvs && next_state != state && !state->exposed &&
                           pol->precision == RQ_POLICY_FP32 && pol->sas_mode == RQ_SAS_OFF;
     const uint64_t now_ns = eligible ? host_now_ns() : 0;
-    dev->res_streak = !eligible ? 0 : now_ns - dev->res_last_step_ns < kResidentMaxGapNs ? dev->res_streak + 1 : 1;
-    if (eligible) dev->res_last_step_ns = now_ns;
+    dev->res_streak = !eligible ? 0 : now_ns - dev->res_last_step_ns < kResidentMaxGapNs && dev->res_last_step_env == env->uid ? dev->res_streak + 1 : 1;
+    if (eligible) { dev->res_last_step_ns = now_ns; dev->res_last_step_env = env->uid; }      // (in a row = the same env: two loops taking turns keep their launches)
     dev->res_pol_streak = 0;
     const bool bound = dev->res_running && !dev->res_policy_mode && dev->res_env == env && dev->res_env_uid == env->uid && dev->res_params == params &&
                        dev->res_params_version == params->version && dev->res_policy == pol && dev->res_seed == rng->seed &&

@@ -141,6 +141,7 @@ struct rq_device {
     uint64_t res_last_post_ns = 0;       // host clock of the last command: a kernel idle for too long may be leaving, it is not posted to
     uint64_t res_born_ns = 0;            // host clock at the kernel's launch
     uint64_t res_last_step_ns = 0;       // host clock of the last eligible rq_step (the streak counts steps that follow one another closely)
+    uint64_t res_last_step_env = 0;      // ... and the uid of the env it stepped
     uint64_t res_posts_at_start = 0;     // res_posts when the running kernel was started: what it has served = res_posts - this
     uint32_t res_backoff = 0, res_backoff_left = 0;    // eligible steps still to let pass before another kernel is started
     uint64_t res_idle_ticks = kResidentIdleTicks, res_life_ticks = kResidentLifeTicks;       // RQ_RESIDENT_IDLE_TICKS / _LIFE_TICKS (tests)
@@ -159,6 +160,7 @@ struct rq_device {
     bool res_policy_mode = false;        // the running kernel is k_resident_policy
     uint32_t res_pol_streak = 0;         // eligible rq_policy_evaluate_step calls in a row (each within kResidentMaxGapNs of the one before)
     uint64_t res_pol_last_ns = 0;        // host clock of the last of them
+    const rq_policy* res_pol_last = nullptr; uint32_t res_pol_last_batch = 0;      // ... and whose it was (never dereferenced)
     uint32_t res_pol_batch = 0;          // the batch the running kernel was started for
     float* res_pol_hidden = nullptr;     // the hidden-state buffer it keeps up to date
     uint32_t res_pending_first = 0, res_pending_last = 0;   // the posted command's sequence numbers: the first one published = consumed

@@ -409,3 +409,19 @@ def test_the_policy_alone_at_batch_one_beats_its_launch(device):
     off, on = timed(False), timed(True)
     print(f"[policy alone, batch 1, NumPy arrays] launch {off:.2f} us, resident executor {on:.2f} us per call")
     assert on < 0.67 * off, (on, off)
+
+
+def test_two_policies_evaluated_in_turns_keep_their_launches(device):
+    """A student and a teacher on the same rows, call after call: neither is "called again and again" - no resident kernel is started
+    for one only to be retired by the other (that would cost both a kernel start per call)."""
+    from raptor_amd.foundation_policy import Raptor
+    a, b = Raptor(device), Raptor(device)
+    a.reset(); b.reset()
+    device.set_resident(True)
+    X = np.random.default_rng(1).standard_normal((200, 4, 22)).astype(np.float32)
+    before = device.resident()
+    for t in range(200):
+        ya, yb = a.evaluate_step(X[t]), b.evaluate_step(X[t])
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))        # same weights, same rows, same history
+    after = device.resident()
+    assert after["starts"] == before["starts"] and after["commands"] == before["commands"]
