@@ -107,7 +107,9 @@ def _compile(src, force, src_dir, obj_dir, flags, rewrite):
     is_hip = src.endswith(".hip")
     if not force and not _stale(obj, deps) and (not is_hip or os.path.exists(lst)):
         return obj, False
-    flags = flags + SOURCE_FLAGS.get(src, [])
+    # -cuid: clang derives the id that keeps a unit's internal device symbols apart from the unit's PATH; given by name instead, the
+    # library is the same file wherever the tree is built - and the profiles that cite its sha256 (bench.py rocprof_launch_stats) stay its
+    flags = flags + SOURCE_FLAGS.get(src, []) + [f"-cuid=rq_{stem}"]
     if not is_hip:
         _run([_hipcc()] + flags + ["-x", "hip", "-c", path, "-o", obj])
         return obj, True
