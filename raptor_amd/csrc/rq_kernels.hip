@@ -413,10 +413,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
                                          const float* state, float* __restrict__ action, float* next_state,
                                          const StatsPtrs& st, uint32_t flags, const SampleCfg& sc, uint64_t seed,
                                          float* __restrict__ hidden, const float* __restrict__ weights,
-                                         const Mailbox& mb, const ObsNext& on,
-                                         const float* act_regs = nullptr, float* obs_regs = nullptr) {
-    // act_regs / obs_regs (the resident executor, k_resident_loop): the env's four actions handed over in registers (they are also
-    // filed in `action`), and the 22 policy inputs of the observation this step assembles handed back - nullptr everywhere else
+                                         const Mailbox& mb, const ObsNext& on) {
     if (ROLLOUT && st.frozen[i]) { st.last_done[i] = 4; return; }
     const size_t ld = b.ld;
     const EnvConsts k = make_consts([&](int f) { return field(params, f, ld)[i]; });
@@ -426,10 +423,7 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
     y.load([&](int j) { return field(state, j, ld)[i]; });
 #pragma unroll
     for (int j = 0; j < 6; ++j) f6[j] = field(state, (RQ_S_FORCE + j), ld)[i];
-    if (act_regs != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = act_regs[j]; field(action, j, ld)[i] = a[j]; }
-    } else if (mb.rows_in != nullptr) {      // actions handed over in the host mailbox (kernel argument)
+    if (mb.rows_in != nullptr) {      // actions handed over in the host mailbox (kernel argument)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[j] = mb.rows_in[(size_t)i * mb.in_stride + j]; field(action, j, ld)[i] = a[j]; }
     } else {
@@ -477,10 +471,6 @@ __device__ __forceinline__ void step_env(uint32_t i, const Batch& b, const StepC
         }
 #pragma unroll
         for (int j = 0; j < 22; ++j) o[j] = head[j];
-        if (obs_regs != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 22; ++j) obs_regs[j] = head[j];
-        }
         const float inv = 2.0f / (k.rmax - k.rmin);
         o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
         o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
@@ -521,6 +511,68 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // kernel's lifetime.  The kernel leaves on a QUIT command, or by itself after `idle_ticks` without one (a host that died or went
 // away must not leave a wave spinning), and says so in `exited`; a command it never consumed is replayed by the host as launches
 // (rq_capi_vector.cpp resident_*).  It is never the device stream's business: the host retires it before anything else is enqueued.
+// What a resident wave keeps of its env from command to command: the constants (the parameters cannot change under a running kernel),
+// the state, the disturbance, the statistics.  A command whose input buffer is the one the previous command wrote (the loop's own shape:
+// state.assign(next_state)) loads nothing; any other buffer is loaded as step_env loads it.  Everything is still STORED every step:
+// the buffers are what the API shows.
+struct ResidentEnv {
+    EnvConsts k;
+    QuadState y;
+    float f6[6];
+    Stats st;
+    const float* have_state;         // the buffer whose contents y / f6 hold (wave-uniform)
+};
+
+// step_env<false> for one command of a resident wave, its loads skipped where the registers hold the values: same functions in the
+// same order, same stores (+ the observation rows to pinned memory first: they are what the host waits for).  x: the 22 policy inputs
+// of the observation this step assembles (zeros for lanes past the batch: they feed the matrix cores).
+__device__ __forceinline__ void resident_env_step(const ResidentArgs& ra, ResidentEnv& e, uint32_t i, bool valid, const float* state_in,
+                                                  float* state_out, float* obs_out, const float (&a_in)[4], float (&x)[22]) {
+    const size_t ld = ra.b.ld;
+    if (state_in != e.have_state) {          // wave-uniform: not the buffer the previous command wrote
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        e.y.load([&](int f) { return field(state_in, f, ld)[i]; });
+#pragma unroll
+        for (int f = 0; f < 6; ++f) e.f6[f] = field(state_in, (RQ_S_FORCE + f), ld)[i];
+    }
+#pragma unroll
+    for (int c = 0; c < 22; ++c) x[c] = 0.0f;
+    f32x2 AC01, AC23;
+    const Disturbance ds = make_disturbance(e.k, ra.c.gravity, e.f6);
+    bool term;
+    const float r = step_inplace<false>(ra.c, e.k, ds, e.y, a_in, AC01, AC23, term);
+    if (ra.c.action_history_raw) { AC01 = f32x2{a_in[0], a_in[1]}; AC23 = f32x2{a_in[2], a_in[3]}; }
+    const bool ended = stats_update(ra.c.episode_step_limit, r, term, e.st);
+    float o[RQ_OBSERVATION_DIM];
+    observe_head<false>(e.y, AC01, AC23, NoiseCfg{}, ra.seed, 0u, ra.b.env_offset + i, x);
+#pragma unroll
+    for (int c = 0; c < 22; ++c) o[c] = x[c];
+    const float inv = 2.0f / (e.k.rmax - e.k.rmin);
+    o[22] = fmaf(e.y.R01[0] - e.k.rmin, inv, -1.0f); o[23] = fmaf(e.y.R01[1] - e.k.rmin, inv, -1.0f);
+    o[24] = fmaf(e.y.R23[0] - e.k.rmin, inv, -1.0f); o[25] = fmaf(e.y.R23[1] - e.k.rmin, inv, -1.0f);
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < RQ_OBSERVATION_DIM; ++c) ra.rows_obs[(size_t)i * RQ_OBSERVATION_DIM + c] = o[c];       // what the host waits for first
+#pragma unroll
+        for (int c = 0; c < 4; ++c) field(ra.act, c, ld)[i] = a_in[c];
+        ra.st.last_reward[i] = r;
+        ra.st.last_terminated[i] = term ? 1 : 0;
+        ra.st.last_done[i] = term ? 1 : (ended ? 2 : 0);
+        store_stats(ra.st, i, e.st, ended);
+        e.y.store([&](int f, float v) { field(state_out, f, ld)[i] = v; });
+        field(state_out, (RQ_S_LAST_ACTION + 0), ld)[i] = AC01[0]; field(state_out, (RQ_S_LAST_ACTION + 1), ld)[i] = AC01[1];
+        field(state_out, (RQ_S_LAST_ACTION + 2), ld)[i] = AC23[0]; field(state_out, (RQ_S_LAST_ACTION + 3), ld)[i] = AC23[1];
+#pragma unroll
+        for (int c = 0; c < RQ_OBSERVATION_DIM; ++c) put<kNtObs>(&field(obs_out, c, ld)[i], o[c]);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) field(state_out, (RQ_S_FORCE + f), ld)[i] = e.f6[f];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 22; ++c) x[c] = 0.0f;                 // lanes past the batch feed the matrix cores zeros
+    }
+    e.have_state = state_out;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loop(ResidentArgs ra) {
     typedef ActorF32Lean ACTOR;                 // the build launch_actor_step takes for fp32 policies: the same bits
@@ -534,6 +586,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
     const uint32_t i0 = wave_base + lane;
     const bool valid = i0 < n;
     const uint32_t i = valid ? i0 : n - 1;
+    // (round 6, second half) env constants, state, statistics and the policy's hidden state stay in registers from command to command,
+    // as in k_resident_small below: a command that continues where the previous one stopped loads nothing (README loop at 100 envs:
+    // two dependent trips to memory less per iteration)
+    ResidentEnv e{make_consts([&](int f) { return field(ra.params, f, ra.b.ld)[i]; }), QuadState{}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+                  load_stats(ra.st, i), nullptr};
+    float hQ[4][4] = {};
+    const float* have_hidden = nullptr;
     uint32_t expect = ra.first_packet;
     uint32_t left_bits = 0;                     // why the kernel left (workgroup-uniform)
     unsigned long long idle_since = (unsigned long long)wall_clock64();
@@ -601,24 +660,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES <= 4 ? 1 : 2) void k_resident_loo
         if (rows_bad) { left_bits = kRbLeftIdle; break; }
         const unsigned long long t_rows = (unsigned long long)wall_clock64();
         float x[22];
-#pragma unroll
-        for (int k = 0; k < 22; ++k) x[k] = 0.0f;                        // lanes past the batch feed the matrix cores zeros
-        if (valid) {
-            const Mailbox mb{nullptr, 0u, ra.rows_obs, nullptr, nullptr, 0u};
-            const ObsNext on{obs_out, NoiseCfg{}, 0u, 0u, nullptr};
-            step_env<false>(i, ra.b, ra.c, ra.params, state_in, ra.act, state_out, ra.st, 0u, ra.sc, ra.seed, nullptr, nullptr, mb, on,
-                            a_in, x);
-        }
+        resident_env_step(ra, e, i, valid, state_in, state_out, obs_out, a_in, x);
         const unsigned long long t_stepped = (unsigned long long)wall_clock64();
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(ra.flag, seq_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t_flag1 = (unsigned long long)wall_clock64();
         // the policy on the observation just assembled: what the speculative k_actor_step launch computed
-        float hQ[4][4], a[4];
-        load_hidden_q(hidden_in, ra.ld_h, wave_base, n, hQ);
+        float a[4];
+        if (hidden_in != have_hidden) load_hidden_q(hidden_in, ra.ld_h, wave_base, n, hQ);      // workgroup-uniform
         actor.step(x, hQ, a);
         store_hidden_q(hidden_out, ra.ld_h, wave_base, __builtin_amdgcn_ballot_w64(valid), hQ);
+        have_hidden = hidden_out;
         if (valid) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { field(ra.pol_act, k, ra.ld_h)[i] = a[k]; ra.rows_act[(size_t)i * 4 + k] = a[k]; }
@@ -661,11 +714,8 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
     const bool valid = lane < n;
     const uint32_t i = valid ? lane : n - 1;
     const size_t ld = ra.b.ld;
-    const EnvConsts k = make_consts([&](int f) { return field(ra.params, f, ld)[i]; });      // the parameters cannot change under a running kernel
-    QuadState y{};
-    float f6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    Stats st = load_stats(ra.st, i);
-    const float* have_state = nullptr;         // the buffer whose contents y / f6 hold
+    ResidentEnv e{make_consts([&](int f) { return field(ra.params, f, ld)[i]; }), QuadState{}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+                  load_stats(ra.st, i), nullptr};
     float hq[4] = {0.f, 0.f, 0.f, 0.f};
     const float* have_hidden = nullptr;
     const uint32_t hj = j < n ? j : n - 1;     // tile 0 of the Q layout: lane (q, j) = env j, hidden features 4 q .. 4 q + 3
@@ -708,51 +758,9 @@ __global__ __launch_bounds__(64, 1) void k_resident_small(ResidentArgs ra) {
         float a_in[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) a_in[c] = __builtin_bit_cast(float, (uint32_t)__shfl((int)w, (int)(16 + 4 * i + c)));
-        if (state_in != have_state) {            // wave-uniform: not the buffer the previous command wrote
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            y.load([&](int f) { return field(state_in, f, ld)[i]; });
-#pragma unroll
-            for (int f = 0; f < 6; ++f) f6[f] = field(state_in, (RQ_S_FORCE + f), ld)[i];
-        }
         const unsigned long long t_rows = timed ? (unsigned long long)wall_clock64() : 0ull;
-        // ---- step_env<false>, its loads skipped: same functions in the same order ----
         float x[22];
-#pragma unroll
-        for (int c = 0; c < 22; ++c) x[c] = 0.0f;
-        f32x2 AC01, AC23;
-        const Disturbance ds = make_disturbance(k, ra.c.gravity, f6);
-        bool term;
-        const float r = step_inplace<false>(ra.c, k, ds, y, a_in, AC01, AC23, term);
-        if (ra.c.action_history_raw) { AC01 = f32x2{a_in[0], a_in[1]}; AC23 = f32x2{a_in[2], a_in[3]}; }
-        const bool ended = stats_update(ra.c.episode_step_limit, r, term, st);
-        float o[RQ_OBSERVATION_DIM];
-        observe_head<false>(y, AC01, AC23, NoiseCfg{}, ra.seed, 0u, ra.b.env_offset + i, x);
-#pragma unroll
-        for (int c = 0; c < 22; ++c) o[c] = x[c];
-        const float inv = 2.0f / (k.rmax - k.rmin);
-        o[22] = fmaf(y.R01[0] - k.rmin, inv, -1.0f); o[23] = fmaf(y.R01[1] - k.rmin, inv, -1.0f);
-        o[24] = fmaf(y.R23[0] - k.rmin, inv, -1.0f); o[25] = fmaf(y.R23[1] - k.rmin, inv, -1.0f);
-        if (valid) {
-#pragma unroll
-            for (int c = 0; c < RQ_OBSERVATION_DIM; ++c) ra.rows_obs[(size_t)i * RQ_OBSERVATION_DIM + c] = o[c];       // what the host waits for first
-#pragma unroll
-            for (int c = 0; c < 4; ++c) field(ra.act, c, ld)[i] = a_in[c];
-            ra.st.last_reward[i] = r;
-            ra.st.last_terminated[i] = term ? 1 : 0;
-            ra.st.last_done[i] = term ? 1 : (ended ? 2 : 0);
-            store_stats(ra.st, i, st, ended);
-            y.store([&](int f, float v) { field(state_out, f, ld)[i] = v; });
-            field(state_out, (RQ_S_LAST_ACTION + 0), ld)[i] = AC01[0]; field(state_out, (RQ_S_LAST_ACTION + 1), ld)[i] = AC01[1];
-            field(state_out, (RQ_S_LAST_ACTION + 2), ld)[i] = AC23[0]; field(state_out, (RQ_S_LAST_ACTION + 3), ld)[i] = AC23[1];
-#pragma unroll
-            for (int c = 0; c < RQ_OBSERVATION_DIM; ++c) put<kNtObs>(&field(obs_out, c, ld)[i], o[c]);
-#pragma unroll
-            for (int f = 0; f < 6; ++f) field(state_out, (RQ_S_FORCE + f), ld)[i] = f6[f];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 22; ++c) x[c] = 0.0f;                 // lanes past the batch feed the matrix cores zeros
-        }
-        have_state = state_out;
+        resident_env_step(ra, e, i, valid, state_in, state_out, obs_out, a_in, x);
         const unsigned long long t_stepped = timed ? (unsigned long long)wall_clock64() : 0ull;
         __threadfence_system();
         if (lane == 0) __hip_atomic_store(ra.flag, seq_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
