@@ -505,12 +505,14 @@ __global__ __launch_bounds__(kBlock) void k_step(Batch b, StepCfg c, const float
 // a speculative k_actor_step evaluates the policy on it) - two launches, 19.4 us per iteration against 6.9 us for a native CPU loop.
 // What is left of that is launch + completion.  This kernel removes it: ONE workgroup stays on the device for as long as the host
 // keeps calling step() on the same objects, polls a 64-byte command line in pinned host memory, and for every command does exactly what
-// the two launches did - step_env<false> (actions in from pinned rows, next state, statistics, the next observation to the env's
-// buffer and to pinned rows), then ACTOR::step on that observation (new hidden state to the policy's spare buffer, actions to pinned
+// the two launches did - what step_env<false> does (resident_env_step below: actions in from pinned rows, next state, statistics, the
+// next observation to the env's buffer and to pinned rows), then ACTOR::step on that observation (new hidden state to the policy's spare buffer, actions to pinned
 // rows) - publishing the same two sequence numbers in the same pinned flag.  The policy's operand image is loaded once for the
 // kernel's lifetime.  The kernel leaves on a QUIT command, or by itself after `idle_ticks` without one (a host that died or went
 // away must not leave a wave spinning), and says so in `exited`; a command it never consumed is replayed by the host as launches
 // (rq_capi_vector.cpp resident_*).  It is never the device stream's business: the host retires it before anything else is enqueued.
+// Kernels: k_resident_loop (13 .. 256 envs, 1 - 4 waves), k_resident_small (at most 12 envs), k_resident_policy (the policy alone).
+
 // What a resident wave keeps of its env from command to command: the constants (the parameters cannot change under a running kernel),
 // the state, the disturbance, the statistics.  A command whose input buffer is the one the previous command wrote (the loop's own shape:
 // state.assign(next_state)) loads nothing; any other buffer is loaded as step_env loads it.  Everything is still STORED every step:
