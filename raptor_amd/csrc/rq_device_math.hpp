@@ -824,7 +824,11 @@ struct ActorF32T {
     // run() computes for tile 0 and nothing else - 30 MFMAs instead of 120.  A tile's columns never meet another tile's, and every
     // accumulator chain below is run()'s (bias, W_h h for k = 0..15, then W_i y0 for k = 0..15; layer_2 as run() writes it), so envs
     // 0..15 get the bits the four-tile step gives them.  hq = hQ[0]; lanes 16 j + ... of rows >= 16 of the tiles hold nothing read.
-    __device__ __forceinline__ void step_tile0(const float (&o)[22], float (&hq)[4], float (&a)[4]) const {
+    // between(): called once the recurrent MFMAs (which do not need the observation) are issued and the observation is back from LDS -
+    // the resident executor publishes the env step's rows there: their stores have had that long to land, and the policy's critical
+    // path no longer contains the wait for them.
+    template <class F>
+    __device__ __forceinline__ void step_tile0(const float (&o)[22], float (&hq)[4], float (&a)[4], F&& between) const {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const f32x4 cbni = {W[QW_BNI], W[QW_BNI + 1], W[QW_BNI + 2], W[QW_BNI + 3]};
         float hQ[4][4];
@@ -838,6 +842,8 @@ struct ActorF32T {
         recurrent_tile<0>(hQ, gr, gz, gnh);
 #pragma unroll
         for (int s = 0; s < 6; ++s) X[s] = rd[0][4 * s];
+        __builtin_amdgcn_sched_barrier(0);
+        between();
         __builtin_amdgcn_sched_barrier(0);
         f32x4 y0 = mfma16(W[QW_L0], X[0], zero);
 #pragma unroll
