@@ -437,3 +437,36 @@ def test_sample_and_squash_layer(device, oracle, weights):
     assert np.abs(A["act"]).max() <= 1.0 and A["act"].std() > 0.05
     with pytest.raises(Exception):
         a.policy.evaluate_sequence(np.zeros((3, 300, 22), np.float32))       # deterministic passes reject sampling
+
+
+def test_the_readmes_own_simulator_snippet_as_written(device, oracle, weights):
+    """README.md:17-25: `observation = np.array([[*sim.position, *R(sim.orientation).flatten(), ...]])` is a float64 array of one row,
+    `policy.evaluate_step(observation)[0]` the action; Raptor() takes no device.  Whatever dtype or container the caller builds -
+    float64 array, nested list, float32 array - the policy sees the same float32 rows and answers the same bits, call after call
+    (the third call on goes to the resident policy executor; float64 / list inputs take the converting path in front of it)."""
+    from raptor_amd.foundation_policy import Raptor
+    rng = np.random.default_rng(3)
+    rows = [rng.standard_normal(22) for _ in range(60)]
+    answers = []
+    for kind in ("float64", "list", "float32"):
+        policy = Raptor()                                  # README.md:20: no arguments
+        policy.reset()
+        out = []
+        for r in rows:
+            position, rot, vel, omega, action = r[0:3], r[3:12].reshape(3, 3), r[12:15], r[15:18], r[18:22]
+            observation = np.array([[*position, *rot.flatten(), *vel, *omega, *action]])          # README.md:23 (float64)
+            assert observation.dtype == np.float64 and observation.shape == (1, 22)
+            if kind == "list":
+                observation = observation.tolist()
+            elif kind == "float32":
+                observation = observation.astype(np.float32)
+            a = policy.evaluate_step(observation)[0]       # README.md:24
+            assert a.shape == (4,) and a.dtype == np.float32
+            out.append(a.copy())
+        answers.append(np.array(out))
+    assert np.array_equal(answers[0].view(np.uint32), answers[1].view(np.uint32))
+    assert np.array_equal(answers[0].view(np.uint32), answers[2].view(np.uint32))
+    H = np.tile(weights[2000:2016], (1, 1)).astype(np.float32)
+    for t, r in enumerate(rows):
+        ref = oracle.actor_batch_step(weights, r.astype(np.float32)[None, :], H)
+        assert np.max(np.abs(answers[0][t] - ref[0])) < 1e-5, t
