@@ -156,14 +156,16 @@ class Raptor:
     def evaluate_step(self, observation):
         """README.md:24,97 — one recurrent step; ``observation`` [B, >=22] -> action [B,4]."""
         fast = _lib.fast
-        if fast is not None and self._h is not None and type(observation) is np.ndarray and observation.ndim == 2:
+        if type(observation) is not np.ndarray or observation.dtype != np.float32:
+            observation = np.asarray(observation, np.float32)      # README.md:23 builds a float64 array; lists work too
+        if fast is not None and self._h is not None and observation.ndim == 2:
             act = np.empty((observation.shape[0], POLICY_OUTPUT_DIM), np.float32)      # (no ctypes in between: csrc/rq_pyfast.c)
             status = fast.evaluate_step(_lib.fn_addr("rq_policy_evaluate_step"), self._h, observation, act, POLICY_INPUT_DIM)
             if status == 0:
                 return act
             if status != 1:
                 _lib.check(status)
-        obs = np.asarray(observation, np.float32)
+        obs = observation
         if obs.ndim != 2 or obs.shape[1] < POLICY_INPUT_DIM:
             raise ValueError("observation must be [batch, >=22]")
         if not obs.flags.c_contiguous:
